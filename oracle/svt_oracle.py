@@ -1,0 +1,303 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU fp32 restatement of the reference's singing-transcription forward path, written from the
+numerical recipe in SURVEY.md §9 with plain ``torch`` functional ops (the same ATen op classes the
+reference reaches through HuggingFace ``transformers``: conv1d, group_norm / layer_norm, erf-GELU,
+linear, softmax attention).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import this module; the product path (``svt_speechbrain_amd``) never does
+and fails loudly when the HIP library is missing.
+
+Parity pin: ``tests/golden/*.pt`` were generated in the build container by
+``tests/golden/make_golden.py`` from an *import of the reference itself*
+(``/root/reference/MIR_ST500/huggingface_interface.py`` + HF transformers 5.15.0 eager attention,
+``speechbrain.nnet.linear.Linear``, ``N20EMv2/audio_visual/fusion.py``, ``MIR_ST500/utils.py``,
+``speechbrain/decoders/ctc.py``, ``speechbrain/processing/features.py``) and this oracle is checked
+against them in ``tests/test_oracle_golden.py`` (CPU, ``-m "not gpu"``).  The reference holds no golden
+vectors of its own for the encoder / fusion / frame2note; its doctest known-answers for
+``ctc_greedy_decode``/``filter_ctc_output``/``spectral_magnitude`` are included in the same test file.
+
+Reference anchors (file:line relative to /root/reference, ``HF:`` = transformers
+``models/wav2vec2/modeling_wav2vec2.py``):
+  * wrapper forward            MIR_ST500/huggingface_interface.py:279-297
+  * conv feature extractor     HF:254-323, 382-419
+  * feature projection         HF:422-434  (HuBERT: modeling_hubert.py:216-232)
+  * positional conv            HF:326-379
+  * encoder (post-/pre-LN)     HF:575-654, 657-802 ; attention HF:438-548 ; FFN HF:551-572
+  * frame head                 speechbrain/nnet/linear.py:63-76 ; slicing MIR_ST500/train_audio_ssl.py:41-46
+  * per-frame decode           MIR_ST500/train_audio_ssl.py:93-100
+  * frame2note                 MIR_ST500/utils.py:82-149
+  * RCA fusion                 N20EMv2/audio_visual/fusion.py:54-79,137-183,192-210
+  * ctc greedy                 speechbrain/decoders/ctc.py:297-383
+  * Fbank chain                speechbrain/lobes/features.py:126-143, processing/features.py:133-188,327-356,490-712
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# audio encoder
+# ------------------------------------------------------------------------------------------------
+def _posconv_weight(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    """weight-norm(dim=2): W[:,:,j] = g[j] * v[:,:,j] / ||v[:,:,j]||_F  (HF:326-352; both key spellings)."""
+    pc = prefix + "encoder.pos_conv_embed.conv."
+    if pc + "parametrizations.weight.original0" in sd:
+        g, v = sd[pc + "parametrizations.weight.original0"], sd[pc + "parametrizations.weight.original1"]
+    elif pc + "weight_g" in sd:
+        g, v = sd[pc + "weight_g"], sd[pc + "weight_v"]
+    else:
+        return sd[pc + "weight"]
+    nrm = v.float().pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return g.float() * v.float() / nrm
+
+
+def conv_feature_extractor(sd, cfg, x: torch.Tensor, prefix: str = "", taps: Optional[dict] = None) -> torch.Tensor:
+    """(B, L) -> (B, C, T).  HF:382-419."""
+    h = x[:, None, :]
+    for i, (k, s) in enumerate(zip(cfg.conv_kernel, cfg.conv_stride)):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        h = F.conv1d(h, sd[p + "conv.weight"], sd.get(p + "conv.bias"), stride=s)
+        if cfg.feat_extract_norm == "group" and i == 0:
+            c = h.shape[1]
+            h = F.group_norm(h, c, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], eps=1e-5)
+        elif cfg.feat_extract_norm == "layer":
+            c = h.shape[1]
+            h = F.layer_norm(h.transpose(1, 2), (c,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"],
+                             eps=1e-5).transpose(1, 2)
+        h = F.gelu(h)
+        if taps is not None:
+            taps[f"conv{i}"] = h.transpose(1, 2).contiguous()
+    return h
+
+
+def attention(sd, p: str, u: torch.Tensor, nheads: int) -> torch.Tensor:
+    """HF:466-548 eager path; no mask."""
+    B, T, D = u.shape
+    dh = D // nheads
+    q = F.linear(u, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
+    k = F.linear(u, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
+    v = F.linear(u, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5), dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, D)
+    return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+def encoder_forward(sd: Dict[str, torch.Tensor], cfg, wav: torch.Tensor, normalize_wav: bool = True,
+                    output_norm: bool = True, prefix: str = "", taps: Optional[dict] = None) -> torch.Tensor:
+    """``HuggingFaceWav2Vec2.extract_features``: f32 (B, L) -> f32 (B, T, D)."""
+    x = wav.float()
+    if normalize_wav:
+        x = F.layer_norm(x, x.shape)  # whole-batch LN, eps 1e-5
+    h = conv_feature_extractor(sd, cfg, x, prefix, taps).transpose(1, 2)  # (B, T, C)
+    C = h.shape[-1]
+    eps = cfg.layer_norm_eps
+    if cfg.feat_proj_layer_norm:
+        h = F.layer_norm(h, (C,), sd[prefix + "feature_projection.layer_norm.weight"],
+                         sd[prefix + "feature_projection.layer_norm.bias"], eps=eps)
+    h = F.linear(h, sd[prefix + "feature_projection.projection.weight"],
+                 sd[prefix + "feature_projection.projection.bias"])
+    if taps is not None:
+        taps["proj"] = h.clone()
+    # positional conv embedding (HF:326-379)
+    D = cfg.hidden_size
+    kp, g = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    w = _posconv_weight(sd, prefix)
+    pos = F.conv1d(h.transpose(1, 2), w, sd[prefix + "encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=g)
+    if kp % 2 == 0:
+        pos = pos[:, :, :-1]
+    pos = F.gelu(pos).transpose(1, 2)
+    h = h + pos
+    if taps is not None:
+        taps["pos"] = h.clone()
+    nh = cfg.num_attention_heads
+
+    def ln(t, key):
+        return F.layer_norm(t, (D,), sd[prefix + key + ".weight"], sd[prefix + key + ".bias"], eps=eps)
+
+    def ffn(t, p):
+        t = F.gelu(F.linear(t, sd[p + "intermediate_dense.weight"], sd[p + "intermediate_dense.bias"]))
+        return F.linear(t, sd[p + "output_dense.weight"], sd[p + "output_dense.bias"])
+
+    if not cfg.do_stable_layer_norm:
+        h = ln(h, "encoder.layer_norm")
+        for l in range(cfg.num_hidden_layers):
+            p = f"encoder.layers.{l}"
+            h = ln(h + attention(sd, prefix + p + ".attention.", h, nh), p + ".layer_norm")
+            h = ln(h + ffn(h, prefix + p + ".feed_forward."), p + ".final_layer_norm")
+            if taps is not None:
+                taps[f"layer{l}"] = h.clone()
+    else:
+        for l in range(cfg.num_hidden_layers):
+            p = f"encoder.layers.{l}"
+            h = h + attention(sd, prefix + p + ".attention.", ln(h, p + ".layer_norm"), nh)
+            h = h + ffn(ln(h, p + ".final_layer_norm"), prefix + p + ".feed_forward.")
+            if taps is not None:
+                taps[f"layer{l}"] = h.clone()
+        h = ln(h, "encoder.layer_norm")
+    if output_norm:
+        h = F.layer_norm(h, h.shape)
+    return h
+
+
+def head_forward(feats: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    return F.linear(feats, w, b)
+
+
+def decode_frames(logits: torch.Tensor, n_octave: int = 4, n_class: int = 12):
+    """Per-frame decode of ``MIR_ST500/train_audio_ssl.py:41-46,93-100``.
+    logits (..., 2 + (n_octave+1) + (n_class+1)) -> p_on f32, p_off f32, oct i64, pc i64."""
+    p_on = torch.sigmoid(logits[..., 0])
+    p_off = torch.sigmoid(logits[..., 1])
+    octv = torch.argmax(logits[..., 2:2 + n_octave + 1], dim=-1)
+    pc = torch.argmax(logits[..., 2 + n_octave + 1:], dim=-1)
+    return p_on, p_off, octv, pc
+
+
+def frame2note(frame_info: Sequence, onset_thres: float, offset_thres: float, frame_size: float = 1 / 49.8):
+    """Greedy frame -> note scan (``MIR_ST500/utils.py:82-149``).  ``frame_info[i]`` =
+    (p_on, p_off, octave, pitch_class); probabilities are float32 (numpy scalars / 0-dim tensors)."""
+    n = len(frame_info)
+    on = np.array([np.float32(f[0]) for f in frame_info], dtype=np.float32)
+    notes: List[list] = []
+    start = None
+    votes: List[int] = []
+    t_now = 0.0
+    thr_on, thr_off = onset_thres, offset_thres
+
+    def flush(t_end):
+        if votes:
+            notes.append([start, t_end, max(set(votes), key=votes.count) + 36])
+
+    for i in range(n):
+        t_now = frame_size * i
+        p_on, p_off, octv, pc = frame_info[i]
+        lo = max(i - 3, 0)
+        hi = min(i + 4, n - 1)
+        is_onset = bool(np.float32(p_on) >= thr_on) and bool(on[i] == np.amax(on[lo:hi]))
+        if is_onset:
+            if start is not None:
+                flush(t_now)
+            start = t_now
+            votes = []
+        elif bool(np.float32(p_off) >= thr_off):
+            if start is not None:
+                flush(t_now)
+                start = None
+                votes = []
+        if start is not None:
+            if int(octv) != 4 and int(pc) != 12:
+                votes.append(int(int(octv) * 12 + int(pc)))
+    if start is not None:
+        flush(t_now)
+    return notes
+
+
+# ------------------------------------------------------------------------------------------------
+# RCA fusion
+# ------------------------------------------------------------------------------------------------
+def _mha_packed(x_q, x_kv, w_in, b_in, w_out, b_out, nhead):
+    B, Tq, D = x_q.shape
+    Tk = x_kv.shape[1]
+    dh = D // nhead
+    q = F.linear(x_q, w_in[:D], b_in[:D]).view(B, Tq, nhead, dh).transpose(1, 2)
+    k = F.linear(x_kv, w_in[D:2 * D], b_in[D:2 * D]).view(B, Tk, nhead, dh).transpose(1, 2)
+    v = F.linear(x_kv, w_in[2 * D:], b_in[2 * D:]).view(B, Tk, nhead, dh).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, Tq, D)
+    return F.linear(o, w_out, b_out)
+
+
+def rca_layer(sd, p, src_kv, src_q, alpha, nhead, eps=1e-6):
+    """``RCALayer.forward`` (fusion.py:137-183): post-norm, shared attention weights, ReLU FFN."""
+    D = src_kv.shape[-1]
+    w_in, b_in = sd[p + "self_att.att.in_proj_weight"], sd[p + "self_att.att.in_proj_bias"]
+    w_o, b_o = sd[p + "self_att.att.out_proj.weight"], sd[p + "self_att.att.out_proj.bias"]
+    sa = _mha_packed(src_kv, src_kv, w_in, b_in, w_o, b_o, nhead)
+    ca = _mha_packed(src_q, src_kv, w_in, b_in, w_o, b_o, nhead)
+    x = src_kv + sa * alpha + ca * (1 - alpha)
+    x = F.layer_norm(x, (D,), sd[p + "norm1.norm.weight"], sd[p + "norm1.norm.bias"], eps=eps)
+    y = F.linear(F.relu(F.linear(x, sd[p + "pos_ffn.ffn.0.weight"], sd[p + "pos_ffn.ffn.0.bias"])),
+                 sd[p + "pos_ffn.ffn.3.weight"], sd[p + "pos_ffn.ffn.3.bias"])
+    return F.layer_norm(x + y, (D,), sd[p + "norm2.norm.weight"], sd[p + "norm2.norm.bias"], eps=eps)
+
+
+def fusion_forward(sd, audio: torch.Tensor, video: torch.Tensor, alpha: float = 0.5, nhead: int = 8,
+                   prefix: str = "") -> torch.Tensor:
+    """``FusionRCA.forward`` (fusion.py:192-210)."""
+    B, T1, D = audio.shape
+    T2 = video.shape[1]
+    diff = T1 - T2
+    if diff < 0:
+        video = video[:, :diff]
+    elif diff > 0:
+        video = torch.cat([video, torch.zeros(video.shape[0], diff, D, dtype=video.dtype)], dim=1)
+    pe = sd[prefix + "fusion.positional_encoding.pe"][:, :T1]
+    s1 = audio + pe
+    s2 = video + pe
+    o1 = rca_layer(sd, prefix + "fusion.layer1.", s1, s2, alpha, nhead)
+    o2 = rca_layer(sd, prefix + "fusion.layer2.", s2, s1, alpha, nhead)
+    return o1 + o2
+
+
+# ------------------------------------------------------------------------------------------------
+# CTC greedy + Fbank (named by north_star; not on a recipe path — SURVEY.md F3/F4)
+# ------------------------------------------------------------------------------------------------
+def filter_ctc_output(seq: Sequence, blank_id=-1) -> list:
+    out = []
+    prev = object()
+    for s in seq:
+        if s != prev:
+            out.append(s)
+        prev = s
+    return [s for s in out if s != blank_id]
+
+
+def ctc_greedy_decode(probs: torch.Tensor, seq_lens: torch.Tensor, blank_id: int = -1) -> List[List[int]]:
+    """``speechbrain/decoders/ctc.py:341-383``: probs (B, T, V), relative lens (B,)."""
+    if isinstance(blank_id, int) and blank_id < 0:
+        blank_id = probs.shape[-1] + blank_id
+    T = probs.shape[1]
+    out = []
+    for seq, rel in zip(probs, seq_lens):
+        n = int(torch.round(rel * T))
+        ids = torch.argmax(seq[:n], dim=-1).tolist() if n > 0 else []
+        out.append(filter_ctc_output(ids, blank_id))
+    return out
+
+
+def mel_filterbank(n_mels=40, n_fft=400, sr=16000, f_min=0.0, f_max=8000.0) -> torch.Tensor:
+    """Triangular mel matrix (n_stft, n_mels): ``processing/features.py:452-470,586-610``."""
+    def to_mel(hz):
+        return 2595.0 * math.log10(1.0 + hz / 700.0)
+    mel = torch.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2)
+    hz = 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    band = hz[1:] - hz[:-1]
+    band = band[:-1]
+    f_central = hz[1:-1]
+    n_stft = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sr // 2, n_stft)
+    fc = f_central.repeat(n_stft, 1).transpose(0, 1)
+    bd = band.repeat(n_stft, 1).transpose(0, 1)
+    slope = (all_freqs.repeat(n_mels, 1) - fc) / bd
+    left = slope + 1.0
+    right = -slope + 1.0
+    fb = torch.max(torch.zeros(1), torch.min(left, right)).transpose(0, 1)
+    return fb  # (n_stft, n_mels)
+
+
+def fbank(wav: torch.Tensor, n_mels=40, n_fft=400, win=400, hop=160, sr=16000, top_db=80.0) -> torch.Tensor:
+    """Default ``Fbank`` chain (deltas=False, context=False): STFT -> power -> mel -> dB -> top_db clip."""
+    window = torch.hamming_window(win)
+    st = torch.stft(wav.float(), n_fft, hop, win, window, center=True, pad_mode="constant", normalized=False,
+                    onesided=True, return_complex=True)
+    power = (st.real ** 2 + st.imag ** 2).transpose(1, 2)  # (B, frames, n_stft)
+    fb = torch.matmul(power, mel_filterbank(n_mels, n_fft, sr))
+    db = 10.0 * torch.log10(torch.clamp(fb, min=1e-10))
+    db = db - 10.0 * math.log10(max(1e-10, 1.0))  # db_multiplier with ref_value 1.0 -> 0
+    mx = db.amax(dim=(-2, -1)) - top_db
+    return torch.max(db, mx.view(-1, 1, 1))

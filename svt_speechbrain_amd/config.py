@@ -1,0 +1,112 @@
+"""Encoder configuration for the singing-transcription hot path.
+
+The fields mirror the subset of the HuggingFace ``Wav2Vec2Config`` / ``HubertConfig`` that the
+reference's encoder forward actually reads (reference call site:
+``MIR_ST500/huggingface_interface.py:107-124,169-179``; HF ``modeling_wav2vec2.py:254-434,657-802``).
+Everything is a runtime parameter: the C-ABI (``include/svt_mi355.h``, ``svt_config``) carries the
+same fields, so large / HuBERT variants need no recompilation.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Tuple
+
+
+@dataclasses.dataclass(frozen=True)
+class EncoderConfig:
+    name: str = "wav2vec2-base"
+    family: str = "wav2vec2"  # "wav2vec2" | "hubert" (selects the HF key layout only)
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    conv_dim: Tuple[int, ...] = (512,) * 7
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    feat_extract_norm: str = "group"  # "group": GroupNorm on conv0 only; "layer": LN after every conv
+    conv_bias: bool = False
+    do_stable_layer_norm: bool = False  # False: post-LN encoder; True: pre-LN + final LN
+    feat_proj_layer_norm: bool = True  # always True for wav2vec2; optional for HuBERT
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    def frames(self, n_samples: int) -> int:
+        """Number of encoder frames for a waveform of ``n_samples`` (no padding in any conv)."""
+        t = n_samples
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            t = (t - k) // s + 1
+        return t
+
+    def frame_counts(self, n_samples: int):
+        out = []
+        t = n_samples
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            t = (t - k) // s + 1
+            out.append(t)
+        return out
+
+    def flops_per_clip(self, n_samples: int, head_out: int = 20) -> float:
+        """Algorithmic FLOPs (2*MAC; norms/activations/softmax excluded) — SURVEY.md §8(d)."""
+        ts = self.frame_counts(n_samples)
+        fl = 0.0
+        cin = 1
+        for t, k, c in zip(ts, self.conv_kernel, self.conv_dim):
+            fl += 2.0 * t * k * cin * c
+            cin = c
+        T = ts[-1]
+        D, F = self.hidden_size, self.intermediate_size
+        fl += 2.0 * T * cin * D  # feature projection
+        fl += 2.0 * T * D * (D // self.num_conv_pos_embedding_groups) * self.num_conv_pos_embeddings
+        per_layer = 4 * 2.0 * T * D * D + 2 * 2.0 * T * T * D + 2 * 2.0 * T * D * F
+        fl += self.num_hidden_layers * per_layer
+        fl += 2.0 * T * D * head_out
+        return fl
+
+
+PRESETS = {
+    "wav2vec2-base": EncoderConfig(),
+    "wav2vec2-large-lv60": EncoderConfig(
+        name="wav2vec2-large-lv60", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+        intermediate_size=4096, feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True),
+    "hubert-large-ll60k": EncoderConfig(
+        name="hubert-large-ll60k", family="hubert", hidden_size=1024, num_hidden_layers=24,
+        num_attention_heads=16, intermediate_size=4096, feat_extract_norm="layer", conv_bias=True,
+        do_stable_layer_norm=True, feat_proj_layer_norm=True),
+    # Small configurations for golden fixtures / fast parity tests (SURVEY.md §8c "tiny config").
+    "tiny-group": EncoderConfig(
+        name="tiny-group", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, num_conv_pos_embeddings=16,
+        num_conv_pos_embedding_groups=4),
+    "tiny-layer": EncoderConfig(
+        name="tiny-layer", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, num_conv_pos_embeddings=16,
+        num_conv_pos_embedding_groups=4, feat_extract_norm="layer", conv_bias=True,
+        do_stable_layer_norm=True),
+    "tiny-hubert": EncoderConfig(
+        name="tiny-hubert", family="hubert", hidden_size=64, num_hidden_layers=2,
+        num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
+        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, feat_extract_norm="layer",
+        conv_bias=True, do_stable_layer_norm=True, feat_proj_layer_norm=False),
+}
+
+
+def config_from_source(source: str) -> EncoderConfig:
+    """Pick a preset from a HF hub id / local name the way the reference picks the model class:
+    by substring (``MIR_ST500/huggingface_interface.py:107-119``)."""
+    key = source.rstrip("/").split("/")[-1]
+    if key in PRESETS:
+        return PRESETS[key]
+    low = source.lower()
+    if "hubert" in low:
+        return PRESETS["hubert-large-ll60k"]
+    if "data2vec" in low or "wavlm" in low:
+        raise NotImplementedError(
+            f"{source}: data2vec/WavLM encoders are out of scope for the MI355X path (SURVEY.md §8 note iii)")
+    if "wav2vec2" in low:
+        return PRESETS["wav2vec2-large-lv60"] if "large" in low else PRESETS["wav2vec2-base"]
+    raise ValueError(f"cannot infer an encoder family from source={source!r}")

@@ -1,0 +1,289 @@
+"""Generate the golden fixtures in this directory by importing the REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and HF transformers); the fixtures it writes
+(*.pt, data only: seeds, inputs, expected outputs) are committed, the reference never is.
+
+    python tests/golden/make_golden.py [--only NAME]
+
+What runs is the reference's own code: ``HuggingFaceWav2Vec2.forward`` (MIR_ST500/huggingface_interface.py:263-297)
+over HF ``Wav2Vec2Model`` / ``HubertModel`` (eager attention, fp32), ``speechbrain.nnet.linear.Linear``,
+``fusion.FusionRCA``, ``utils.frame2note``, ``speechbrain.decoders.ctc``, and the STFT ->
+spectral_magnitude -> Filterbank chain.  Weights come from ``svt_speechbrain_amd.weights`` (seeded) and are
+loaded into the reference modules with ``load_state_dict``.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from svt_speechbrain_amd.config import PRESETS  # noqa: E402
+from svt_speechbrain_amd import weights as W  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    import transformers  # noqa: F401  (must precede the stubs: the wrapper probes torchaudio via find_spec)
+    from transformers import Wav2Vec2Model, HubertModel, Wav2Vec2Config, HubertConfig  # noqa: F401
+
+    class Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return Stub(self.__name__ + "." + n)
+
+        def __call__(self, *a, **k):
+            return None
+
+    for m in ["hyperpyyaml", "torchaudio", "ruamel", "ruamel.yaml"]:
+        sys.modules.setdefault(m, Stub(m))
+    for p in [REF, REF + "/MIR_ST500", REF + "/N20EMv2/audio_visual"]:
+        if p not in sys.path:
+            sys.path.append(p)
+    import speechbrain  # noqa: F401
+    import huggingface_interface
+    import fusion
+    import utils
+    return huggingface_interface, fusion, utils
+
+
+def hf_model(cfg):
+    from transformers import Wav2Vec2Model, HubertModel, Wav2Vec2Config, HubertConfig
+    kw = dict(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+              num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+              conv_dim=list(cfg.conv_dim), conv_kernel=list(cfg.conv_kernel), conv_stride=list(cfg.conv_stride),
+              feat_extract_norm=cfg.feat_extract_norm, conv_bias=cfg.conv_bias,
+              do_stable_layer_norm=cfg.do_stable_layer_norm,
+              num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+              num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups,
+              layer_norm_eps=cfg.layer_norm_eps, hidden_dropout=0.0, attention_dropout=0.0,
+              activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, apply_spec_augment=False,
+              attn_implementation="eager")
+    if cfg.family == "hubert":
+        hc = HubertConfig(feat_proj_layer_norm=cfg.feat_proj_layer_norm, **kw)
+        m = HubertModel(hc)
+    else:
+        m = Wav2Vec2Model(Wav2Vec2Config(**kw))
+    return m.eval()
+
+
+def reference_encoder(hi, cfg, sd, normalize_wav=True, output_norm=True):
+    """The reference wrapper object with our seeded weights inside (no network: bypass __init__)."""
+    model = hf_model(cfg)
+    own = model.state_dict()
+    missing = [k for k in own if k not in sd]
+    assert all(k == "masked_spec_embed" for k in missing), missing
+    full = dict(sd)
+    for k in missing:
+        full[k] = own[k]
+    model.load_state_dict(full, strict=True)
+    w = hi.HuggingFaceWav2Vec2.__new__(hi.HuggingFaceWav2Vec2)
+    torch.nn.Module.__init__(w)
+    w.model = model
+    w.normalize_wav = normalize_wav
+    w.output_norm = output_norm
+    w.freeze = True
+    w.freeze_feature_extractor = False
+    return w.eval()
+
+
+def synth_wav(B, L, seed=1986):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+
+
+def sd_digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def decode(utils, logits):
+    """The reference's per-frame loop (MIR_ST500/train_audio_ssl.py:93-100) + frame2note, per clip."""
+    out = []
+    for b in range(logits.shape[0]):
+        lg = logits[b]
+        on, off = torch.sigmoid(lg[:, 0]), torch.sigmoid(lg[:, 1])
+        po, pc = lg[:, 2:7], lg[:, 7:]
+        pred = []
+        for f in range(lg.shape[0]):
+            pred.append((on[f], off[f], torch.argmax(po[f]).item(), torch.argmax(pc[f]).item()))
+        notes = utils.frame2note(pred, onset_thres=0.4, offset_thres=0.5, frame_size=1 / 49.8)
+        out.append(dict(p_on=on.clone(), p_off=off.clone(),
+                        oct=torch.tensor([p[2] for p in pred]), pc=torch.tensor([p[3] for p in pred]),
+                        notes=[[float(n[0]), float(n[1]), int(n[2])] for n in notes]))
+    return out
+
+
+def make_encoder_case(hi, utils, name, cfg_name, B, L, seed, pad_to=None, full=True, lens=None):
+    import speechbrain as sb
+    cfg = PRESETS[cfg_name]
+    sd = W.seeded_encoder_state_dict(cfg, seed=seed)
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=seed + 1000)
+    enc = reference_encoder(hi, cfg, sd)
+    head = sb.nnet.linear.Linear(n_neurons=20, input_size=cfg.hidden_size)
+    head.load_state_dict(hd, strict=True)
+    wav = synth_wav(B, L, seed=seed + 7)
+    if lens is not None:  # ragged, right-zero-padded batch
+        for b, n in enumerate(lens):
+            wav[b, n:] = 0.0
+    with torch.no_grad():
+        feats = enc(wav)
+        logits = head(feats)
+    dec = decode(utils, logits)
+    fx = dict(name=name, cfg=cfg_name, B=B, L=L, weight_seed=seed, head_seed=seed + 1000, wav_seed=seed + 7,
+              lens=lens, sd_sha256=sd_digest(sd), T=feats.shape[1],
+              logits=logits.clone(), decode=dec)
+    if full:
+        fx["wav"] = wav.clone()
+        fx["feats"] = feats.clone()
+    else:
+        fx["feats_strided"] = feats[:, ::25, ::16].clone()
+        fx["wav_sha256"] = hashlib.sha256(wav.numpy().tobytes()).hexdigest()
+        fx["feats_absmean"] = float(feats.abs().mean())
+    torch.save(fx, os.path.join(HERE, name + ".pt"))
+    print(name, tuple(feats.shape), "notes/clip", [len(d["notes"]) for d in dec])
+
+
+def make_fusion_cases(fusion_mod):
+    sd = W.seeded_fusion_state_dict(1024, 3072, seed=3986)
+    m = fusion_mod.FusionRCA().eval()
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    cases = [("fusion_trunc", 2, 499, 500), ("fusion_pad", 1, 250, 240), ("fusion_eq", 1, 64, 64)]
+    for name, B, T1, T2 in cases:
+        g = torch.Generator().manual_seed(77 + T1)
+        a = torch.randn(B, T1, 1024, generator=g)
+        v = torch.randn(B, T2, 1024, generator=g)
+        with torch.no_grad():
+            out = m(a, v)
+        fx = dict(name=name, B=B, T1=T1, T2=T2, in_seed=77 + T1, weight_seed=3986, sd_sha256=sd_digest(sd),
+                  out_strided=out[:, ::7, ::5].clone(), out_absmean=float(out.abs().mean()),
+                  out_first=out[:, :4].clone())
+        torch.save(fx, os.path.join(HERE, name + ".pt"))
+        print(name, tuple(out.shape))
+
+
+def make_frame2note_cases(utils):
+    f32 = np.float32
+    cases = {}
+    rng = np.random.RandomState(5)
+
+    def mk(on, off, octv, pc):
+        return [(torch.tensor(f32(a)), torch.tensor(f32(b)), int(c), int(d)) for a, b, c, d in zip(on, off, octv, pc)]
+
+    n = 60
+    base_on = np.full(n, 0.1, f32)
+    base_off = np.full(n, 0.1, f32)
+    octv = np.full(n, 2)
+    pc = np.full(n, 5)
+    # plateau of equal onset probabilities (every frame equals the window max)
+    on = base_on.copy(); on[10:14] = 0.8; off = base_off.copy(); off[30] = 0.9
+    cases["plateau"] = (on, off, octv, pc)
+    # exact-threshold values (float32(0.4) vs python 0.4)
+    on = base_on.copy(); on[5] = f32(0.4); on[20] = np.nextafter(f32(0.4), f32(0)); off = base_off.copy(); off[15] = f32(0.5); off[40] = 0.7
+    cases["thresholds"] = (on, off, octv, pc)
+    # pitch-mode ties
+    on = base_on.copy(); on[3] = 0.9; off = base_off.copy(); off[25] = 0.9
+    o2 = octv.copy(); p2 = pc.copy()
+    o2[3:14] = 1; p2[3:14] = 7; o2[14:25] = 3; p2[14:25] = 2
+    cases["mode_tie"] = (on, off, o2, p2)
+    # onset at the last frame, open note at the end
+    on = base_on.copy(); on[8] = 0.7; on[n - 1] = 0.95
+    cases["last_frame"] = (on, base_off.copy(), octv, pc)
+    # silence classes only -> empty result
+    on = base_on.copy(); on[8] = 0.7; off = base_off.copy(); off[20] = 0.8
+    cases["silence"] = (on, off, np.full(n, 4), np.full(n, 12))
+    # consecutive onsets without offsets
+    on = base_on.copy(); on[[5, 15, 25, 35]] = [0.5, 0.6, 0.7, 0.8]
+    cases["re_onset"] = (on, base_off.copy(), octv, rng.randint(0, 12, n))
+    # random
+    for s in range(4):
+        r = np.random.RandomState(100 + s)
+        m = 200 + 37 * s
+        cases[f"random{s}"] = (r.rand(m).astype(f32), r.rand(m).astype(f32), r.randint(0, 5, m), r.randint(0, 13, m))
+    # tiny
+    cases["two_frames"] = (np.array([0.9, 0.9], f32), np.array([0.1, 0.9], f32), np.array([1, 1]), np.array([2, 2]))
+    out = {}
+    for k, (on, off, o, p) in cases.items():
+        notes = utils.frame2note(mk(on, off, o, p), onset_thres=0.4, offset_thres=0.5, frame_size=1 / 49.8)
+        out[k] = dict(p_on=torch.from_numpy(np.asarray(on, f32)), p_off=torch.from_numpy(np.asarray(off, f32)),
+                      oct=torch.from_numpy(np.asarray(o)), pc=torch.from_numpy(np.asarray(p)),
+                      notes=[[float(a), float(b), int(c)] for a, b, c in notes])
+        print("frame2note", k, len(notes))
+    torch.save(out, os.path.join(HERE, "frame2note.pt"))
+
+
+def make_ctc_fbank_cases():
+    from speechbrain.decoders.ctc import ctc_greedy_decode, filter_ctc_output
+    from speechbrain.processing.features import STFT, spectral_magnitude, Filterbank
+    out = {}
+    # doctest known answers (speechbrain/decoders/ctc.py:317-320, 366-372)
+    probs = torch.tensor([[[0.3, 0.7], [0.0, 0.0]], [[0.2, 0.8], [0.9, 0.1]]])
+    lens = torch.tensor([0.51, 1.0])
+    out["doctest"] = dict(probs=probs, lens=lens, blank=0, expect=ctc_greedy_decode(probs, lens, 0))
+    assert out["doctest"]["expect"] == [[1], [1]]
+    assert filter_ctc_output(['a', 'a', 'blank', 'b', 'b', 'blank', 'c'], blank_id='blank') == ['a', 'b', 'c']
+    g = torch.Generator().manual_seed(11)
+    for i, (B, T, V) in enumerate([(3, 50, 7), (2, 120, 31), (4, 9, 3)]):
+        p = torch.log_softmax(torch.randn(B, T, V, generator=g) * 2, dim=-1)
+        ln = torch.rand(B, generator=g) * 0.6 + 0.4
+        ln[0] = 1.0
+        out[f"rand{i}"] = dict(probs=p, lens=ln, blank=-1, expect=ctc_greedy_decode(p, ln, -1))
+    torch.save(out, os.path.join(HERE, "ctc.pt"))
+    # Fbank default chain (lobes/features.py:134-136); the Fbank class itself needs a GPU
+    stft = STFT(sample_rate=16000, n_fft=400, win_length=25, hop_length=10)
+    fb = Filterbank(sample_rate=16000, n_fft=400, n_mels=40, f_min=0, f_max=8000)
+    fo = {}
+    for name, B, L in [("a", 2, 16000), ("b", 3, 4321)]:
+        wav = synth_wav(B, L, seed=500 + L)
+        feats = fb(spectral_magnitude(stft(wav)))
+        fo[name] = dict(wav=wav, feats=feats)
+        print("fbank", name, tuple(feats.shape))
+    assert float(spectral_magnitude(torch.Tensor([[3, 4]]), power=0.5)) == 5.0
+    torch.save(fo, os.path.join(HERE, "fbank.pt"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    hi, fusion_mod, utils = import_reference()
+    jobs = {
+        "tiny_group": lambda: make_encoder_case(hi, utils, "tiny_group", "tiny-group", 2, 4000, 11),
+        "tiny_layer": lambda: make_encoder_case(hi, utils, "tiny_layer", "tiny-layer", 2, 4000, 12),
+        "tiny_hubert": lambda: make_encoder_case(hi, utils, "tiny_hubert", "tiny-hubert", 2, 4000, 13),
+        "tiny_group_ragged": lambda: make_encoder_case(hi, utils, "tiny_group_ragged", "tiny-group", 3, 6000, 14,
+                                                       lens=[6000, 3300, 4711]),
+        "base_c1": lambda: make_encoder_case(hi, utils, "base_c1", "wav2vec2-base", 1, 80000, 21, full=False),
+        "base_b2": lambda: make_encoder_case(hi, utils, "base_b2", "wav2vec2-base", 2, 160000, 22, full=False),
+        "large_c1": lambda: make_encoder_case(hi, utils, "large_c1", "wav2vec2-large-lv60", 1, 80000, 23, full=False),
+        "hubert_large_c1": lambda: make_encoder_case(hi, utils, "hubert_large_c1", "hubert-large-ll60k", 1, 48000, 24,
+                                                      full=False),
+        "fusion": lambda: make_fusion_cases(fusion_mod),
+        "frame2note": lambda: make_frame2note_cases(utils),
+        "ctc_fbank": make_ctc_fbank_cases,
+    }
+    for k, fn in jobs.items():
+        if args.only and args.only != k:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""CPU: pin the oracle (oracle/svt_oracle.py) to the golden vectors captured from the reference
+itself (tests/golden/make_golden.py).  Tolerances: 2e-5 on O(1) feats/logits (fp32 op-order noise
+between the oracle's functional ops and HF modules), exact on argmax / notes."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svt_oracle as O
+from svt_speechbrain_amd import weights as W
+from svt_speechbrain_amd.config import PRESETS
+
+
+def synth_wav(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+
+
+def sd_digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _run_case(fx):
+    cfg = PRESETS[fx["cfg"]]
+    sd = W.seeded_encoder_state_dict(cfg, seed=fx["weight_seed"])
+    assert sd_digest(sd) == fx["sd_sha256"], "seeded weight generator drifted from the golden fixtures"
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=fx["head_seed"])
+    wav = fx["wav"] if "wav" in fx else synth_wav(fx["B"], fx["L"], fx["wav_seed"])
+    if "wav" not in fx and fx.get("lens"):
+        for b, n in enumerate(fx["lens"]):
+            wav[b, n:] = 0
+    with torch.no_grad():
+        feats = O.encoder_forward(sd, cfg, wav)
+        logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
+    return cfg, feats, logits
+
+
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged"])
+def test_oracle_tiny(golden, name):
+    fx = golden(name)
+    cfg, feats, logits = _run_case(fx)
+    assert feats.shape[1] == fx["T"] == cfg.frames(fx["L"])
+    assert (feats - fx["feats"]).abs().max() < 2e-5
+    assert (logits - fx["logits"]).abs().max() < 2e-5
+    p_on, p_off, octv, pc = O.decode_frames(logits)
+    for b, d in enumerate(fx["decode"]):
+        assert torch.equal(octv[b], d["oct"]) and torch.equal(pc[b], d["pc"])
+        assert (p_on[b] - d["p_on"]).abs().max() < 1e-5
+        notes = O.frame2note(list(zip(d["p_on"].numpy(), d["p_off"].numpy(), d["oct"].tolist(), d["pc"].tolist())), 0.4, 0.5)
+        assert notes == d["notes"]
+
+
+@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1"])
+def test_oracle_full_size(golden, name):
+    fx = golden(name)
+    torch.set_num_threads(8)
+    cfg, feats, logits = _run_case(fx)
+    assert feats.shape[1] == fx["T"]
+    assert (feats[:, ::25, ::16] - fx["feats_strided"]).abs().max() < 1e-4
+    assert (logits - fx["logits"]).abs().max() < 2e-4
+    p_on, p_off, octv, pc = O.decode_frames(logits)
+    d = fx["decode"][0]
+    # argmax may legitimately differ only where the top-2 logits are within fp32 noise
+    mism = (octv[0] != d["oct"]) | (pc[0] != d["pc"])
+    assert int(mism.sum()) == 0
+
+
+def test_oracle_frame2note_golden(golden):
+    cases = golden("frame2note")
+    for k, c in cases.items():
+        info = list(zip(c["p_on"].numpy(), c["p_off"].numpy(), c["oct"].tolist(), c["pc"].tolist()))
+        assert O.frame2note(info, 0.4, 0.5, 1 / 49.8) == c["notes"], k
+
+
+def test_frame2note_single_frame_raises():
+    # np.amax on an empty window (MIR_ST500/utils.py:115) -> ValueError when a song has one frame
+    with pytest.raises(ValueError):
+        O.frame2note([(np.float32(0.9), np.float32(0.1), 1, 1)], 0.4, 0.5)
+
+
+@pytest.mark.parametrize("name", ["fusion_eq", "fusion_pad", "fusion_trunc"])
+def test_oracle_fusion(golden, name):
+    fx = golden(name)
+    sd = W.seeded_fusion_state_dict(1024, 3072, seed=fx["weight_seed"])
+    assert sd_digest(sd) == fx["sd_sha256"]
+    g = torch.Generator().manual_seed(fx["in_seed"])
+    a = torch.randn(fx["B"], fx["T1"], 1024, generator=g)
+    v = torch.randn(fx["B"], fx["T2"], 1024, generator=g)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = O.fusion_forward(sd, a, v)
+    assert out.shape == (fx["B"], fx["T1"], 1024)
+    assert (out[:, ::7, ::5] - fx["out_strided"]).abs().max() < 5e-5
+    assert (out[:, :4] - fx["out_first"]).abs().max() < 5e-5
+
+
+def test_oracle_ctc(golden):
+    cases = golden("ctc")
+    for k, c in cases.items():
+        assert O.ctc_greedy_decode(c["probs"], c["lens"], c["blank"]) == c["expect"], k
+    # doctest known answers of the reference (speechbrain/decoders/ctc.py:317-320, 366-372)
+    assert O.filter_ctc_output(['a', 'a', 'blank', 'b', 'b', 'blank', 'c'], blank_id='blank') == ['a', 'b', 'c']
+    assert cases["doctest"]["expect"] == [[1], [1]]
+
+
+def test_oracle_fbank(golden):
+    cases = golden("fbank")
+    for k, c in cases.items():
+        out = O.fbank(c["wav"])
+        assert out.shape == c["feats"].shape
+        assert (out - c["feats"]).abs().max() < 2e-3, k  # dB scale, values O(10..80)
