@@ -1,0 +1,162 @@
+/*
+ * svt_mi355.h — C-ABI of the MI355X-native singing-transcription hot path.
+ *
+ * This is the drop-in boundary.  The reference is 100 % Python; its "FFI" for this
+ * path is the set of torch ops reached from
+ *   MIR_ST500/huggingface_interface.py:263-297   (HuggingFaceWav2Vec2.forward / extract_features)
+ *   speechbrain/nnet/linear.py:63-76             (Linear.forward, the 20-way frame head)
+ *   MIR_ST500/train_audio_ssl.py:41-46,93-100    (logit slicing, sigmoid / argmax per frame)
+ *   N20EMv2/audio_visual/fusion.py:192-210       (FusionRCA.forward)
+ *   speechbrain/decoders/ctc.py:341-383          (ctc_greedy_decode)
+ *   speechbrain/lobes/features.py:126-143        (Fbank.forward)
+ * Each entry point below names the interface it replaces.  A maintainer binds them with ctypes
+ * (INTEGRATION.md shows the stub); svt_speechbrain_amd/ does exactly that.
+ *
+ * Conventions
+ *   - plain C types only: pointers + sizes, no torch / HIP types in signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - every *_dev pointer is device memory on the object's device, caller-owned, never mutated when
+ *     const.  Host pointers are named *_host.
+ *   - all functions return 0 on success or a negative svt_status; svt_last_error() returns a
+ *     thread-local text.  Nothing aborts, nothing synchronises the device or allocates inside a
+ *     forward call (workspace is caller-supplied), so calls may be captured into a hipGraph.
+ *   - one object per device; an object is NOT thread-safe.
+ */
+#ifndef SVT_MI355_H
+#define SVT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_ABI_VERSION 1
+#define SVT_MAX_CONV_LAYERS 8
+
+typedef enum {
+  SVT_OK = 0,
+  SVT_ERR_INVALID = -1,     /* bad argument / config / shape              */
+  SVT_ERR_KEY = -2,         /* unknown or missing parameter key           */
+  SVT_ERR_STATE = -3,       /* call order (e.g. encode before finalize)   */
+  SVT_ERR_WORKSPACE = -4,   /* workspace too small                        */
+  SVT_ERR_HIP = -5,         /* HIP runtime error (text in last_error)     */
+  SVT_ERR_NO_DEVICE = -6    /* no gfx950 device visible                   */
+} svt_status;
+
+typedef enum { SVT_PREC_FP32 = 0, SVT_PREC_BF16 = 1 } svt_precision;
+typedef enum { SVT_NORM_GROUP = 0, SVT_NORM_LAYER = 1 } svt_feat_norm;
+typedef enum { SVT_F32 = 0 } svt_dtype;
+
+/* Mirrors the HF Wav2Vec2Config / HubertConfig fields the forward reads
+ * (huggingface_interface.py:107-124,169-179) plus the wrapper's two flags (:99-100,130). */
+typedef struct svt_encoder_config {
+  int32_t struct_size;          /* = sizeof(svt_encoder_config) */
+  int32_t hidden_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t intermediate_size;
+  int32_t num_conv_layers;
+  int32_t conv_dim[SVT_MAX_CONV_LAYERS];
+  int32_t conv_kernel[SVT_MAX_CONV_LAYERS];
+  int32_t conv_stride[SVT_MAX_CONV_LAYERS];
+  int32_t feat_extract_norm;    /* svt_feat_norm */
+  int32_t conv_bias;
+  int32_t stable_layer_norm;    /* do_stable_layer_norm */
+  int32_t feat_proj_layer_norm;
+  int32_t pos_conv_kernel;      /* num_conv_pos_embeddings */
+  int32_t pos_conv_groups;      /* num_conv_pos_embedding_groups */
+  float layer_norm_eps;
+  int32_t normalize_wav;        /* wrapper: F.layer_norm(wav, wav.shape) */
+  int32_t output_norm;          /* wrapper: F.layer_norm(out, out.shape) */
+  int32_t precision;            /* svt_precision: operand type of the MFMA contractions */
+} svt_encoder_config;
+
+typedef struct svt_encoder svt_encoder;
+typedef struct svt_linear svt_linear;
+typedef struct svt_rca svt_rca;
+
+/* one decoded frame: what the reference's per-frame loop appends to song_pred
+ * (MIR_ST500/train_audio_ssl.py:95-100) */
+typedef struct svt_frame {
+  float p_on;
+  float p_off;
+  int32_t octave;
+  int32_t pitch_class;
+} svt_frame;
+
+const char* svt_last_error(void);
+int svt_abi_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => the product path must fail loudly) */
+int svt_device_count(void);
+
+/* ---- encoder: replaces HuggingFaceWav2Vec2 (huggingface_interface.py:47-297) + the HF model it wraps ---- */
+int svt_encoder_create(const svt_encoder_config* cfg, int device, svt_encoder** out);
+void svt_encoder_destroy(svt_encoder* e);
+/* copy one parameter by its HF state-dict key (without the wrapper's "model." prefix); both weight-norm
+ * spellings of the positional conv are accepted (…conv.weight_g/_v and …parametrizations.weight.original0/1).
+ * replaces: Module.load_state_dict (speechbrain/utils/checkpoints.py:69-95, train_audio_ssl.py:232-234) */
+int svt_encoder_load_param(svt_encoder* e, const char* key, const void* data_host, int dtype,
+                           const int64_t* shape, int ndim);
+/* fold weight-norm, pack q/k/v, reorder conv kernels for implicit GEMM, cast to the operand type,
+ * upload.  Fails with SVT_ERR_KEY (naming the key) if a required parameter was never loaded. */
+int svt_encoder_finalize(svt_encoder* e);
+/* read a (possibly folded) parameter back as fp32 by HF key — for state_dict() round trips */
+int svt_encoder_get_param(svt_encoder* e, const char* key, void* out_host, int64_t capacity_elems);
+int64_t svt_encoder_num_frames(const svt_encoder* e, int64_t n_samples);
+int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t n_samples);
+/* replaces: HuggingFaceWav2Vec2.extract_features (:279-297): wav f32 (B,L) -> feats f32 (B,T,D) */
+int svt_encoder_forward(svt_encoder* e, const float* wav_dev, int32_t batch, int64_t n_samples,
+                        float* feats_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- frame head + per-frame decode: replaces speechbrain.nnet.linear.Linear (linear.py:41-76)
+ *      and the sigmoid/argmax loop (train_audio_ssl.py:41-46,93-100) ---- */
+int svt_linear_create(int32_t in_features, int32_t out_features, int has_bias, int device, svt_linear** out);
+void svt_linear_destroy(svt_linear* l);
+int svt_linear_load(svt_linear* l, const float* weight_host /*out x in*/, const float* bias_host /*out or NULL*/);
+/* y = x W^T + b, fp32 in / fp32 accumulate / fp32 out; rows = product of leading dims */
+int svt_linear_forward(svt_linear* l, const float* x_dev, int64_t rows, float* y_dev, void* stream);
+/* logits (rows, 2+n_octave+1+n_class+1) -> frames; argmax = first maximum, sigmoid in fp32 */
+int svt_decode_frames(const float* logits_dev, int64_t rows, int32_t n_out, int32_t n_octave,
+                      int32_t n_class, svt_frame* frames_dev, int device, void* stream);
+
+/* ---- RCA fusion: replaces FusionRCA (N20EMv2/audio_visual/fusion.py:186-209) ---- */
+int svt_rca_create(int32_t d_model, int32_t nhead, int32_t d_ffn, float alpha, int32_t max_len,
+                   int32_t precision, int device, svt_rca** out);
+void svt_rca_destroy(svt_rca* r);
+/* keys as in the FusionRCA state dict: "fusion.layer1.self_att.att.in_proj_weight", … */
+int svt_rca_load_param(svt_rca* r, const char* key, const void* data_host, int dtype,
+                       const int64_t* shape, int ndim);
+int svt_rca_finalize(svt_rca* r);
+int64_t svt_rca_workspace_bytes(const svt_rca* r, int32_t batch, int32_t t_audio);
+/* audio (B,T1,D), video (B,T2,D) f32 -> out (B,T1,D) f32; video is truncated / zero-padded to T1 */
+int svt_rca_forward(svt_rca* r, const float* audio_dev, int32_t t_audio, const float* video_dev,
+                    int32_t t_video, int32_t batch, float* out_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* stream);
+
+/* ---- CTC greedy: replaces speechbrain.decoders.ctc.ctc_greedy_decode (ctc.py:341-383) ----
+ * probs (B,T,V) f32, rel_lens (B,) f32 (device).  tokens_dev (B,T) i32 receives the collapsed, blank-free
+ * ids left-aligned per row; out_lens_dev (B,) i32 their counts.  blank < 0 counts from V. */
+int svt_ctc_greedy(const float* probs_dev, int32_t batch, int32_t t, int32_t v, const float* rel_lens_dev,
+                   int32_t blank, int32_t* tokens_dev, int32_t* out_lens_dev, int device, void* stream);
+
+/* ---- Fbank: replaces speechbrain.lobes.features.Fbank default chain (features.py:126-143) ----
+ * wav (B,L) f32 -> (B, 1+L/hop, n_mels) f32; hamming win, centred, constant pad, power, triangular mel,
+ * 10 log10 clamp 1e-10, per-sequence top_db clip. */
+int64_t svt_fbank_workspace_bytes(int32_t batch, int64_t n_samples, int32_t n_fft, int32_t hop, int32_t n_mels);
+int svt_fbank(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t sample_rate, int32_t n_fft,
+              int32_t win_length, int32_t hop_length, int32_t n_mels, float f_min, float f_max, float top_db,
+              float* out_dev, void* workspace_dev, size_t workspace_bytes, int device, void* stream);
+
+/* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----
+ * When enabled, forward calls bracket every launch of the dense contraction kernel with hipEvents on
+ * the launch stream; svt_prof_read returns accumulated launches / milliseconds / algorithmic flops. */
+int svt_prof_enable(int on);
+int svt_prof_reset(void);
+int svt_prof_read(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_MI355_H */

@@ -1,0 +1,12 @@
+"""svt_speechbrain_amd — MI355X-native singing-transcription forward path (drop-in for the hot path of
+guxm2021/SVT_SpeechBrain; see DESIGN.md / INTEGRATION.md).  Importing the package never touches the GPU."""
+from .config import EncoderConfig, PRESETS, config_from_source  # noqa: F401
+from .huggingface_interface import HuggingFaceWav2Vec2  # noqa: F401
+from .linear import Linear  # noqa: F401
+from .fusion import FusionRCA  # noqa: F401
+from .features import Fbank  # noqa: F401
+from .decode import decode_frames, frame2note, frames_to_info, ctc_greedy_decode, filter_ctc_output  # noqa: F401
+from .amt import AMTForward  # noqa: F401
+
+__all__ = ["EncoderConfig", "PRESETS", "config_from_source", "HuggingFaceWav2Vec2", "Linear", "FusionRCA", "Fbank",
+           "decode_frames", "frame2note", "frames_to_info", "ctc_greedy_decode", "filter_ctc_output", "AMTForward"]

@@ -1,0 +1,137 @@
+"""ctypes binding of ``libsvt_mi355.so`` (C-ABI: ``include/svt_mi355.h``).
+
+The HIP library is the product; there is NO CPU fallback.  Importing this module never touches the GPU,
+but every compute entry point raises ``SvtError`` when the library is missing or no gfx950 device is
+visible (SURVEY.md §8b error conventions: Python exceptions, never an abort).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvt_mi355.so")
+MAX_CONV = 8
+
+
+class SvtError(RuntimeError):
+    pass
+
+
+class EncoderConfigC(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("hidden_size", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("intermediate_size", C.c_int32),
+        ("num_conv_layers", C.c_int32),
+        ("conv_dim", C.c_int32 * MAX_CONV),
+        ("conv_kernel", C.c_int32 * MAX_CONV),
+        ("conv_stride", C.c_int32 * MAX_CONV),
+        ("feat_extract_norm", C.c_int32),
+        ("conv_bias", C.c_int32),
+        ("stable_layer_norm", C.c_int32),
+        ("feat_proj_layer_norm", C.c_int32),
+        ("pos_conv_kernel", C.c_int32),
+        ("pos_conv_groups", C.c_int32),
+        ("layer_norm_eps", C.c_float),
+        ("normalize_wav", C.c_int32),
+        ("output_norm", C.c_int32),
+        ("precision", C.c_int32),
+    ]
+
+
+class FrameC(C.Structure):
+    _fields_ = [("p_on", C.c_float), ("p_off", C.c_float), ("octave", C.c_int32), ("pitch_class", C.c_int32)]
+
+
+# every symbol include/svt_mi355.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I64P = C.POINTER(C.c_int64)
+SYMBOLS = {
+    "svt_last_error": (C.c_char_p, []),
+    "svt_abi_version": (C.c_int, []),
+    "svt_device_count": (C.c_int, []),
+    "svt_encoder_create": (C.c_int, [C.POINTER(EncoderConfigC), C.c_int, C.POINTER(_P)]),
+    "svt_encoder_destroy": (None, [_P]),
+    "svt_encoder_load_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int, _I64P, C.c_int]),
+    "svt_encoder_finalize": (C.c_int, [_P]),
+    "svt_encoder_get_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "svt_encoder_num_frames": (C.c_int64, [_P, C.c_int64]),
+    "svt_encoder_workspace_bytes": (C.c_int64, [_P, C.c_int32, C.c_int64]),
+    "svt_encoder_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_size_t, _P]),
+    "svt_linear_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int, C.c_int, C.POINTER(_P)]),
+    "svt_linear_destroy": (None, [_P]),
+    "svt_linear_load": (C.c_int, [_P, _P, _P]),
+    "svt_linear_forward": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "svt_decode_frames": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int, _P]),
+    "svt_rca_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int, C.POINTER(_P)]),
+    "svt_rca_destroy": (None, [_P]),
+    "svt_rca_load_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int, _I64P, C.c_int]),
+    "svt_rca_finalize": (C.c_int, [_P]),
+    "svt_rca_workspace_bytes": (C.c_int64, [_P, C.c_int32, C.c_int32]),
+    "svt_rca_forward": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
+    "svt_ctc_greedy": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int, _P]),
+    "svt_fbank_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "svt_fbank": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_float, C.c_float, C.c_float, _P, _P, C.c_size_t, C.c_int, _P]),
+    "svt_prof_enable": (C.c_int, [C.c_int]),
+    "svt_prof_reset": (C.c_int, []),
+    "svt_prof_read": (C.c_int, [_I64P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol; raises SvtError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvtError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C svt_speechbrain_amd/csrc`). The MI355X path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.svt_abi_version() != 1:
+        raise SvtError("libsvt_mi355.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().svt_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise SvtError(f"{what}: {last_error()} (status {rc})")
+
+
+def require_gpu() -> None:
+    lib = load()
+    if lib.svt_device_count() < 1:
+        raise SvtError("no gfx950 (MI355X) device is visible: the HIP path cannot run and there is no CPU fallback")
+
+
+def stream_ptr(device) -> int:
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_index(device) -> int:
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise SvtError(f"tensors must live on a ROCm device ('cuda:N'), got {d}")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def ptr(t) -> int:
+    return int(t.data_ptr())

@@ -1,0 +1,1020 @@
+// C-ABI (include/svt_mi355.h) and host-side orchestration of the forward path.
+// Host code only: parameter intake by HF key, one-time re-layout / fold / cast, workspace carving
+// and the launch sequence.  No allocation, no synchronisation inside a forward call.
+#include "../../include/svt_mi355.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace svt {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_err = std::string("HIP error ") + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ") at " + file + ":" +
+          std::to_string(line) + " in " + what;
+  return SVT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------- profiling (dominant kernel)
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t used = 0;
+  double flops = 0, bytes = 0;
+  static constexpr size_t kMax = 16384;
+};
+static ProfState g_prof;
+void prof_begin(hipStream_t s) {
+  if (!g_prof.on || g_prof.used >= ProfState::kMax) return;
+  if (g_prof.used == g_prof.ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof.on = false; return; }
+    g_prof.ev.emplace_back(a, b);
+  }
+  (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
+}
+void prof_end(hipStream_t s, double flops, double bytes) {
+  if (!g_prof.on || g_prof.used >= g_prof.ev.size()) return;
+  (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+  g_prof.used++;
+  g_prof.flops += flops;
+  g_prof.bytes += bytes;
+}
+
+// ---------------------------------------------------------------- small helpers
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  int alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    SVT_HIP(hipMalloc(&p, n ? n : 16));
+    return 0;
+  }
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Param {
+  std::vector<float> v;
+  std::vector<int64_t> shape;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+typedef std::map<std::string, Param> ParamMap;
+
+static int load_param_into(ParamMap& m, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+  if (!key || !data || (ndim > 0 && !shape) || ndim < 0 || ndim > 6) { set_error("load_param: bad argument"); return SVT_ERR_INVALID; }
+  if (dtype != SVT_F32) { set_error("load_param: only SVT_F32 host tensors are accepted"); return SVT_ERR_INVALID; }
+  Param p;
+  p.shape.assign(shape, shape + ndim);
+  const int64_t n = p.numel();
+  p.v.assign((const float*)data, (const float*)data + n);
+  m[key] = std::move(p);
+  return SVT_OK;
+}
+
+static const Param* find(const ParamMap& m, const std::string& k) {
+  auto it = m.find(k);
+  return it == m.end() ? nullptr : &it->second;
+}
+
+static int need(const ParamMap& m, const std::string& k, std::vector<int64_t> shape, const Param** out) {
+  const Param* p = find(m, k);
+  if (!p) { set_error("missing parameter: " + k); return SVT_ERR_KEY; }
+  if (p->shape != shape) {
+    std::string s = "parameter " + k + " has shape (";
+    for (auto d : p->shape) s += std::to_string(d) + ",";
+    s += ") expected (";
+    for (auto d : shape) s += std::to_string(d) + ",";
+    set_error(s + ")");
+    return SVT_ERR_INVALID;
+  }
+  *out = p;
+  return SVT_OK;
+}
+
+// upload fp32 host data as fp32 or (prec) bf16 operand
+static int upload_f32(DevBuf& b, const float* h, size_t n) {
+  if (int r = b.alloc(n * 4)) return r;
+  SVT_HIP(hipMemcpy(b.p, h, n * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+static int upload_operand(int prec, DevBuf& b, const float* h, size_t n) {
+  if (!prec) return upload_f32(b, h, n);
+  DevBuf tmp;
+  if (int r = upload_f32(tmp, h, n)) return r;
+  if (int r = b.alloc(n * 2)) return r;
+  if (int r = launch_f32_to_bf16(tmp.as<float>(), b.as<bf16_t>(), (int64_t)n, 0)) return r;
+  SVT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int round_up_int(int x, int a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  }
+};
+
+// ---------------------------------------------------------------- attention (materialised scores)
+struct AttnBufs {
+  float* S;   // (B,H,T,Tp) fp32
+  void* P;    // operand type
+  void* Vt;   // (B,H,dh,Tp)
+};
+static size_t esize(int prec) { return prec ? 2 : 4; }
+
+// out[b,t,h*dh+d] = softmax(scale * q k^T) v ; q rows at Q + (b*T+t)*ldq + h*dh, likewise K (ldkv), V (ldkv)
+static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
+                                 int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
+                                 long ldo, hipStream_t s) {
+  const int Tp = round_up_int(T, 8);
+  GemmArgs g;
+  g.A = Q; g.W = K; g.C = ab.S;
+  g.M = T; g.N = T; g.K = dh;
+  g.a_rpb = T; g.a_bstride = 0; g.a_rstride = ldq;
+  g.ldw = ldkv; g.ldc = Tp;
+  g.nz = B * H; g.nz2 = H;
+  g.a_z1 = (long)T * ldq; g.a_z2 = dh;
+  g.w_z1 = (long)T * ldkv; g.w_z2 = dh;
+  g.c_z1 = (long)H * T * Tp; g.c_z2 = (long)T * Tp;
+  g.alpha = scale; g.out_f32 = 1;
+  if (int r = launch_gemm(prec, g, s)) return r;
+  if (int r = launch_softmax_rows(prec, ab.S, (int64_t)B * H * T, T, Tp, ab.P, s)) return r;
+  if (!vt_ready)
+    if (int r = launch_transpose_v(prec, V, B, T, H, dh, ldkv, 0, Tp, ab.Vt, s)) return r;
+  GemmArgs o;
+  o.A = ab.P; o.W = ab.Vt; o.C = out;
+  o.M = T; o.N = dh; o.K = Tp;
+  o.a_rpb = T; o.a_rstride = Tp;
+  o.ldw = Tp; o.ldc = ldo;
+  o.nz = B * H; o.nz2 = H;
+  o.a_z1 = (long)H * T * Tp; o.a_z2 = (long)T * Tp;
+  o.w_z1 = (long)H * dh * Tp; o.w_z2 = (long)dh * Tp;
+  o.c_z1 = (long)T * ldo; o.c_z2 = dh;
+  return launch_gemm(prec, o, s);
+}
+
+}  // namespace svt
+
+using namespace svt;
+
+// =================================================================================================
+// encoder
+// =================================================================================================
+struct ConvLayerW {
+  DevBuf w;      // layer 0: fp32 (C,k); others: operand type (Cout, k*Cin) tap-major
+  DevBuf bias;   // fp32 or empty
+  DevBuf gamma, beta;
+};
+struct EncLayerW {
+  DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+};
+
+struct svt_encoder {
+  svt_encoder_config cfg;
+  int device = 0;
+  bool finalized = false;
+  ParamMap params;
+  std::vector<ConvLayerW> conv;
+  DevBuf fp_g, fp_b, proj_w, proj_b, pos_w, pos_b, enc_g, enc_b;
+  std::vector<EncLayerW> layers;
+};
+
+static int validate_cfg(const svt_encoder_config& c) {
+  if (c.struct_size != (int32_t)sizeof(svt_encoder_config)) { set_error("svt_encoder_config: struct_size mismatch (ABI)"); return SVT_ERR_INVALID; }
+  if (c.num_conv_layers < 1 || c.num_conv_layers > SVT_MAX_CONV_LAYERS) { set_error("num_conv_layers out of range"); return SVT_ERR_INVALID; }
+  if (c.conv_kernel[0] != 10) { set_error("conv layer 0 must have kernel 10 (wav2vec2/HuBERT geometry)"); return SVT_ERR_INVALID; }
+  if (c.conv_stride[0] > 5 || c.conv_stride[0] < 1) { set_error("conv layer 0 stride must be 1..5"); return SVT_ERR_INVALID; }
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    if (c.conv_dim[i] % 8 || c.conv_dim[i] < 8) { set_error("conv_dim must be a multiple of 8"); return SVT_ERR_INVALID; }
+    if (c.conv_kernel[i] < 1 || c.conv_stride[i] < 1) { set_error("bad conv geometry"); return SVT_ERR_INVALID; }
+  }
+  if (c.conv_dim[0] > 512) { set_error("conv_dim[0] > 512 unsupported"); return SVT_ERR_INVALID; }
+  if (c.hidden_size % c.num_heads) { set_error("hidden_size % num_heads != 0"); return SVT_ERR_INVALID; }
+  const int dh = c.hidden_size / c.num_heads;
+  if (dh % 8) { set_error("head_dim must be a multiple of 8"); return SVT_ERR_INVALID; }
+  if (c.hidden_size % c.pos_conv_groups || (c.hidden_size / c.pos_conv_groups) % 8) { set_error("hidden_size/pos_conv_groups must be a multiple of 8"); return SVT_ERR_INVALID; }
+  if (c.intermediate_size % 8 || c.hidden_size % 8) { set_error("sizes must be multiples of 8"); return SVT_ERR_INVALID; }
+  if (c.feat_extract_norm != SVT_NORM_GROUP && c.feat_extract_norm != SVT_NORM_LAYER) { set_error("feat_extract_norm"); return SVT_ERR_INVALID; }
+  if (c.precision != SVT_PREC_FP32 && c.precision != SVT_PREC_BF16) { set_error("precision"); return SVT_ERR_INVALID; }
+  return SVT_OK;
+}
+
+static int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible: the MI355X path cannot run (there is no CPU fallback)"); return SVT_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { set_error("device index out of range"); return SVT_ERR_INVALID; }
+  hipDeviceProp_t prop;
+  SVT_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    set_error(std::string("device arch is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return SVT_ERR_NO_DEVICE;
+  }
+  SVT_HIP(hipSetDevice(device));
+  return SVT_OK;
+}
+
+extern "C" {
+
+const char* svt_last_error(void) { return g_err.c_str(); }
+int svt_abi_version(void) { return SVT_ABI_VERSION; }
+int svt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::string(prop.gcnArchName).find("gfx950") != std::string::npos) ++ok;
+  }
+  return ok;
+}
+
+int svt_prof_enable(int on) { g_prof.on = on != 0; return SVT_OK; }
+int svt_prof_reset(void) { g_prof.used = 0; g_prof.flops = 0; g_prof.bytes = 0; return SVT_OK; }
+int svt_prof_read(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
+  double ms = 0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    SVT_HIP(hipEventSynchronize(g_prof.ev[i].second));
+    float t = 0;
+    SVT_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
+    ms += t;
+  }
+  if (launches) *launches = (int64_t)g_prof.used;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = g_prof.flops;
+  if (total_bytes) *total_bytes = g_prof.bytes;
+  return SVT_OK;
+}
+
+int svt_encoder_create(const svt_encoder_config* cfg, int device, svt_encoder** out) {
+  if (!cfg || !out) { set_error("svt_encoder_create: null argument"); return SVT_ERR_INVALID; }
+  if (int r = validate_cfg(*cfg)) return r;
+  if (int r = check_device(device)) return r;
+  svt_encoder* e = new svt_encoder();
+  e->cfg = *cfg;
+  e->device = device;
+  *out = e;
+  return SVT_OK;
+}
+
+void svt_encoder_destroy(svt_encoder* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  delete e;
+}
+
+int svt_encoder_load_param(svt_encoder* e, const char* key, const void* data_host, int dtype, const int64_t* shape,
+                           int ndim) {
+  if (!e) { set_error("null encoder"); return SVT_ERR_INVALID; }
+  e->finalized = false;
+  return load_param_into(e->params, key, data_host, dtype, shape, ndim);
+}
+
+int svt_encoder_get_param(svt_encoder* e, const char* key, void* out_host, int64_t capacity_elems) {
+  if (!e || !key || !out_host) { set_error("get_param: null argument"); return SVT_ERR_INVALID; }
+  const Param* p = find(e->params, key);
+  if (!p) { set_error(std::string("unknown parameter: ") + key); return SVT_ERR_KEY; }
+  if ((int64_t)p->v.size() > capacity_elems) { set_error("get_param: buffer too small"); return SVT_ERR_INVALID; }
+  memcpy(out_host, p->v.data(), p->v.size() * 4);
+  return SVT_OK;
+}
+
+int svt_encoder_finalize(svt_encoder* e) {
+  if (!e) { set_error("null encoder"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(e->device));
+  const svt_encoder_config& c = e->cfg;
+  const int prec = c.precision;
+  const ParamMap& P = e->params;
+  const Param* p = nullptr;
+  e->conv.clear();
+  e->conv.resize(c.num_conv_layers);
+  int cin = 1;
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    const std::string pre = "feature_extractor.conv_layers." + std::to_string(i) + ".";
+    const int co = c.conv_dim[i], k = c.conv_kernel[i];
+    if (int r = need(P, pre + "conv.weight", {co, cin, k}, &p)) return r;
+    ConvLayerW& L = e->conv[i];
+    if (i == 0) {
+      if (int r = upload_f32(L.w, p->v.data(), p->v.size())) return r;
+    } else {
+      // (Cout, Cin, k) -> (Cout, k*Cin) tap-major: the implicit-GEMM row of output frame t is the
+      // contiguous channels-last slice x[t*s : t*s+k, :]
+      std::vector<float> wt((size_t)co * k * cin);
+      for (int o = 0; o < co; ++o)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int j = 0; j < k; ++j) wt[((size_t)o * k + j) * cin + ci] = p->v[((size_t)o * cin + ci) * k + j];
+      if (int r = upload_operand(prec, L.w, wt.data(), wt.size())) return r;
+    }
+    if (c.conv_bias) {
+      if (int r = need(P, pre + "conv.bias", {co}, &p)) return r;
+      if (int r = upload_f32(L.bias, p->v.data(), p->v.size())) return r;
+    }
+    const bool has_norm = c.feat_extract_norm == SVT_NORM_LAYER || i == 0;
+    if (has_norm) {
+      if (int r = need(P, pre + "layer_norm.weight", {co}, &p)) return r;
+      if (int r = upload_f32(L.gamma, p->v.data(), p->v.size())) return r;
+      if (int r = need(P, pre + "layer_norm.bias", {co}, &p)) return r;
+      if (int r = upload_f32(L.beta, p->v.data(), p->v.size())) return r;
+    }
+    cin = co;
+  }
+  const int D = c.hidden_size, F = c.intermediate_size;
+  if (c.feat_proj_layer_norm) {
+    if (int r = need(P, "feature_projection.layer_norm.weight", {cin}, &p)) return r;
+    if (int r = upload_f32(e->fp_g, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, "feature_projection.layer_norm.bias", {cin}, &p)) return r;
+    if (int r = upload_f32(e->fp_b, p->v.data(), p->v.size())) return r;
+  }
+  if (int r = need(P, "feature_projection.projection.weight", {D, cin}, &p)) return r;
+  if (int r = upload_operand(prec, e->proj_w, p->v.data(), p->v.size())) return r;
+  if (int r = need(P, "feature_projection.projection.bias", {D}, &p)) return r;
+  if (int r = upload_f32(e->proj_b, p->v.data(), p->v.size())) return r;
+
+  // positional conv: fold weight-norm (dim=2): W[:,:,j] = g[j] v[:,:,j] / ||v[:,:,j]||_F ; accept both spellings
+  {
+    const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
+    const std::string pc = "encoder.pos_conv_embed.conv.";
+    std::vector<float> w((size_t)D * cg * kp);
+    const Param *g = find(P, pc + "parametrizations.weight.original0"), *v = find(P, pc + "parametrizations.weight.original1");
+    if (!g || !v) { g = find(P, pc + "weight_g"); v = find(P, pc + "weight_v"); }
+    if (g && v) {
+      if (g->numel() != kp || v->shape != std::vector<int64_t>({D, cg, kp})) { set_error("pos_conv weight-norm tensors have the wrong shape"); return SVT_ERR_INVALID; }
+      std::vector<double> nrm(kp, 0.0);
+      for (size_t i = 0; i < v->v.size(); ++i) nrm[i % kp] += (double)v->v[i] * (double)v->v[i];
+      for (int j = 0; j < kp; ++j) nrm[j] = std::sqrt(nrm[j]);
+      for (size_t i = 0; i < v->v.size(); ++i) w[i] = (float)((double)g->v[i % kp] * (double)v->v[i] / nrm[i % kp]);
+    } else if (const Param* pw = find(P, pc + "weight")) {
+      if (pw->shape != std::vector<int64_t>({D, cg, kp})) { set_error("pos_conv weight has the wrong shape"); return SVT_ERR_INVALID; }
+      w = pw->v;
+    } else {
+      set_error("missing parameter: " + pc + "parametrizations.weight.original0/1 (or weight_g/weight_v)");
+      return SVT_ERR_KEY;
+    }
+    // (D, cg, kp) -> per group (cg_out, kp*cg_in) tap-major
+    std::vector<float> wt(w.size());
+    for (int o = 0; o < D; ++o)
+      for (int ci = 0; ci < cg; ++ci)
+        for (int j = 0; j < kp; ++j) wt[((size_t)o * kp + j) * cg + ci] = w[((size_t)o * cg + ci) * kp + j];
+    if (int r = upload_operand(prec, e->pos_w, wt.data(), wt.size())) return r;
+    if (int r = need(P, pc + "bias", {D}, &p)) return r;
+    if (int r = upload_f32(e->pos_b, p->v.data(), p->v.size())) return r;
+  }
+  if (int r = need(P, "encoder.layer_norm.weight", {D}, &p)) return r;
+  if (int r = upload_f32(e->enc_g, p->v.data(), p->v.size())) return r;
+  if (int r = need(P, "encoder.layer_norm.bias", {D}, &p)) return r;
+  if (int r = upload_f32(e->enc_b, p->v.data(), p->v.size())) return r;
+
+  e->layers.clear();
+  e->layers.resize(c.num_layers);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string pre = "encoder.layers." + std::to_string(l) + ".";
+    EncLayerW& L = e->layers[l];
+    std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D);
+    const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int i = 0; i < 3; ++i) {
+      if (int r = need(P, pre + "attention." + names[i] + ".weight", {D, D}, &p)) return r;
+      memcpy(wqkv.data() + (size_t)i * D * D, p->v.data(), (size_t)D * D * 4);
+      if (int r = need(P, pre + "attention." + names[i] + ".bias", {D}, &p)) return r;
+      memcpy(bqkv.data() + (size_t)i * D, p->v.data(), (size_t)D * 4);
+    }
+    if (int r = upload_operand(prec, L.wqkv, wqkv.data(), wqkv.size())) return r;
+    if (int r = upload_f32(L.bqkv, bqkv.data(), bqkv.size())) return r;
+    if (int r = need(P, pre + "attention.out_proj.weight", {D, D}, &p)) return r;
+    if (int r = upload_operand(prec, L.wo, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "attention.out_proj.bias", {D}, &p)) return r;
+    if (int r = upload_f32(L.bo, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "layer_norm.weight", {D}, &p)) return r;
+    if (int r = upload_f32(L.ln1g, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "layer_norm.bias", {D}, &p)) return r;
+    if (int r = upload_f32(L.ln1b, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "feed_forward.intermediate_dense.weight", {F, D}, &p)) return r;
+    if (int r = upload_operand(prec, L.w1, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "feed_forward.intermediate_dense.bias", {F}, &p)) return r;
+    if (int r = upload_f32(L.b1, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "feed_forward.output_dense.weight", {D, F}, &p)) return r;
+    if (int r = upload_operand(prec, L.w2, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "feed_forward.output_dense.bias", {D}, &p)) return r;
+    if (int r = upload_f32(L.b2, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "final_layer_norm.weight", {D}, &p)) return r;
+    if (int r = upload_f32(L.ln2g, p->v.data(), p->v.size())) return r;
+    if (int r = need(P, pre + "final_layer_norm.bias", {D}, &p)) return r;
+    if (int r = upload_f32(L.ln2b, p->v.data(), p->v.size())) return r;
+  }
+  SVT_HIP(hipDeviceSynchronize());
+  e->finalized = true;
+  return SVT_OK;
+}
+
+int64_t svt_encoder_num_frames(const svt_encoder* e, int64_t n_samples) {
+  if (!e) return -1;
+  int64_t t = n_samples;
+  for (int i = 0; i < e->cfg.num_conv_layers; ++i) {
+    if (t < e->cfg.conv_kernel[i]) return 0;
+    t = (t - e->cfg.conv_kernel[i]) / e->cfg.conv_stride[i] + 1;
+  }
+  return t;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct EncWs {
+  double* mom;      // [0..1] wav, [2..3] out, [4 ..] window moments B*65
+  size_t mom_bytes;
+  float* coef;
+  void* act[2];
+  float* convF;     // fp32 pre-LN conv output (layer mode)
+  void* xln;
+  float* hF;
+  float* preF;
+  void* xb;
+  float* xF;
+  void* posg;
+  void* qkv;
+  AttnBufs ab;
+  void* attn_o;
+  void* ffn;
+  size_t total;
+};
+
+EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
+  const svt_encoder_config& c = e->cfg;
+  const size_t es = esize(c.precision);
+  Carver cv(base);
+  EncWs w;
+  w.mom_bytes = align_up((4 + (size_t)B * 65) * sizeof(double));
+  w.mom = (double*)cv.take(w.mom_bytes);
+  w.coef = (float*)cv.take((size_t)B * c.conv_dim[0] * 11 * 4);
+  size_t max_act = 0, max_f = 0;
+  int64_t t = L;
+  for (int i = 0; i < c.num_conv_layers; ++i) {
+    t = (t - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    const size_t n = (size_t)B * t * c.conv_dim[i];
+    if (n * es > max_act) max_act = n * es;
+    if (i > 0 && n * 4 > max_f) max_f = n * 4;
+  }
+  const int64_t T = t;
+  w.act[0] = cv.take(max_act);
+  w.act[1] = cv.take(max_act);
+  w.convF = c.feat_extract_norm == SVT_NORM_LAYER ? (float*)cv.take(max_f) : nullptr;
+  const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
+  const size_t rows = (size_t)B * T;
+  const int Tp = round_up_int((int)T, 8);
+  w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers - 1] * es);
+  w.hF = (float*)cv.take(rows * D * 4);
+  w.preF = (float*)cv.take(rows * D * 4);
+  w.xb = cv.take(rows * D * es);
+  w.xF = c.precision ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
+  w.posg = cv.take((size_t)B * (T + c.pos_conv_kernel) * D * es);
+  w.qkv = cv.take(rows * 3 * D * es);
+  w.ab.S = (float*)cv.take((size_t)B * H * T * Tp * 4);
+  w.ab.P = cv.take((size_t)B * H * T * Tp * es);
+  w.ab.Vt = cv.take((size_t)B * H * dh * Tp * es);
+  w.attn_o = cv.take(rows * D * es);
+  w.ffn = cv.take(rows * F * es);
+  w.total = cv.off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t n_samples) {
+  if (!e || batch < 1) { set_error("workspace_bytes: bad argument"); return -1; }
+  if (svt_encoder_num_frames(e, n_samples) < 1) { set_error("waveform shorter than the receptive field"); return -1; }
+  return (int64_t)carve_encoder(e, batch, n_samples, nullptr).total;
+}
+
+int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, float* feats, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!e || !wav || !feats || !workspace) { set_error("encoder_forward: null argument"); return SVT_ERR_INVALID; }
+  if (!e->finalized) { set_error("encoder_forward: parameters not finalized"); return SVT_ERR_STATE; }
+  if (B < 1) { set_error("encoder_forward: batch < 1"); return SVT_ERR_INVALID; }
+  const int64_t T = svt_encoder_num_frames(e, L);
+  if (T < 1) { set_error("encoder_forward: waveform shorter than the receptive field"); return SVT_ERR_INVALID; }
+  const svt_encoder_config& c = e->cfg;
+  const int prec = c.precision;
+  EncWs w = carve_encoder(e, B, L, workspace);
+  if (w.total > workspace_bytes) { set_error("encoder_forward: workspace too small (" + std::to_string(workspace_bytes) + " < " + std::to_string(w.total) + ")"); return SVT_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  SVT_HIP(hipSetDevice(e->device));
+  SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_bytes, s));
+  double* wav_mom = c.normalize_wav ? w.mom : nullptr;
+  double* out_mom = w.mom + 2;
+  double* wm = w.mom + 4;
+  const int64_t n_wav = (int64_t)B * L;
+  if (c.normalize_wav)
+    if (int r = launch_moments(wav, n_wav, wav_mom, s)) return r;
+
+  // ---- conv feature extractor (channels-last activations) ----
+  int64_t tin = L;
+  int64_t t1 = (L - c.conv_kernel[0]) / c.conv_stride[0] + 1;
+  const ConvLayerW& c0 = e->conv[0];
+  if (c.feat_extract_norm == SVT_NORM_GROUP) {
+    if (int r = launch_conv0_window_moments(wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, wm, s)) return r;
+    if (int r = launch_conv0_group_coef(wav_mom, n_wav, wm, B, t1, c.conv_dim[0], c.conv_kernel[0], c0.w.as<float>(),
+                                        c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
+                                        c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s)) return r;
+    if (int r = launch_conv0_group_apply(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], w.coef,
+                                         w.act[0], s)) return r;
+  } else {
+    if (int r = launch_conv0_layer(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], wav_mom, n_wav,
+                                   1e-5f, c0.w.as<float>(), c.conv_bias ? c0.bias.as<float>() : nullptr,
+                                   c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s)) return r;
+  }
+  tin = t1;
+  int cur = 0;
+  for (int i = 1; i < c.num_conv_layers; ++i) {
+    const int cin = c.conv_dim[i - 1], co = c.conv_dim[i], k = c.conv_kernel[i], st = c.conv_stride[i];
+    const int64_t tout = (tin - k) / st + 1;
+    const ConvLayerW& Lw = e->conv[i];
+    GemmArgs g;
+    g.A = w.act[cur]; g.W = Lw.w.p;
+    g.M = (int)((int64_t)B * tout); g.N = co; g.K = k * cin;
+    g.a_rpb = (int)tout; g.a_bstride = tin * cin; g.a_rstride = (long)st * cin;
+    g.ldw = g.K; g.ldc = co;
+    g.bias = c.conv_bias ? Lw.bias.as<float>() : nullptr;
+    if ((int64_t)B * tout > 2147483647LL) { set_error("encoder_forward: batch*frames exceeds 2^31"); return SVT_ERR_INVALID; }
+    if (c.feat_extract_norm == SVT_NORM_LAYER) {
+      g.C = w.convF; g.out_f32 = 1; g.act = ACT_NONE;
+      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_layernorm(prec, w.convF, 1, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(),
+                                   1e-5f, 1, w.act[cur ^ 1], nullptr, s)) return r;
+    } else {
+      g.C = w.act[cur ^ 1]; g.act = ACT_GELU;
+      if (int r = launch_gemm(prec, g, s)) return r;
+    }
+    cur ^= 1;
+    tin = tout;
+  }
+  const int C = c.conv_dim[c.num_conv_layers - 1];
+  const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
+  const int64_t rows = (int64_t)B * T;
+  const float eps = c.layer_norm_eps;
+
+  // ---- feature projection ----
+  const void* proj_in = w.act[cur];
+  if (c.feat_proj_layer_norm) {
+    if (int r = launch_layernorm(prec, w.act[cur], prec ? 0 : 1, rows, C, e->fp_g.as<float>(), e->fp_b.as<float>(), eps, 0,
+                                 w.xln, nullptr, s)) return r;
+    proj_in = w.xln;
+  }
+  {
+    GemmArgs g;
+    g.A = proj_in; g.W = e->proj_w.p; g.C = w.hF; g.bias = e->proj_b.as<float>();
+    g.M = (int)rows; g.N = D; g.K = C; g.a_rpb = (int)rows; g.a_rstride = C; g.ldw = C; g.ldc = D; g.out_f32 = 1;
+    if (int r = launch_gemm(prec, g, s)) return r;
+  }
+  // ---- positional conv embedding: pre = h + gelu(grouped_conv(h) + b) ----
+  {
+    const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
+    if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, w.posg, s)) return r;
+    GemmArgs g;
+    g.A = w.posg; g.W = e->pos_w.p; g.C = w.preF; g.bias = e->pos_b.as<float>(); g.resid = w.hF;
+    g.M = (int)T; g.N = cg; g.K = kp * cg;
+    g.a_rpb = (int)T; g.a_rstride = cg;
+    g.ldw = g.K; g.ldc = D;
+    g.nz = B * G; g.nz2 = G;
+    g.a_z1 = (long)G * (T + kp) * cg; g.a_z2 = (long)(T + kp) * cg;
+    g.w_z1 = 0; g.w_z2 = (long)cg * g.K;
+    g.c_z1 = (long)T * D; g.c_z2 = cg; g.bias_z2 = cg;
+    g.act = ACT_GELU; g.out_f32 = 1;
+    if (int r = launch_gemm(prec, g, s)) return r;
+  }
+  const float scale = 1.0f / std::sqrt((float)dh);
+  auto attention = [&](void) -> int {
+    return attention_scores_path(prec, w.qkv, 3L * D, (const char*)w.qkv + (size_t)D * esize(prec),
+                                 (const char*)w.qkv + (size_t)2 * D * esize(prec), 3L * D, B, (int)T, H, dh, scale, w.ab,
+                                 false, w.attn_o, D, s);
+  };
+  auto gemm_rows = [&](const void* A, int K, const DevBuf& W, const DevBuf& bias, int N, void* Cout, int out_f32, int act,
+                       const float* resid) -> int {
+    GemmArgs g;
+    g.A = A; g.W = W.p; g.C = Cout; g.bias = bias.as<float>(); g.resid = resid;
+    g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N;
+    g.out_f32 = out_f32; g.act = act;
+    return launch_gemm(prec, g, s);
+  };
+  float* final_x = nullptr;
+  if (!c.stable_layer_norm) {
+    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.xb,
+                                 prec ? w.xF : nullptr, s)) return r;
+    for (int l = 0; l < c.num_layers; ++l) {
+      const EncLayerW& Lw = e->layers[l];
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = attention()) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, w.preF, 1, ACT_NONE, w.xF)) return r;
+      if (int r = launch_layernorm(prec, w.preF, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
+                                   prec ? w.xF : nullptr, s)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, w.preF, 1, ACT_NONE, w.xF)) return r;
+      if (int r = launch_layernorm(prec, w.preF, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb,
+                                   prec ? w.xF : nullptr, s)) return r;
+    }
+    final_x = w.xF;
+  } else {
+    float* h = w.preF;
+    for (int l = 0; l < c.num_layers; ++l) {
+      const EncLayerW& Lw = e->layers[l];
+      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb, nullptr, s)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = attention()) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, h, 1, ACT_NONE, h)) return r;
+      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb, nullptr, s)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, h, 1, ACT_NONE, h)) return r;
+    }
+    // final LN -> fp32 (hF is free by now)
+    if (int r = launch_layernorm(0, h, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.hF, nullptr, s)) return r;
+    final_x = w.hF;
+  }
+  // ---- wrapper's whole-batch output LayerNorm ----
+  const int64_t n_out = rows * D;
+  if (c.output_norm) {
+    if (int r = launch_moments(final_x, n_out, out_mom, s)) return r;
+    if (int r = launch_global_norm(final_x, feats, n_out, out_mom, 1e-5f, s)) return r;
+  } else {
+    SVT_HIP(hipMemcpyAsync(feats, final_x, (size_t)n_out * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return SVT_OK;
+}
+
+// =================================================================================================
+// frame head + decode
+// =================================================================================================
+}  // extern "C"
+
+struct svt_linear {
+  int in_f = 0, out_f = 0, has_bias = 0, device = 0;
+  bool loaded = false;
+  DevBuf w, b;
+};
+
+extern "C" {
+
+int svt_linear_create(int32_t in_features, int32_t out_features, int has_bias, int device, svt_linear** out) {
+  if (!out || in_features < 1 || out_features < 1) { set_error("svt_linear_create: bad argument"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  svt_linear* l = new svt_linear();
+  l->in_f = in_features; l->out_f = out_features; l->has_bias = has_bias; l->device = device;
+  *out = l;
+  return SVT_OK;
+}
+void svt_linear_destroy(svt_linear* l) {
+  if (!l) return;
+  (void)hipSetDevice(l->device);
+  delete l;
+}
+int svt_linear_load(svt_linear* l, const float* weight_host, const float* bias_host) {
+  if (!l || !weight_host) { set_error("svt_linear_load: null argument"); return SVT_ERR_INVALID; }
+  if (l->has_bias && !bias_host) { set_error("svt_linear_load: bias expected"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(l->device));
+  if (int r = upload_f32(l->w, weight_host, (size_t)l->in_f * l->out_f)) return r;
+  if (l->has_bias)
+    if (int r = upload_f32(l->b, bias_host, (size_t)l->out_f)) return r;
+  l->loaded = true;
+  return SVT_OK;
+}
+int svt_linear_forward(svt_linear* l, const float* x, int64_t rows, float* y, void* stream) {
+  if (!l || !x || !y) { set_error("svt_linear_forward: null argument"); return SVT_ERR_INVALID; }
+  if (!l->loaded) { set_error("svt_linear_forward: weights not loaded"); return SVT_ERR_STATE; }
+  if (rows < 1) return SVT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  SVT_HIP(hipSetDevice(l->device));
+  const float* b = l->has_bias ? l->b.as<float>() : nullptr;
+  if (l->out_f <= 32) return launch_linear_f32(x, rows, l->in_f, l->w.as<float>(), b, l->out_f, y, s);
+  if (l->in_f % 4) { set_error("svt_linear_forward: in_features must be a multiple of 4 for out_features > 32"); return SVT_ERR_INVALID; }
+  if (rows > 2147483647LL) { set_error("svt_linear_forward: too many rows"); return SVT_ERR_INVALID; }
+  GemmArgs g;
+  g.A = x; g.W = l->w.p; g.C = y; g.bias = b;
+  g.M = (int)rows; g.N = l->out_f; g.K = l->in_f; g.a_rpb = (int)rows; g.a_rstride = l->in_f; g.ldw = l->in_f;
+  g.ldc = l->out_f; g.out_f32 = 1;
+  return launch_gemm(0, g, s);
+}
+
+int svt_decode_frames(const float* logits, int64_t rows, int32_t n_out, int32_t n_octave, int32_t n_class,
+                      svt_frame* frames, int device, void* stream) {
+  if (!logits || !frames) { set_error("svt_decode_frames: null argument"); return SVT_ERR_INVALID; }
+  if (n_out != 2 + n_octave + 1 + n_class + 1) { set_error("svt_decode_frames: n_out != 2 + (n_octave+1) + (n_class+1)"); return SVT_ERR_INVALID; }
+  if (rows < 1) return SVT_OK;
+  SVT_HIP(hipSetDevice(device));
+  static_assert(sizeof(svt_frame) == sizeof(FrameOut), "frame layout");
+  return launch_decode_frames(logits, rows, n_out, n_octave, n_class, (FrameOut*)frames, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// RCA fusion
+// =================================================================================================
+struct RcaLayerW {
+  DevBuf win, bin, wo, bo, w1, b1, w2, b2, n1g, n1b, n2g, n2b;
+};
+struct svt_rca {
+  int D = 0, H = 0, F = 0, max_len = 0, prec = 0, device = 0;
+  float alpha = 0.5f;
+  bool finalized = false;
+  ParamMap params;
+  DevBuf pe;
+  RcaLayerW L[2];
+};
+
+namespace {
+struct RcaWs {
+  float *s1F, *s2F;
+  void *s1T, *s2T;
+  void* qkv;     // (rows, 3D) projections of the kv stream
+  void* qc;      // (rows, D) cross query
+  AttnBufs ab;
+  void *att_s, *att_c, *blend;
+  float *preF, *xF;
+  void* xT;
+  void* ffn;
+  float *o1, *o2;
+  size_t total;
+};
+RcaWs carve_rca(const svt_rca* r, int B, int T, void* base) {
+  Carver cv(base);
+  RcaWs w;
+  const size_t es = esize(r->prec), rows = (size_t)B * T, D = r->D;
+  const int dh = r->D / r->H, Tp = round_up_int(T, 8);
+  w.s1F = (float*)cv.take(rows * D * 4);
+  w.s2F = (float*)cv.take(rows * D * 4);
+  w.s1T = r->prec ? cv.take(rows * D * es) : (void*)w.s1F;
+  w.s2T = r->prec ? cv.take(rows * D * es) : (void*)w.s2F;
+  w.qkv = cv.take(rows * 3 * D * es);
+  w.qc = cv.take(rows * D * es);
+  w.ab.S = (float*)cv.take((size_t)B * r->H * T * Tp * 4);
+  w.ab.P = cv.take((size_t)B * r->H * T * Tp * es);
+  w.ab.Vt = cv.take((size_t)B * r->H * dh * Tp * es);
+  w.att_s = cv.take(rows * D * es);
+  w.att_c = cv.take(rows * D * es);
+  w.blend = cv.take(rows * D * es);
+  w.preF = (float*)cv.take(rows * D * 4);
+  w.xT = cv.take(rows * D * es);
+  w.xF = r->prec ? (float*)cv.take(rows * D * 4) : (float*)w.xT;
+  w.ffn = cv.take(rows * r->F * es);
+  w.o1 = (float*)cv.take(rows * D * 4);
+  w.o2 = (float*)cv.take(rows * D * 4);
+  w.total = cv.off;
+  return w;
+}
+}  // namespace
+
+extern "C" {
+
+int svt_rca_create(int32_t d_model, int32_t nhead, int32_t d_ffn, float alpha, int32_t max_len, int32_t precision,
+                   int device, svt_rca** out) {
+  if (!out || d_model < 8 || nhead < 1 || d_model % nhead || (d_model / nhead) % 8 || d_ffn % 8 || d_model % 8) {
+    set_error("svt_rca_create: bad geometry");
+    return SVT_ERR_INVALID;
+  }
+  if (precision != SVT_PREC_FP32 && precision != SVT_PREC_BF16) { set_error("svt_rca_create: precision"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  svt_rca* r = new svt_rca();
+  r->D = d_model; r->H = nhead; r->F = d_ffn; r->alpha = alpha; r->max_len = max_len; r->prec = precision; r->device = device;
+  *out = r;
+  return SVT_OK;
+}
+void svt_rca_destroy(svt_rca* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  delete r;
+}
+int svt_rca_load_param(svt_rca* r, const char* key, const void* data_host, int dtype, const int64_t* shape, int ndim) {
+  if (!r) { set_error("null rca"); return SVT_ERR_INVALID; }
+  r->finalized = false;
+  return load_param_into(r->params, key, data_host, dtype, shape, ndim);
+}
+int svt_rca_finalize(svt_rca* r) {
+  if (!r) { set_error("null rca"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(r->device));
+  const ParamMap& P = r->params;
+  const Param* p = nullptr;
+  const int D = r->D, F = r->F;
+  if (int rc = need(P, "fusion.positional_encoding.pe", {1, r->max_len, D}, &p)) return rc;
+  if (int rc = upload_f32(r->pe, p->v.data(), p->v.size())) return rc;
+  for (int l = 0; l < 2; ++l) {
+    const std::string pre = std::string("fusion.layer") + (l ? "2" : "1") + ".";
+    RcaLayerW& L = r->L[l];
+    if (int rc = need(P, pre + "self_att.att.in_proj_weight", {3 * D, D}, &p)) return rc;
+    if (int rc = upload_operand(r->prec, L.win, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "self_att.att.in_proj_bias", {3 * D}, &p)) return rc;
+    if (int rc = upload_f32(L.bin, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "self_att.att.out_proj.weight", {D, D}, &p)) return rc;
+    if (int rc = upload_operand(r->prec, L.wo, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "self_att.att.out_proj.bias", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.bo, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "pos_ffn.ffn.0.weight", {F, D}, &p)) return rc;
+    if (int rc = upload_operand(r->prec, L.w1, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "pos_ffn.ffn.0.bias", {F}, &p)) return rc;
+    if (int rc = upload_f32(L.b1, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "pos_ffn.ffn.3.weight", {D, F}, &p)) return rc;
+    if (int rc = upload_operand(r->prec, L.w2, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "pos_ffn.ffn.3.bias", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.b2, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "norm1.norm.weight", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.n1g, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "norm1.norm.bias", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.n1b, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "norm2.norm.weight", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.n2g, p->v.data(), p->v.size())) return rc;
+    if (int rc = need(P, pre + "norm2.norm.bias", {D}, &p)) return rc;
+    if (int rc = upload_f32(L.n2b, p->v.data(), p->v.size())) return rc;
+  }
+  SVT_HIP(hipDeviceSynchronize());
+  r->finalized = true;
+  return SVT_OK;
+}
+int64_t svt_rca_workspace_bytes(const svt_rca* r, int32_t batch, int32_t t_audio) {
+  if (!r || batch < 1 || t_audio < 1) { set_error("svt_rca_workspace_bytes: bad argument"); return -1; }
+  return (int64_t)carve_rca(r, batch, t_audio, nullptr).total;
+}
+
+int svt_rca_forward(svt_rca* r, const float* audio, int32_t T1, const float* video, int32_t T2, int32_t B, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!r || !audio || !video || !out || !workspace) { set_error("svt_rca_forward: null argument"); return SVT_ERR_INVALID; }
+  if (!r->finalized) { set_error("svt_rca_forward: parameters not finalized"); return SVT_ERR_STATE; }
+  if (B < 1 || T1 < 1 || T2 < 1) { set_error("svt_rca_forward: empty input"); return SVT_ERR_INVALID; }
+  if (T1 > r->max_len) { set_error("svt_rca_forward: sequence longer than the positional table"); return SVT_ERR_INVALID; }
+  RcaWs w = carve_rca(r, B, T1, workspace);
+  if (w.total > workspace_bytes) { set_error("svt_rca_forward: workspace too small"); return SVT_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  SVT_HIP(hipSetDevice(r->device));
+  const int prec = r->prec, D = r->D, H = r->H, F = r->F, dh = D / H, T = T1;
+  const int64_t rows = (int64_t)B * T;
+  const size_t es = esize(prec);
+  // frame alignment (fusion.py:195-205) + positional encoding (fusion.py:60-61)
+  if (int rc = launch_add_pe(prec, audio, B, T, T, D, r->pe.as<float>(), w.s1F, prec ? w.s1T : nullptr, s)) return rc;
+  // video: T2 frames per clip in memory; frames >= T1 are dropped, frames in [T2, T1) read as zero
+  if (int rc = launch_add_pe(prec, video, B, T, T2, D, r->pe.as<float>(), w.s2F, prec ? w.s2T : nullptr, s)) return rc;
+  const float scale = 1.0f / std::sqrt((float)dh);
+  auto gemm_rows = [&](const void* A, int K, const void* W, const float* bias, int N, void* C, int out_f32, int act,
+                       const float* resid) -> int {
+    GemmArgs g;
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
+    g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N; g.out_f32 = out_f32; g.act = act;
+    return launch_gemm(prec, g, s);
+  };
+  auto layer = [&](const RcaLayerW& L, const void* kvT, const float* kvF, const void* qT, float* outF) -> int {
+    // one packed in-projection of the kv stream gives the self-attention q, and k, v for BOTH attentions
+    if (int rc = gemm_rows(kvT, D, L.win.p, L.bin.as<float>(), 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return rc;
+    if (int rc = gemm_rows(qT, D, L.win.p, L.bin.as<float>(), D, w.qc, 0, ACT_NONE, nullptr)) return rc;
+    const char* kp = (const char*)w.qkv + (size_t)D * es;
+    const char* vp = (const char*)w.qkv + (size_t)2 * D * es;
+    if (int rc = attention_scores_path(prec, w.qkv, 3L * D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, false, w.att_s, D, s)) return rc;
+    if (int rc = attention_scores_path(prec, w.qc, D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, true, w.att_c, D, s)) return rc;
+    // out_proj is linear: alpha*Wo(a_s) + (1-alpha)*Wo(a_c) + bo = Wo(alpha*a_s + (1-alpha)*a_c) + bo
+    if (int rc = launch_axpby(prec, w.att_s, w.att_c, r->alpha, 1.f - r->alpha, w.blend, rows * D, s)) return rc;
+    if (int rc = gemm_rows(w.blend, D, L.wo.p, L.bo.as<float>(), D, w.preF, 1, ACT_NONE, kvF)) return rc;
+    if (int rc = launch_layernorm(prec, w.preF, 1, rows, D, L.n1g.as<float>(), L.n1b.as<float>(), 1e-6f, 0, w.xT,
+                                  prec ? w.xF : nullptr, s)) return rc;
+    if (int rc = gemm_rows(w.xT, D, L.w1.p, L.b1.as<float>(), F, w.ffn, 0, ACT_RELU, nullptr)) return rc;
+    if (int rc = gemm_rows(w.ffn, F, L.w2.p, L.b2.as<float>(), D, w.preF, 1, ACT_NONE, w.xF)) return rc;
+    return launch_layernorm(0, w.preF, 1, rows, D, L.n2g.as<float>(), L.n2b.as<float>(), 1e-6f, 0, outF, nullptr, s);
+  };
+  if (int rc = layer(r->L[0], w.s1T, w.s1F, w.s2T, w.o1)) return rc;
+  if (int rc = layer(r->L[1], w.s2T, w.s2F, w.s1T, w.o2)) return rc;
+  return launch_add_f32(w.o1, w.o2, out, rows * D, s);
+}
+
+// =================================================================================================
+// CTC greedy, Fbank
+// =================================================================================================
+int svt_ctc_greedy(const float* probs, int32_t B, int32_t T, int32_t V, const float* rel_lens, int32_t blank,
+                   int32_t* tokens, int32_t* out_lens, int device, void* stream) {
+  if (!probs || !rel_lens || !tokens || !out_lens) { set_error("svt_ctc_greedy: null argument"); return SVT_ERR_INVALID; }
+  if (B < 1 || T < 1 || V < 1) { set_error("svt_ctc_greedy: empty input"); return SVT_ERR_INVALID; }
+  if (blank < 0) blank += V;
+  SVT_HIP(hipSetDevice(device));
+  return launch_ctc_greedy(probs, B, T, V, rel_lens, blank, tokens, out_lens, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace {
+struct FbankConst {
+  DevBuf window, basis, mel;
+  int nb = 0, nbp = 0;
+};
+std::mutex g_fb_mu;
+std::map<std::string, FbankConst*> g_fb;
+
+int fbank_consts(int device, int sr, int n_fft, int win, int n_mels, float f_min, float f_max, FbankConst** out) {
+  const std::string key = std::to_string(device) + ":" + std::to_string(sr) + ":" + std::to_string(n_fft) + ":" +
+                          std::to_string(win) + ":" + std::to_string(n_mels) + ":" + std::to_string(f_min) + ":" + std::to_string(f_max);
+  std::lock_guard<std::mutex> lk(g_fb_mu);
+  auto it = g_fb.find(key);
+  if (it != g_fb.end()) { *out = it->second; return 0; }
+  FbankConst* fc = new FbankConst();
+  const int nb = n_fft / 2 + 1, nbp = round_up_int(nb, 8);
+  fc->nb = nb; fc->nbp = nbp;
+  // periodic hamming window of length win, centred in n_fft
+  std::vector<float> window(n_fft, 0.f);
+  const int left = (n_fft - win) / 2;
+  for (int n = 0; n < win; ++n) window[left + n] = (float)(0.54 - 0.46 * std::cos(2.0 * M_PI * n / win));
+  // DFT basis rows: [0,nb) cos, [nbp,nbp+nb) -sin, zero rows in between (keeps every row 16-byte aligned)
+  std::vector<float> basis((size_t)2 * nbp * n_fft, 0.f);
+  for (int k = 0; k < nb; ++k)
+    for (int n = 0; n < n_fft; ++n) {
+      const double a = 2.0 * M_PI * (double)((long)k * n % n_fft) / n_fft;
+      basis[(size_t)k * n_fft + n] = (float)std::cos(a);
+      basis[(size_t)(nbp + k) * n_fft + n] = (float)(-std::sin(a));
+    }
+  // triangular mel filters (speechbrain/processing/features.py:452-470,586-610), fp32 arithmetic like the reference
+  std::vector<float> mel((size_t)n_mels * nbp, 0.f);
+  {
+    const double mlo = 2595.0 * std::log10(1.0 + f_min / 700.0), mhi = 2595.0 * std::log10(1.0 + f_max / 700.0);
+    std::vector<float> hz(n_mels + 2);
+    for (int i = 0; i < n_mels + 2; ++i) {
+      // torch.linspace in fp32: start + i*step for the first half, end - (n-1-i)*step for the second
+      const float start = (float)mlo, end = (float)mhi;
+      const float step = (end - start) / (float)(n_mels + 1);
+      const float m = (i < (n_mels + 2) / 2) ? start + step * (float)i : end - step * (float)(n_mels + 1 - i);
+      hz[i] = 700.f * (std::pow(10.f, m / 2595.f) - 1.f);
+    }
+    for (int f = 0; f < n_mels; ++f) {
+      const float fc_ = hz[f + 1], band = hz[f + 1] - hz[f];
+      for (int k = 0; k < nb; ++k) {
+        const float start = 0.f, end = (float)(sr / 2);
+        const float step = (end - start) / (float)(nb - 1);
+        const float fr = (k < nb / 2) ? start + step * (float)k : end - step * (float)(nb - 1 - k);
+        const float slope = (fr - fc_) / band;
+        const float v = std::fmax(0.f, std::fmin(slope + 1.f, -slope + 1.f));
+        mel[(size_t)f * nbp + k] = v;
+      }
+    }
+  }
+  if (int r = upload_f32(fc->window, window.data(), window.size())) return r;
+  if (int r = upload_f32(fc->basis, basis.data(), basis.size())) return r;
+  if (int r = upload_f32(fc->mel, mel.data(), mel.size())) return r;
+  g_fb[key] = fc;
+  *out = fc;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t svt_fbank_workspace_bytes(int32_t B, int64_t L, int32_t n_fft, int32_t hop, int32_t n_mels) {
+  if (B < 1 || L < 1 || n_fft < 8 || hop < 1) return -1;
+  const int64_t nf = 1 + L / hop;
+  const int nb = n_fft / 2 + 1, nbp = round_up_int(nb, 8);
+  const size_t rows = (size_t)B * nf;
+  (void)n_mels;
+  (void)nb;
+  return (int64_t)(align_up(rows * n_fft * 4) + align_up(rows * 2 * nbp * 4) + align_up(rows * nbp * 4));
+}
+
+int svt_fbank(const float* wav, int32_t B, int64_t L, int32_t sr, int32_t n_fft, int32_t win_length, int32_t hop,
+              int32_t n_mels, float f_min, float f_max, float top_db, float* out, void* workspace, size_t workspace_bytes,
+              int device, void* stream) {
+  if (!wav || !out || !workspace) { set_error("svt_fbank: null argument"); return SVT_ERR_INVALID; }
+  if (n_fft % 4 || win_length > n_fft || n_mels < 1 || n_mels > 1024) { set_error("svt_fbank: unsupported geometry"); return SVT_ERR_INVALID; }
+  const int64_t need_bytes = svt_fbank_workspace_bytes(B, L, n_fft, hop, n_mels);
+  if (need_bytes < 0 || (size_t)need_bytes > workspace_bytes) { set_error("svt_fbank: workspace too small"); return SVT_ERR_WORKSPACE; }
+  if (int r = check_device(device)) return r;
+  FbankConst* fc = nullptr;
+  if (int r = fbank_consts(device, sr, n_fft, win_length, n_mels, f_min, f_max, &fc)) return r;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nf = 1 + L / hop;
+  const int64_t rows = (int64_t)B * nf;
+  Carver cv(workspace);
+  float* frames = (float*)cv.take((size_t)rows * n_fft * 4);
+  float* reim = (float*)cv.take((size_t)rows * 2 * fc->nbp * 4);
+  float* power = (float*)cv.take((size_t)rows * fc->nbp * 4);
+  if (int r = launch_fbank_frames(wav, B, L, n_fft, hop, nf, fc->window.as<float>(), frames, s)) return r;
+  GemmArgs g;
+  g.A = frames; g.W = fc->basis.p; g.C = reim;
+  g.M = (int)rows; g.N = 2 * fc->nbp; g.K = n_fft; g.a_rpb = (int)rows; g.a_rstride = n_fft; g.ldw = n_fft; g.ldc = 2 * fc->nbp; g.out_f32 = 1;
+  if (int r = launch_gemm(0, g, s)) return r;
+  if (int r = launch_power_spectrum(reim, rows, fc->nb, fc->nbp, 2 * fc->nbp, power, fc->nbp, s)) return r;
+  GemmArgs m;
+  m.A = power; m.W = fc->mel.p; m.C = out;
+  m.M = (int)rows; m.N = n_mels; m.K = fc->nbp; m.a_rpb = (int)rows; m.a_rstride = fc->nbp; m.ldw = fc->nbp; m.ldc = n_mels; m.out_f32 = 1;
+  if (int r = launch_gemm(0, m, s)) return r;
+  return launch_fbank_db(out, B, nf * n_mels, top_db, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Shared declarations for the MI355X (gfx950) singing-transcription kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace svt {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SVT_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return svt::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define SVT_LAUNCH_CHECK() SVT_HIP(hipGetLastError())
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+// C[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[n]) + resid[z][m][n]
+// A rows may overlap (implicit-GEMM view of a strided 1-D convolution over a channels-last tensor):
+//   row m of batch z starts at A + z-offset + (m / a_rpb) * a_bstride + (m % a_rpb) * a_rstride.
+struct GemmArgs {
+  const void* A = nullptr;
+  const void* W = nullptr;
+  void* C = nullptr;
+  const float* bias = nullptr;
+  const float* resid = nullptr;  // fp32, same indexing as C
+  int M = 0, N = 0, K = 0;
+  int a_rpb = 1;
+  long a_bstride = 0, a_rstride = 0;
+  long ldw = 0, ldc = 0;
+  int nz = 1, nz2 = 1;  // batch z = z1 * nz2 + z2
+  long a_z1 = 0, a_z2 = 0, w_z1 = 0, w_z2 = 0, c_z1 = 0, c_z2 = 0, bias_z2 = 0;
+  float alpha = 1.f;
+  int act = ACT_NONE;
+  int out_f32 = 0;  // C is fp32 regardless of the operand type
+  int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
+};
+
+// operand type: 0 = fp32 (v_mfma_f32_16x16x4_f32, exact fp32 fma chain), 1 = bf16 (v_mfma_f32_16x16x32_bf16)
+int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
+
+// ---- profiling of the dominant kernel (bench.py roofline leg) ----
+void prof_begin(hipStream_t s);
+void prof_end(hipStream_t s, double flops, double bytes);
+
+// ---- elementwise / reduction kernels (kernels.hip) ----
+int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// moments[0] += sum(x), moments[1] += sum(x^2) over n fp32 values (fp64 accumulation); caller zeroes moments
+int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s);
+// y = (x - mean) * rsqrt(var + eps) from global moments over n elements (no affine)
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s);
+
+// row LayerNorm over D: in fp32 or operand type; outputs: yT (operand type, may be null) and yF (fp32, may be null)
+int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
+                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s);
+
+// conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
+int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,
+                                double* wm /*B x 65*/, hipStream_t s);
+int launch_conv0_group_coef(const double* wav_moments /*2, or null*/, int64_t n_wav, const double* wm, int B,
+                            int64_t T1, int C, int k, const float* w0 /*C x k*/, const float* b0 /*C or null*/,
+                            const float* gamma, const float* beta, float eps_wav, float eps_gn,
+                            float* coef /*B x C x (k+1)*/, hipStream_t s);
+int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
+                             const float* coef, void* out /*B x T1 x C*/, hipStream_t s);
+// conv layer 0 in "layer" mode: conv + bias + LayerNorm over channels + GELU
+int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
+                       const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s);
+
+// positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front
+int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, void* out, hipStream_t s);
+
+// attention helpers for the materialised-score path
+int launch_softmax_rows(int prec, const float* S, int64_t rows, int T, int Tp, void* P, hipStream_t s);
+// V slice of the packed qkv (B*T, ld) at column offset voff -> Vt (B, H, dh, Tp) operand type, zero padded
+int launch_transpose_v(int prec, const void* qkv, int B, int T, int H, int dh, long ld, long voff, int Tp,
+                       void* Vt, hipStream_t s);
+
+// out = a*x + b*y (fp32 or operand type)
+int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s);
+// RCA: s = x + pe[t] (x f32 (B,T,D); x2 may be shorter in T: rows >= T2 read as zero) -> fp32 + operand type
+int launch_add_pe(int prec, const float* x, int B, int T, int Tsrc, int D, const float* pe, float* outF, void* outT,
+                  hipStream_t s);
+int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
+
+// frame head (fp32 GEMV, N small) and per-frame decode
+int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
+                      hipStream_t s);
+struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };
+int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
+                         hipStream_t s);
+int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,
+                      int32_t* out_lens, hipStream_t s);
+
+// Fbank pieces
+int launch_fbank_frames(const float* wav, int B, int64_t L, int n_fft, int hop, int64_t nframes, const float* window,
+                        float* frames /*B*nframes x n_fft*/, hipStream_t s);
+int launch_power_spectrum(const float* reim /*rows x ld: re at [0,nb), im at [imoff, imoff+nb)*/, int64_t rows, int nb,
+                          int imoff, int ld, float* power /*rows x ldp*/, int ldp, hipStream_t s);
+int launch_fbank_db(float* fb, int B, int64_t per_seq, float top_db, hipStream_t s);
+
+}  // namespace svt

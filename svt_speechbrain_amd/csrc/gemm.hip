@@ -1,0 +1,287 @@
+// Dense contraction kernel for gfx950: C = act(alpha * A W^T + bias) + resid, A (M,K) and W (N,K)
+// both K-contiguous.  It carries every dense product of the encoder:
+// conv layers 1-6 as implicit GEMM over the channels-last activation (overlapping A rows), feature
+// projection, the grouped positional conv (batched over (clip, group)), q/k/v/out projections, FFN,
+// and (materialised-score attention path) QK^T and PV.
+//
+// Structure (wave64, 256 threads = 4 waves, one 64x64 output sub-tile per wave):
+//   * K is consumed in 128-byte slabs per row (64 bf16 / 32 fp32).  Global -> register -> LDS staging:
+//     one wave instruction loads 8 rows x 128 B (full lines), and writes 16-byte pieces into LDS in
+//     *fragment order*, so that every MFMA operand read is one ds_read_b128 of 64 lanes x 16 B
+//     contiguous (conflict-free by construction, no swizzle needed).
+//   * LDS is double buffered; the next slab's global loads are issued before the MFMAs of the current
+//     slab and written after them (one barrier per slab).
+//   * The MFMA computes the transposed tile (A-operand = W rows, B-operand = activation rows), and the
+//     W rows of each 64-row group are permuted at staging time so that a lane ends up holding 16
+//     CONSECUTIVE output columns of one output row: the epilogue is bias/act/residual on registers
+//     and 16-byte stores, no LDS round trip.
+//   * fp32 operands use v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chain) with the same staging and
+//     fragment layout: a fragment is 8 k-consecutive elements per lane for both types.
+#include "common.h"
+
+namespace svt {
+namespace {
+
+template <typename T> struct OpTraits;
+template <> struct OpTraits<float> {
+  static constexpr int EPP = 4;   // elements per 16-byte piece
+  static constexpr int BK = 32;   // elements per 128-byte slab row
+};
+template <> struct OpTraits<bf16_t> {
+  static constexpr int EPP = 8;
+  static constexpr int BK = 64;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_GELU) return gelu_erf(v);
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  constexpr int EPP = OpTraits<T>::EPP;
+  constexpr int BK = OpTraits<T>::BK;
+  constexpr int KS = BK / 32;         // 32-element MFMA k-steps per slab (2 bf16, 1 fp32)
+  constexpr int PPC = 8 / EPP;        // 16-byte pieces per 8-element fragment (1 bf16, 2 fp32)
+  constexpr int WAVES_N = BN / 64;
+  constexpr int XP = BM / 32;         // 16-byte pieces of the activation slab per thread
+  constexpr int WP = BN / 32;
+  constexpr int X_PIECES = BM * 8;    // pieces per activation slab
+  constexpr int STAGE_PIECES = (BM + BN) * 8;
+
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // 2 stages x STAGE_PIECES
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  // block -> tile.  blockIdx.x walks M fastest so that consecutive blocks share the same W panel (L2).
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile_m = blockIdx.x % tiles_m;
+  const int tile_n = blockIdx.x / tiles_m;
+  const int z = blockIdx.y;
+  const int z1 = z / p.nz2, z2 = z % p.nz2;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const T* A = (const T*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
+  const T* W = (const T*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
+
+  // per-thread source rows (clamped: out-of-range rows are computed on valid memory and never stored)
+  const int prow = lane & 7;   // row inside an 8-row group
+  const int pc = lane >> 3;    // 16-byte piece inside the 128-byte slab row
+  const T* xsrc[XP];
+  int xdst[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    int r = (i * 4 + wave) * 8 + prow;  // row in tile
+    int m = m0 + r;
+    if (m > p.M - 1) m = p.M - 1;
+    long off = (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride;
+    xsrc[i] = A + off + pc * EPP;
+    const int e0 = pc * EPP;
+    const int ks = e0 / 32, cq = (e0 % 32) / 8, h = (e0 % 8) / EPP;
+    xdst[i] = (((r >> 4) * KS + ks) * PPC + h) * 64 + cq * 16 + (r & 15);
+  }
+  const T* wsrc[WP];
+  int wdst[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    int r = (i * 4 + wave) * 8 + prow;
+    int n = n0 + r;
+    if (n > p.N - 1) n = p.N - 1;
+    wsrc[i] = W + (long)n * p.ldw + pc * EPP;
+    const int e0 = pc * EPP;
+    const int ks = e0 / 32, cq = (e0 % 32) / 8, h = (e0 % 8) / EPP;
+    // row permutation inside each 64-row group: tile row (q*16 + nb*4 + rr) -> MFMA block nb, row 4q+rr
+    const int g = r >> 6, q = (r & 63) >> 4, nb = (r & 15) >> 2, rr = r & 3;
+    wdst[i] = X_PIECES + ((((g * 4 + nb) * KS + ks) * PPC + h) * 64 + cq * 16 + (4 * q + rr));
+  }
+
+  f32x4 acc[4][4];  // [nb][mb]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  uint4 xr[XP], wr[WP];
+
+  auto stage_load = [&](int kt) {
+    const int kbase = kt * BK;
+    const bool ok = (kbase + pc * EPP) < p.K;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      xr[i] = ok ? *(const uint4*)(xsrc[i] + kbase) : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      wr[i] = ok ? *(const uint4*)(wsrc[i] + kbase) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto stage_write = [&](int buf) {
+    uint4* base = lds + buf * STAGE_PIECES;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) base[xdst[i]] = xr[i];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) base[wdst[i]] = wr[i];
+  };
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage_load(kt + 1);
+    const uint4* xb = lds + buf * STAGE_PIECES;
+    const uint4* wb = xb + X_PIECES;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 xf[4][PPC], wf[4][PPC];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int h = 0; h < PPC; ++h) {
+          xf[b][h] = xb[(((wm * 4 + b) * KS + ks) * PPC + h) * 64 + lane];
+          wf[b][h] = wb[(((wn * 4 + b) * KS + ks) * PPC + h) * 64 + lane];
+        }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          if constexpr (sizeof(T) == 2) {
+            acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, wf[nb][0]), __builtin_bit_cast(bf16x8, xf[mb][0]), acc[nb][mb], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 wv = __builtin_bit_cast(f32x4, wf[nb][h]);
+              const f32x4 xv = __builtin_bit_cast(f32x4, xf[mb][h]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[nb][mb], 0, 0, 0);
+            }
+          }
+        }
+    }
+    if (kt + 1 < nk) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][nbase .. nbase+15] for each of its 4 row blocks ----
+  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
+  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
+  const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
+  if (nbase >= p.N) return;
+  const bool full = (nbase + 16 <= p.N) && p.c_vec;
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+  if (bias) {
+    if (full) {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const float4 b4 = *(const float4*)(bias + nbase + j4 * 4);
+        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) if (nbase + j < p.N) bv[j] = bias[nbase + j];
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wm * 64 + mb * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nb * 4 + r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
+    const long idx = coff + (long)m * p.ldc + nbase;
+    if (full) {
+      if (p.resid) {
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 r4 = *(const float4*)(p.resid + idx + j4 * 4);
+          v[j4 * 4 + 0] += r4.x; v[j4 * 4 + 1] += r4.y; v[j4 * 4 + 2] += r4.z; v[j4 * 4 + 3] += r4.w;
+        }
+      }
+      if (p.out_f32 || sizeof(T) == 4) {
+        float* c = (float*)p.C + idx;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+          *(float4*)(c + j4 * 4) = float4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
+      } else {
+        bf16_t* c = (bf16_t*)p.C + idx;
+#pragma unroll
+        for (int j8 = 0; j8 < 2; ++j8) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j8 * 8 + j];
+          *(bf16x8*)(c + j8 * 8) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (nbase + j >= p.N) continue;
+        float o = v[j];
+        if (p.resid) o += p.resid[idx + j];
+        if (p.out_f32 || sizeof(T) == 4) ((float*)p.C)[idx + j] = o;
+        else ((bf16_t*)p.C)[idx + j] = (bf16_t)o;
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN>
+int launch_one(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, a.nz, 1);
+  const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+    attr_set = true;
+  }
+  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.nz +
+                       (double)a.M * a.N * a.nz * ((a.out_f32 || sizeof(T) == 4) ? 4 : 2);
+  prof_begin(s);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN>), grid, dim3(256), lds_bytes, s, a);
+  prof_end(s, flops, bytes);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
+  const int epp = prec ? 8 : 4;
+  if (a.K % epp != 0) { set_error("gemm: K must be a multiple of the 16-byte piece"); return -1; }
+  auto mult = [](long v, long m) { return v % m == 0; };
+  if (!mult(a.a_rstride, epp) || !mult(a.a_bstride, epp) || !mult(a.a_z1, epp) || !mult(a.a_z2, epp) || !mult(a.ldw, epp) ||
+      !mult(a.w_z1, epp) || !mult(a.w_z2, epp) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) {
+    set_error("gemm: operand rows must be 16-byte aligned");
+    return -1;
+  }
+  GemmArgs g = a;
+  const int cel = (a.out_f32 || !prec) ? 4 : 8;  // elements per 16 bytes of C
+  g.c_vec = mult(a.ldc, cel) && mult(a.c_z1, cel) && mult(a.c_z2, cel) && !((uintptr_t)a.C & 15) &&
+            mult(a.ldc, 4) && mult(a.c_z1, 4) && mult(a.c_z2, 4) && !((uintptr_t)a.resid & 15) &&
+            mult(a.bias_z2, 4) && !((uintptr_t)a.bias & 15);
+  const bool narrow = a.N <= 64;
+  if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
+  return narrow ? launch_one<float, 256, 64>(g, s) : launch_one<float, 128, 128>(g, s);
+}
+
+}  // namespace svt

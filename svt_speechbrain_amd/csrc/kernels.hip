@@ -1,0 +1,748 @@
+// HBM-bound kernels of the path: statistics, norms, conv layer 0, operand re-layouts, softmax,
+// frame head and decode.  All are wave64 designs: one wavefront per row where a row reduction is
+// needed (shuffle reductions, no LDS), 16-byte accesses where the layout allows.
+#include "common.h"
+
+namespace svt {
+namespace {
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename V>
+__device__ __forceinline__ V wave_sum(V v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ float ld(const T* p, long i);
+template <> __device__ __forceinline__ float ld<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p, long i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void st(T* p, long i, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, long i, float v) { p[i] = (bf16_t)v; }
+
+// ------------------------------------------------------------------------------------------------
+__global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = (bf16_t)in[i];
+}
+
+// sum / sum of squares in fp64 (two whole-batch layer norms of the wrapper)
+__global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n, double* mom) {
+  __shared__ double sh[2][4];
+  double s = 0.0, ss = 0.0;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = (const float4*)x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const float4 v = x4[i];
+    // fp32 partial of 4 terms, then fp64: keeps the stream cheap and the long sum exact enough
+    const float a = (v.x + v.y) + (v.z + v.w);
+    const float b = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    s += (double)a;
+    ss += (double)b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int64_t j = n4 << 2; j < n; ++j) { s += (double)x[j]; ss += (double)x[j] * (double)x[j]; }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&mom[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomicAdd(&mom[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  }
+}
+
+__global__ void global_norm_kernel(const float* x, float* y, int64_t n, const double* mom, float eps) {
+  const double mean = mom[0] / (double)n;
+  const double var = mom[1] / (double)n - mean * mean;
+  const float mu = (float)mean;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  const int64_t n4 = n >> 2;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    float4 v = ((const float4*)x)[i];
+    v.x = (v.x - mu) * rs; v.y = (v.y - mu) * rs; v.z = (v.z - mu) * rs; v.w = (v.w - mu) * rs;
+    ((float4*)y)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t j = n4 << 2; j < n; ++j) y[j] = (x[j] - mu) * rs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row LayerNorm: one wave per row, two-pass statistics from registers-free re-reads (rows <= 4 KB
+// stay in L1/L2).  Optional exact-erf GELU (conv "layer" mode).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int64_t rows, int D, const float* gamma,
+                                                        const float* beta, float eps, int gelu, TO* yT, float* yF) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TI* xr = x + row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += ld<TI>(xr, i);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = ld<TI>(xr, i) - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  for (int i = lane; i < D; i += 64) {
+    float v = (ld<TI>(xr, i) - mean) * rstd * gamma[i] + beta[i];
+    if (gelu) v = gelu_erf(v);
+    if (yT) st<TO>(yT, row * D + i, v);
+    if (yF) yF[row * D + i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv layer 0, "group" mode.  GroupNorm(C groups) needs per-(clip,channel) mean/var over ALL frames
+// before the GELU.  Because Cin = 1, y[c,t] = w_c . window_t, so the statistics of all C channels
+// follow exactly from the first and second moments of the 10-sample windows:
+//   mean_c = w_c . E[win] ,  E[y_c^2] = w_c^T E[win win^T] w_c
+// (65 fp64 sums per clip) — one cheap pass over the waveform instead of a second pass over the
+// (B, T1, 512) activation.
+constexpr int K0 = 10;
+constexpr int NWM = K0 + K0 * (K0 + 1) / 2;  // 65
+
+__global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* wav, int64_t L, int stride, int64_t T1,
+                                                                   double* wm) {
+  __shared__ double sh[4][NWM];
+  const int b = blockIdx.y;
+  const float* x = wav + (int64_t)b * L;
+  double acc[NWM];
+#pragma unroll
+  for (int i = 0; i < NWM; ++i) acc[i] = 0.0;
+  constexpr int WPT = 8;  // windows per thread
+  const int64_t t0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * WPT;
+  for (int w = 0; w < WPT; ++w) {
+    const int64_t t = t0 + w;
+    if (t >= T1) break;
+    float v[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) v[j] = x[t * stride + j];
+    int idx = K0;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+      acc[j] += (double)v[j];
+#pragma unroll
+      for (int j2 = j; j2 < K0; ++j2) acc[idx++] += (double)(v[j] * v[j2]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NWM; ++i) {
+    const double r = wave_sum(acc[i]);
+    if (lane == 0) sh[wave][i] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NWM)
+    atomicAdd(&wm[b * NWM + threadIdx.x],
+              sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ void conv0_group_coef_kernel(const double* wav_mom, int64_t n_wav, const double* wm, int64_t T1, int C,
+                                        const float* w0, const float* b0, const float* gamma, const float* beta,
+                                        float eps_wav, float eps_gn, float* coef) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mu = 0.0, r = 1.0;
+  if (wav_mom) {
+    mu = wav_mom[0] / (double)n_wav;
+    const double var = wav_mom[1] / (double)n_wav - mu * mu;
+    r = 1.0 / sqrt(var + (double)eps_wav);
+  }
+  const double* m = wm + b * NWM;
+  const double invT = 1.0 / (double)T1;
+  double w[K0], mn[K0];
+  double wsum = 0.0;
+  for (int j = 0; j < K0; ++j) { w[j] = (double)w0[c * K0 + j]; wsum += w[j]; mn[j] = r * (m[j] * invT - mu); }
+  const double bias = b0 ? (double)b0[c] : 0.0;
+  double dot = 0.0;
+  for (int j = 0; j < K0; ++j) dot += w[j] * mn[j];
+  double quad = 0.0;
+  int idx = K0;
+  for (int j = 0; j < K0; ++j)
+    for (int j2 = j; j2 < K0; ++j2) {
+      const double R = r * r * (m[idx] * invT - mu * m[j] * invT - mu * m[j2] * invT + mu * mu);
+      quad += (j == j2 ? 1.0 : 2.0) * w[j] * w[j2] * R;
+      ++idx;
+    }
+  const double mean = dot + bias;
+  const double e2 = quad + 2.0 * bias * dot + bias * bias;
+  double var = e2 - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double a = (double)gamma[c] / sqrt(var + (double)eps_gn);
+  const double shift = (double)beta[c] - mean * a;
+  float* o = coef + ((int64_t)b * C + c) * (K0 + 1);
+  for (int j = 0; j < K0; ++j) o[j] = (float)(a * r * w[j]);
+  o[K0] = (float)(a * (bias - r * mu * wsum) + shift);
+}
+
+// out[b,t,c] = gelu( sum_j coef[b,c,j] * wav[b, t*stride + j] + coef[b,c,K0] ), channels-last.
+// One wave writes whole (b,t) rows: lane = 8 consecutive channels -> 16 B (bf16) / 32 B (fp32) per lane.
+template <typename TO>
+__global__ __launch_bounds__(256) void conv0_group_apply_kernel(const float* wav, int64_t L, int stride, int64_t T1,
+                                                                int C, const float* coef, TO* out) {
+  constexpr int FPW = 32;  // frames per wave
+  __shared__ float xs[4][FPW * 5 + 16];  // stride <= 5 supported by this tile size
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * FPW;
+  if (t0 >= T1) return;
+  const float* x = wav + (int64_t)b * L;
+  const int nfr = (int)((T1 - t0 < FPW) ? (T1 - t0) : FPW);
+  const int ns = (nfr - 1) * stride + K0;
+  for (int i = lane; i < ns; i += 64) xs[wave][i] = x[t0 * stride + i];
+  // (wave-private LDS region: no block barrier needed, but the wave must see its own writes)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const int c0 = lane * 8;
+  if (c0 >= C) return;
+  float cf[8][K0 + 1];
+  const float* cp = coef + ((int64_t)b * C + c0) * (K0 + 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j <= K0; ++j) cf[i][j] = cp[i * (K0 + 1) + j];
+  for (int f = 0; f < nfr; ++f) {
+    float xv[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) xv[j] = xs[wave][f * stride + j];
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = cf[i][K0];
+#pragma unroll
+      for (int j = 0; j < K0; ++j) a = fmaf(cf[i][j], xv[j], a);
+      o[i] = gelu_erf(a);
+    }
+    TO* dst = out + ((int64_t)b * T1 + t0 + f) * C + c0;
+    if constexpr (sizeof(TO) == 2) {
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+      *(bf16x8*)dst = v;
+    } else {
+      *(float4*)dst = float4{o[0], o[1], o[2], o[3]};
+      *(float4*)(dst + 4) = float4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// conv layer 0, "layer" mode: conv (+bias) -> LayerNorm over C -> GELU, one wave per frame.
+template <typename TO>
+__global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int64_t L, int stride, int64_t T1, int C,
+                                                          const double* wav_mom, int64_t n_wav, float eps_wav,
+                                                          const float* w0, const float* b0, const float* gamma,
+                                                          const float* beta, float eps, TO* out) {
+  constexpr int FPW = 16;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * FPW;
+  if (t0 >= T1) return;
+  float mu = 0.f, r = 1.f;
+  if (wav_mom) {
+    const double m = wav_mom[0] / (double)n_wav;
+    const double var = wav_mom[1] / (double)n_wav - m * m;
+    mu = (float)m;
+    r = (float)(1.0 / sqrt(var + (double)eps_wav));
+  }
+  const float* x = wav + (int64_t)b * L;
+  const int c0 = lane * 8;
+  const bool active = c0 < C;
+  float w[8][K0], bb[8], g[8], be[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = active ? c0 + i : 0;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) w[i][j] = w0[c * K0 + j];
+    bb[i] = b0 ? b0[c] : 0.f;
+    g[i] = gamma[c];
+    be[i] = beta[c];
+  }
+  const int nfr = (int)((T1 - t0 < FPW) ? (T1 - t0) : FPW);
+  for (int f = 0; f < nfr; ++f) {
+    float xv[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) xv[j] = (x[(t0 + f) * stride + j] - mu) * r;
+    float y[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = bb[i];
+#pragma unroll
+      for (int j = 0; j < K0; ++j) a = fmaf(w[i][j], xv[j], a);
+      y[i] = a;
+      if (active) s += a;
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = y[i] - mean; if (active) q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (!active) continue;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = gelu_erf((y[i] - mean) * rstd * g[i] + be[i]);
+    TO* dst = out + ((int64_t)b * T1 + t0 + f) * C + c0;
+    if constexpr (sizeof(TO) == 2) {
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+      *(bf16x8*)dst = v;
+    } else {
+      *(float4*)dst = float4{o[0], o[1], o[2], o[3]};
+      *(float4*)(dst + 4) = float4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G, int kp, TO* out) {
+  const int cg = D / G;
+  const int Tp = T + kp;
+  const int64_t n = (int64_t)B * G * Tp * cg;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int ci = (int)(i % cg);
+    int64_t r = i / cg;
+    const int tp = (int)(r % Tp); r /= Tp;
+    const int g = (int)(r % G);
+    const int b = (int)(r / G);
+    const int t = tp - kp / 2;
+    const float v = (t >= 0 && t < T) ? h[((int64_t)b * T + t) * D + g * cg + ci] : 0.f;
+    st<TO>(out, i, v);
+  }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int64_t rows, int T, int Tp, TO* P) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = S + row * Tp;
+  float mx = -INFINITY;
+  for (int i = lane; i < T; i += 64) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int i = lane; i < T; i += 64) sum += expf(s[i] - mx);
+  const float inv = 1.f / wave_sum(sum);
+  for (int i = lane; i < Tp; i += 64) st<TO>(P, row * Tp + i, i < T ? expf(s[i] - mx) * inv : 0.f);
+}
+
+// (B*T, ld)[.., voff + h*dh + d] -> Vt (B, H, dh, Tp); 32x32 LDS tile transpose, zero padded keys
+template <typename TV>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const TV* qkv, int T, int H, int dh, long ldq, long voff,
+                                                          int Tp, TV* Vt) {
+  __shared__ float tile[32][33];
+  const int bh = blockIdx.z;
+  const int b = bh / H, h = bh % H;
+  const int t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, d = d0 + tx;
+    tile[i][tx] = (t < T && d < dh) ? ld<TV>(qkv, ((long)b * T + t) * ldq + voff + (long)h * dh + d) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int d = d0 + i, t = t0 + tx;
+    if (d < dh && t < Tp) st<TV>(Vt, (((long)b * H + h) * dh + d) * Tp + t, tile[tx][i]);
+  }
+}
+
+template <typename TX>
+__global__ void axpby_kernel(const TX* x, const TX* y, float a, float b, TX* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) st<TX>(out, i, a * ld<TX>(x, i) + b * ld<TX>(y, i));
+}
+
+template <typename TO>
+__global__ void add_pe_kernel(const float* x, int B, int T, int Tsrc, int D, const float* pe, float* outF, TO* outT) {
+  const int64_t n = (int64_t)B * T * D;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const float xv = t < Tsrc ? x[((int64_t)b * Tsrc + t) * D + d] : 0.f;
+    const float v = xv + pe[(int64_t)t * D + d];
+    outF[i] = v;
+    if (outT) st<TO>(outT, i, v);
+  }
+}
+
+__global__ void add_f32_kernel(const float* a, const float* b, float* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame head: y[row, n] = x[row,:] . w[n,:] + b[n], N <= 32, fp32 throughout.  One wave per row; the
+// row of x is read once, the N partial sums live in registers, shuffle-reduced at the end.
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* x, int64_t rows, int K, const float* w,
+                                                           const float* b, int N, float* y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * K;
+  float acc[32];
+#pragma unroll
+  for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float xv = xr[k];
+#pragma unroll
+    for (int n = 0; n < 32; ++n)
+      if (n < N) acc[n] = fmaf(xv, w[(long)n * K + k], acc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < 32; ++n) {
+    if (n < N) {
+      const float r = wave_sum(acc[n]);
+      if (lane == 0) y[row * N + n] = r + (b ? b[n] : 0.f);
+    }
+  }
+}
+
+__global__ void decode_frames_kernel(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls,
+                                     FrameOut* out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* l = logits + r * n_out;
+  FrameOut f;
+  f.p_on = 1.f / (1.f + expf(-l[0]));
+  f.p_off = 1.f / (1.f + expf(-l[1]));
+  int bo = 0;
+  float bv = l[2];
+  for (int i = 1; i <= n_oct; ++i)
+    if (l[2 + i] > bv) { bv = l[2 + i]; bo = i; }
+  int bc = 0;
+  const float* c = l + 2 + n_oct + 1;
+  bv = c[0];
+  for (int i = 1; i <= n_cls; ++i)
+    if (c[i] > bv) { bv = c[i]; bc = i; }
+  f.octave = bo;
+  f.pitch_class = bc;
+  out[r] = f;
+}
+
+// CTC greedy: one block per sequence.  argmax per frame, then order-preserving compaction of
+// "first of a run, not blank, inside the relative length".
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* probs, int T, int V, const float* rel_lens,
+                                                         int blank, int32_t* tokens, int32_t* out_lens) {
+  extern __shared__ int32_t ids[];  // T
+  __shared__ int wave_tot[4];
+  __shared__ int running;
+  const int b = blockIdx.x;
+  const float* p = probs + (int64_t)b * T * V;
+  int n = (int)rintf(rel_lens[b] * (float)T);
+  if (n > T) n = T;
+  if (n < 0) n = 0;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const float* q = p + (int64_t)t * V;
+    int best = 0;
+    float bv = q[0];
+    for (int v = 1; v < V; ++v)
+      if (q[v] > bv) { bv = q[v]; best = v; }
+    ids[t] = best;
+  }
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int t = base + threadIdx.x;
+    bool keep = false;
+    int id = 0;
+    if (t < n) {
+      id = ids[t];
+      keep = (t == 0 || id != ids[t - 1]) && id != blank;
+    }
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (keep) tokens[(int64_t)b * T + off + before] = id;
+    __syncthreads();
+    if (threadIdx.x == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_lens[b] = running;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fbank pieces: framing (centred, zero padded) * window; power spectrum; dB + per-sequence top_db clip
+__global__ void fbank_frames_kernel(const float* wav, int64_t L, int n_fft, int hop, int64_t nframes,
+                                    const float* window, float* frames, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int k = (int)(i % n_fft);
+    const int64_t r = i / n_fft;
+    const int64_t f = r % nframes;
+    const int64_t b = r / nframes;
+    const int64_t pos = f * hop + k - n_fft / 2;
+    const float v = (pos >= 0 && pos < L) ? wav[b * L + pos] : 0.f;
+    frames[i] = v * window[k];
+  }
+}
+
+__global__ void power_spectrum_kernel(const float* reim, int64_t rows, int nb, int imoff, int ld, float* power, int ldp) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = rows * ldp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int k = (int)(i % ldp);
+    const int64_t r = i / ldp;
+    float v = 0.f;
+    if (k < nb) {
+      const float re = reim[r * ld + k], im = reim[r * ld + imoff + k];
+      v = re * re + im * im;
+    }
+    power[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void fbank_db_kernel(float* fb, int64_t per_seq, float top_db) {
+  __shared__ float sh[4];
+  float* x = fb + (int64_t)blockIdx.x * per_seq;
+  float mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < per_seq; i += blockDim.x) {
+    const float v = 10.f * log10f(fmaxf(x[i], 1e-10f));
+    x[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  const float floor_db = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) - top_db;
+  for (int64_t i = threadIdx.x; i < per_seq; i += blockDim.x) x[i] = fmaxf(x[i], floor_db);
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+  int64_t g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+// ================================================================================================
+int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s) {
+  hipLaunchKernelGGL(moments_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, x, n, moments);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(global_norm_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, y, n, moments, eps);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
+                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (!prec) {
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, rows, D, gamma, beta, eps,
+                       gelu, (float*)yT, yF);
+  } else if (x_is_f32) {
+    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, rows, D, gamma, beta,
+                       eps, gelu, (bf16_t*)yT, yF);
+  } else {
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, rows, D, gamma, beta,
+                       eps, gelu, (bf16_t*)yT, yF);
+  }
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1, double* wm,
+                                hipStream_t s) {
+  if (k != K0) { set_error("conv layer 0 kernel size must be 10"); return -1; }
+  const int per_block = 256 * 8;
+  dim3 grid((unsigned)((T1 + per_block - 1) / per_block), B);
+  hipLaunchKernelGGL(conv0_window_moments_kernel, grid, dim3(256), 0, s, wav, L, stride, T1, wm);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv0_group_coef(const double* wav_moments, int64_t n_wav, const double* wm, int B, int64_t T1, int C,
+                            int k, const float* w0, const float* b0, const float* gamma, const float* beta,
+                            float eps_wav, float eps_gn, float* coef, hipStream_t s) {
+  if (k != K0) { set_error("conv layer 0 kernel size must be 10"); return -1; }
+  dim3 grid((C + 63) / 64, B);
+  hipLaunchKernelGGL(conv0_group_coef_kernel, grid, dim3(64), 0, s, wav_moments, n_wav, wm, T1, C, w0, b0, gamma, beta,
+                     eps_wav, eps_gn, coef);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
+                             const float* coef, void* out, hipStream_t s) {
+  if (k != K0 || stride > 5 || C > 512 || C % 8) { set_error("conv0: unsupported geometry"); return -1; }
+  dim3 grid((unsigned)((T1 + 127) / 128), B);
+  if (prec)
+    hipLaunchKernelGGL((conv0_group_apply_kernel<bf16_t>), grid, dim3(256), 0, s, wav, L, stride, T1, C, coef,
+                       (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((conv0_group_apply_kernel<float>), grid, dim3(256), 0, s, wav, L, stride, T1, C, coef,
+                       (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
+                       const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s) {
+  if (k != K0 || C > 512 || C % 8) { set_error("conv0: unsupported geometry"); return -1; }
+  dim3 grid((unsigned)((T1 + 63) / 64), B);
+  if (prec)
+    hipLaunchKernelGGL((conv0_layer_kernel<bf16_t>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav,
+                       eps_wav, w0, b0, gamma, beta, eps, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((conv0_layer_kernel<float>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav,
+                       eps_wav, w0, b0, gamma, beta, eps, (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, void* out, hipStream_t s) {
+  const int64_t n = (int64_t)B * (T + kp) * D;
+  if (prec)
+    hipLaunchKernelGGL((posconv_gather_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp,
+                       (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((posconv_gather_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp,
+                       (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_softmax_rows(int prec, const float* S, int64_t rows, int T, int Tp, void* P, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (prec)
+    hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), grid, dim3(256), 0, s, S, rows, T, Tp, (bf16_t*)P);
+  else
+    hipLaunchKernelGGL((softmax_rows_kernel<float>), grid, dim3(256), 0, s, S, rows, T, Tp, (float*)P);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_transpose_v(int prec, const void* qkv, int B, int T, int H, int dh, long ld, long voff, int Tp, void* Vt,
+                       hipStream_t s) {
+  dim3 grid((Tp + 31) / 32, (dh + 31) / 32, B * H);
+  if (prec)
+    hipLaunchKernelGGL((transpose_v_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)qkv, T, H, dh, ld, voff, Tp,
+                       (bf16_t*)Vt);
+  else
+    hipLaunchKernelGGL((transpose_v_kernel<float>), grid, dim3(256), 0, s, (const float*)qkv, T, H, dh, ld, voff, Tp,
+                       (float*)Vt);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s) {
+  if (prec)
+    hipLaunchKernelGGL((axpby_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y,
+                       a, b, (bf16_t*)out, n);
+  else
+    hipLaunchKernelGGL((axpby_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (const float*)y, a,
+                       b, (float*)out, n);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_add_pe(int prec, const float* x, int B, int T, int Tsrc, int D, const float* pe, float* outF, void* outT,
+                  hipStream_t s) {
+  const int64_t n = (int64_t)B * T * D;
+  if (prec)
+    hipLaunchKernelGGL((add_pe_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, x, B, T, Tsrc, D, pe, outF,
+                       (bf16_t*)outT);
+  else
+    hipLaunchKernelGGL((add_pe_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, x, B, T, Tsrc, D, pe, outF,
+                       (float*)nullptr);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
+                      hipStream_t s) {
+  if (N > 32) { set_error("linear_small: N > 32"); return -1; }
+  hipLaunchKernelGGL(linear_small_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, K, w, b, N, y);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(decode_frames_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, logits, rows, n_out,
+                     n_oct, n_cls, out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,
+                      int32_t* out_lens, hipStream_t s) {
+  const size_t lds = (size_t)T * sizeof(int32_t);
+  if (lds > 60000) { set_error("ctc_greedy: T too large for one block"); return -1; }
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), lds, s, probs, T, V, rel_lens, blank, tokens, out_lens);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fbank_frames(const float* wav, int B, int64_t L, int n_fft, int hop, int64_t nframes, const float* window,
+                        float* frames, hipStream_t s) {
+  const int64_t total = (int64_t)B * nframes * n_fft;
+  hipLaunchKernelGGL(fbank_frames_kernel, dim3(grid_for(total)), dim3(256), 0, s, wav, L, n_fft, hop, nframes, window,
+                     frames, total);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_power_spectrum(const float* reim, int64_t rows, int nb, int imoff, int ld, float* power, int ldp,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(power_spectrum_kernel, dim3(grid_for(rows * ldp)), dim3(256), 0, s, reim, rows, nb, imoff, ld,
+                     power, ldp);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fbank_db(float* fb, int B, int64_t per_seq, float top_db, hipStream_t s) {
+  hipLaunchKernelGGL(fbank_db_kernel, dim3(B), dim3(256), 0, s, fb, per_seq, top_db);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace svt

@@ -1,0 +1,101 @@
+"""Frame decode, note assembly and CTC greedy decode.
+
+* ``decode_frames`` — the reference's per-frame ``sigmoid`` / ``argmax`` loop
+  (``MIR_ST500/train_audio_ssl.py:93-100``) as one GPU kernel + one D2H copy instead of 4 syncs per frame.
+* ``frame2note`` — host-side greedy scan with the semantics of ``MIR_ST500/utils.py:82-149`` (float32
+  comparisons, +-3-frame local maximum with the window clipped to N-1, pitch = CPython
+  ``max(set(c), key=c.count)``).  It is sequential host logic in the reference and stays host logic here.
+* ``ctc_greedy_decode`` / ``filter_ctc_output`` — ``speechbrain/decoders/ctc.py:297-383``; argmax +
+  collapse + blank removal run in one kernel, the ragged lists are built on the host.
+"""
+from __future__ import annotations
+
+from itertools import groupby
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FRAME_DTYPE = np.dtype([("p_on", "<f4"), ("p_off", "<f4"), ("octave", "<i4"), ("pitch_class", "<i4")])
+
+
+def decode_frames(logits: torch.Tensor, pitch_octave_num: int = 4, pitch_class_num: int = 12) -> np.ndarray:
+    """logits (..., 2 + (oct+1) + (class+1)) on the GPU -> structured numpy array (...,) of
+    (p_on f32, p_off f32, octave i32, pitch_class i32).  argmax returns the first maximum."""
+    if not logits.is_cuda:
+        raise _lib.SvtError("decode_frames needs GPU logits; there is no CPU fallback")
+    lib = _lib.load()
+    n_out = logits.shape[-1]
+    lg = logits.detach().to(torch.float32).contiguous()
+    rows = lg.numel() // n_out
+    out = torch.empty((rows, 4), dtype=torch.int32, device=lg.device)  # 16 bytes per frame
+    if rows:
+        _lib.check(lib.svt_decode_frames(_lib.ptr(lg), rows, n_out, pitch_octave_num, pitch_class_num, _lib.ptr(out),
+                                         _lib.dev_index(lg.device), _lib.stream_ptr(lg.device)), "svt_decode_frames")
+    host = out.cpu().numpy().view(FRAME_DTYPE).reshape(lg.shape[:-1])
+    return host
+
+
+def frames_to_info(frames: np.ndarray) -> list:
+    """structured frames (N,) -> the list of (p_on, p_off, octave, pitch_class) tuples ``frame2note`` takes."""
+    return list(zip(frames["p_on"], frames["p_off"], frames["octave"].tolist(), frames["pitch_class"].tolist()))
+
+
+def frame2note(frame_info: Sequence, onset_thres: float, offset_thres: float, frame_size: float = 1 / 49.8) -> List[list]:
+    """[(p_on, p_off, octave, pitch_class), ...] -> [[onset_s, offset_s, midi_pitch], ...]."""
+    n = len(frame_info)
+    onset = np.asarray([np.float32(f[0]) for f in frame_info], dtype=np.float32)
+    notes: List[list] = []
+    t_on = None
+    bag: List[int] = []
+    now = 0.0
+    for i in range(n):
+        now = frame_size * i
+        p_on, p_off, octv, pc = frame_info[i]
+        p_on = np.float32(p_on)
+        window = onset[max(i - 3, 0):min(i + 4, n - 1)]
+        # np.amax of an empty window raises ValueError exactly like the reference does for a 1-frame song
+        if p_on >= onset_thres and onset[i] == np.amax(window):
+            if t_on is not None and bag:
+                notes.append([t_on, now, max(set(bag), key=bag.count) + 36])
+            t_on = now
+            bag = []
+        elif np.float32(p_off) >= offset_thres:
+            if t_on is not None:
+                if bag:
+                    notes.append([t_on, now, max(set(bag), key=bag.count) + 36])
+                t_on = None
+                bag = []
+        if t_on is not None and int(octv) != 4 and int(pc) != 12:
+            bag.append(int(int(octv) * 12 + int(pc)))
+    if t_on is not None and bag:
+        notes.append([t_on, now, max(set(bag), key=bag.count) + 36])
+    return notes
+
+
+def filter_ctc_output(string_pred, blank_id=-1):
+    if not isinstance(string_pred, list):
+        raise ValueError("filter_ctc_out can only filter python lists")
+    merged = [k for k, _ in groupby(string_pred)]
+    return [t for t in merged if t != blank_id]
+
+
+def ctc_greedy_decode(probabilities: torch.Tensor, seq_lens: torch.Tensor, blank_id: int = -1) -> List[List[int]]:
+    """probabilities (B, T, V) on the GPU, relative ``seq_lens`` (B,) -> ragged list of token ids."""
+    if not probabilities.is_cuda:
+        raise _lib.SvtError("ctc_greedy_decode needs GPU probabilities; there is no CPU fallback")
+    lib = _lib.load()
+    p = probabilities.detach().to(torch.float32).contiguous()
+    B, T, V = p.shape
+    lens = seq_lens.detach().to(device=p.device, dtype=torch.float32).contiguous()
+    if isinstance(blank_id, int) and blank_id < 0:
+        blank_id = V + blank_id
+    tokens = torch.empty((B, T), dtype=torch.int32, device=p.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=p.device)
+    _lib.check(lib.svt_ctc_greedy(_lib.ptr(p), B, T, V, _lib.ptr(lens), int(blank_id), _lib.ptr(tokens),
+                                  _lib.ptr(counts), _lib.dev_index(p.device), _lib.stream_ptr(p.device)), "svt_ctc_greedy")
+    tok = tokens.cpu().numpy()
+    cnt = counts.cpu().numpy()
+    return [tok[b, :cnt[b]].tolist() for b in range(B)]

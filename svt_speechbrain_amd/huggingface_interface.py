@@ -1,0 +1,289 @@
+"""Drop-in for ``MIR_ST500/huggingface_interface.py`` (``HuggingFaceWav2Vec2``, reference :47-297).
+
+Same constructor keywords, same attributes (``.model``, ``.normalize_wav``, ``.output_norm``,
+``.freeze``), same ``forward(wav: f32[B, L]) -> f32[B, T, D]`` and the same ``state_dict`` key layout
+(``model.<HF key>``), so a recipe yaml selects it by replacing
+``!new:huggingface_interface.HuggingFaceWav2Vec2`` with
+``!new:svt_speechbrain_amd.huggingface_interface.HuggingFaceWav2Vec2``.
+
+The arithmetic (HF ``Wav2Vec2Model`` / ``HubertModel`` forward + the wrapper's two whole-batch layer
+norms) runs in hand-written gfx950 kernels behind the C-ABI; torch is used only as tensor storage.
+The path is inference-only (forward target); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import logging
+import os
+import warnings
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .config import EncoderConfig, PRESETS, config_from_source
+from .weights import encoder_param_shapes, seeded_encoder_state_dict
+
+logger = logging.getLogger(__name__)
+
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+class ParamTree(nn.Module):
+    """A bare module hierarchy that reproduces a dotted state-dict key layout (no forward of its own)."""
+
+    def add(self, dotted: str, tensor: torch.Tensor) -> None:
+        head, _, rest = dotted.partition(".")
+        if not rest:
+            self.register_parameter(head, nn.Parameter(tensor, requires_grad=True))
+            return
+        if head not in self._modules:
+            self.add_module(head, ParamTree())
+        self._modules[head].add(rest, tensor)
+
+
+def _config_to_c(cfg: EncoderConfig, normalize_wav: bool, output_norm: bool, precision: str) -> _lib.EncoderConfigC:
+    c = _lib.EncoderConfigC()
+    c.struct_size = C.sizeof(_lib.EncoderConfigC)
+    c.hidden_size = cfg.hidden_size
+    c.num_layers = cfg.num_hidden_layers
+    c.num_heads = cfg.num_attention_heads
+    c.intermediate_size = cfg.intermediate_size
+    n = len(cfg.conv_dim)
+    if n > _lib.MAX_CONV:
+        raise ValueError("too many conv layers")
+    c.num_conv_layers = n
+    for i in range(n):
+        c.conv_dim[i] = cfg.conv_dim[i]
+        c.conv_kernel[i] = cfg.conv_kernel[i]
+        c.conv_stride[i] = cfg.conv_stride[i]
+    c.feat_extract_norm = 0 if cfg.feat_extract_norm == "group" else 1
+    c.conv_bias = int(cfg.conv_bias)
+    c.stable_layer_norm = int(cfg.do_stable_layer_norm)
+    c.feat_proj_layer_norm = int(cfg.feat_proj_layer_norm)
+    c.pos_conv_kernel = cfg.num_conv_pos_embeddings
+    c.pos_conv_groups = cfg.num_conv_pos_embedding_groups
+    c.layer_norm_eps = cfg.layer_norm_eps
+    c.normalize_wav = int(normalize_wav)
+    c.output_norm = int(output_norm)
+    c.precision = PRECISIONS[precision]
+    return c
+
+
+def _config_from_dir(path: str) -> Optional[EncoderConfig]:
+    f = os.path.join(path, "config.json")
+    if not os.path.isfile(f):
+        return None
+    with open(f) as fh:
+        j = json.load(fh)
+    mt = j.get("model_type", "wav2vec2")
+    if mt not in ("wav2vec2", "hubert"):
+        raise NotImplementedError(f"model_type {mt!r} is out of scope (SURVEY.md §8 note iii)")
+    return EncoderConfig(
+        name=os.path.basename(path.rstrip("/")), family=mt, hidden_size=j["hidden_size"],
+        num_hidden_layers=j["num_hidden_layers"], num_attention_heads=j["num_attention_heads"],
+        intermediate_size=j["intermediate_size"], conv_dim=tuple(j["conv_dim"]), conv_kernel=tuple(j["conv_kernel"]),
+        conv_stride=tuple(j["conv_stride"]), feat_extract_norm=j.get("feat_extract_norm", "group"),
+        conv_bias=bool(j.get("conv_bias", False)), do_stable_layer_norm=bool(j.get("do_stable_layer_norm", False)),
+        feat_proj_layer_norm=bool(j.get("feat_proj_layer_norm", True)),
+        num_conv_pos_embeddings=j.get("num_conv_pos_embeddings", 128),
+        num_conv_pos_embedding_groups=j.get("num_conv_pos_embedding_groups", 16),
+        layer_norm_eps=j.get("layer_norm_eps", 1e-5))
+
+
+class HuggingFaceWav2Vec2(nn.Module):
+    """wav2vec 2.0 / HuBERT encoder on MI355X with the reference wrapper's surface.
+
+    Arguments (reference ``huggingface_interface.py:89-98``)
+    ---------
+    source : str
+        HF hub id (``facebook/wav2vec2-base``, ``facebook/hubert-large-ll60k`` ...), one of
+        ``svt_speechbrain_amd.config.PRESETS`` or a local directory holding ``config.json``
+        (+ optionally ``pytorch_model.bin`` / a SpeechBrain ``*.ckpt``).  The model family is picked by
+        substring exactly like the reference (:107-119).
+    save_path : str
+        kept for signature compatibility (the reference caches downloads there); unused offline.
+    pretrain, output_norm, freeze, freeze_feature_extractor, apply_spec_augment : as the reference.
+        There is no network in this build, so ``pretrain=True`` loads a local checkpoint when ``source``
+        is a directory that has one and otherwise keeps the seeded initialisation (a warning is logged);
+        load real weights afterwards with ``load_state_dict`` (checkpointer path of the recipes).
+
+    Extra keyword-only arguments: ``config`` (an ``EncoderConfig``), ``precision`` ("bf16" throughput mode /
+    "fp32" parity mode; env ``SVT_PRECISION`` sets the default), ``normalize_wav`` (the reference reads
+    ``feature_extractor.do_normalize``; default True), ``seed``.
+    """
+
+    def __init__(self, source, save_path=None, pretrain=True, output_norm=True, freeze=True,
+                 freeze_feature_extractor=False, apply_spec_augment=False, *, config: Optional[EncoderConfig] = None,
+                 precision: Optional[str] = None, normalize_wav: Optional[bool] = None, seed: int = 1986):
+        super().__init__()
+        if apply_spec_augment:
+            raise NotImplementedError("apply_spec_augment is a training-time mask; the MI355X path is forward-only")
+        cfg = config
+        local_ckpt = None
+        if cfg is None and isinstance(source, str) and os.path.isdir(source):
+            cfg = _config_from_dir(source)
+            for fn in sorted(os.listdir(source)):
+                if fn.endswith(".bin") or fn.endswith(".ckpt"):
+                    local_ckpt = os.path.join(source, fn)
+                    break
+            pp = os.path.join(source, "preprocessor_config.json")
+            if normalize_wav is None and os.path.isfile(pp):
+                with open(pp) as fh:
+                    normalize_wav = bool(json.load(fh).get("do_normalize", True))
+        if cfg is None:
+            cfg = config_from_source(source)
+        self.config = cfg
+        self.source = source
+        precision = precision or os.environ.get("SVT_PRECISION", "bf16")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+        self.precision = precision
+        self.normalize_wav = True if normalize_wav is None else bool(normalize_wav)
+        self.output_norm = output_norm
+        self.freeze = freeze
+        self.freeze_feature_extractor = freeze_feature_extractor
+        self.output_size = cfg.hidden_size
+
+        self.model = ParamTree()
+        for k, v in seeded_encoder_state_dict(cfg, seed=seed).items():
+            self.model.add(k, v)
+        if pretrain:
+            if local_ckpt is not None:
+                self._load_local(local_ckpt)
+            else:
+                logger.warning("HuggingFaceWav2Vec2(%s): no network / local checkpoint in this build; weights are "
+                               "seeded random until load_state_dict() is called", source)
+        if self.freeze:
+            self.model.eval()
+            for p in self.model.parameters():
+                p.requires_grad = False
+        else:
+            self.model.train()
+            if self.freeze_feature_extractor:
+                for n, p in self.model.named_parameters():
+                    if n.startswith("feature_extractor."):
+                        p.requires_grad = False
+        self._handle = None
+        self._handle_dev = None
+        self._sig = None
+        self._ws = None
+        self._warned_grad = False
+
+    # ------------------------------------------------------------------ checkpoint intake
+    def _load_local(self, path: str) -> None:
+        sd = torch.load(path, map_location="cpu")
+        own = set(k for k, _ in self.model.named_parameters())
+        # the reference strips a "wav2vec2." prefix when reading SpeechBrain-format checkpoints (:181-215)
+        out = {}
+        for k, v in sd.items():
+            for pre in ("", "model.", "wav2vec2.", "hubert."):
+                if k.startswith(pre) and k[len(pre):] in own:
+                    out[k[len(pre):]] = v
+                    break
+        self._load_model_state(out, strict=False)
+
+    def _load_model_state(self, sd: Dict[str, torch.Tensor], strict: bool) -> None:
+        sd = self._normalise_keys(sd)
+        self.model.load_state_dict(sd, strict=strict)
+        self._sig = None
+
+    def _normalise_keys(self, sd):
+        """Accept both weight-norm spellings of the positional conv and drop the HF-only
+        ``masked_spec_embed`` (SpecAugment embedding, unused: apply_spec_augment=False, reference :127)."""
+        pc = "encoder.pos_conv_embed.conv."
+        ren = {pc + "weight_g": pc + "parametrizations.weight.original0",
+               pc + "weight_v": pc + "parametrizations.weight.original1"}
+        out = {}
+        for k, v in sd.items():
+            for pre in ("model.", ""):
+                if k.startswith(pre) and k[len(pre):] in ren:
+                    k = pre + ren[k[len(pre):]]
+                    break
+            if k.endswith("masked_spec_embed"):
+                continue
+            out[k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        res = super().load_state_dict(self._normalise_keys(dict(state_dict)), strict=strict, **kw)
+        self._sig = None
+        return res
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._sig = None
+        return r
+
+    # ------------------------------------------------------------------ device-side object
+    def _params_signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _sync_device(self, device: torch.device) -> None:
+        lib = _lib.load()
+        _lib.require_gpu()
+        idx = _lib.dev_index(device)
+        key = (idx, self.normalize_wav, self.output_norm, self.precision)
+        sig = self._params_signature()
+        if self._handle is not None and key == self._handle_dev and sig == self._sig:
+            return
+        if self._handle is not None and key != self._handle_dev:
+            lib.svt_encoder_destroy(self._handle)
+            self._handle = None
+        if self._handle is None:
+            h = C.c_void_p()
+            cc = _config_to_c(self.config, self.normalize_wav, self.output_norm, self.precision)
+            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
+            self._handle, self._handle_dev = h, key
+        for name, p in self.model.named_parameters():
+            t = p.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(lib.svt_encoder_load_param(self._handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
+                                                  t.dim()), f"svt_encoder_load_param({name})")
+        _lib.check(lib.svt_encoder_finalize(self._handle), "svt_encoder_finalize")
+        self._sig = sig
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().svt_encoder_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def num_frames(self, n_samples: int) -> int:
+        return self.config.frames(n_samples)
+
+    # ------------------------------------------------------------------ forward (reference :263-297)
+    def forward(self, wav: torch.Tensor) -> torch.Tensor:
+        if not self.freeze and torch.is_grad_enabled() and not self._warned_grad:
+            warnings.warn("svt_speechbrain_amd.HuggingFaceWav2Vec2 is forward-only: the output is detached "
+                          "(fine-tuning the encoder is out of scope of the MI355X path)")
+            self._warned_grad = True
+        with torch.no_grad():
+            return self.extract_features(wav).detach()
+
+    def extract_features(self, wav: torch.Tensor) -> torch.Tensor:
+        if wav.dim() != 2:
+            raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")
+        if not wav.is_cuda:
+            raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
+        lib = _lib.load()
+        self._sync_device(wav.device)
+        x = wav.detach().to(torch.float32).contiguous()
+        B, L = x.shape
+        T = self.config.frames(L)
+        if B < 1 or T < 1:
+            raise ValueError(f"waveform of {L} samples is shorter than the encoder's receptive field")
+        need = lib.svt_encoder_workspace_bytes(self._handle, B, L)
+        if need < 0:
+            raise _lib.SvtError(_lib.last_error())
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=x.device)
+        _lib.check(lib.svt_encoder_forward(self._handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(self._ws),
+                                           self._ws.numel(), _lib.stream_ptr(x.device)), "svt_encoder_forward")
+        return out

@@ -1,0 +1,71 @@
+"""Drop-in for ``speechbrain.nnet.linear.Linear`` (reference ``speechbrain/nnet/linear.py:15-76``): the
+20-way frame head of the AMT recipes (``hparams/train_audio_ssl.yaml:113-115``).  Same constructor, the
+``nn.Linear`` lives under attribute ``.w`` so the state-dict keys are ``w.weight`` / ``w.bias``.
+fp32 in, fp32 accumulate, fp32 out on the GPU (decode thresholds are compared in fp32)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class Linear(nn.Module):
+    def __init__(self, n_neurons, input_shape=None, input_size=None, bias=True, combine_dims=False):
+        super().__init__()
+        self.combine_dims = combine_dims
+        if input_shape is None and input_size is None:
+            raise ValueError("Expected one of input_shape or input_size")
+        if input_size is None:
+            input_size = input_shape[-1]
+            if len(input_shape) == 4 and self.combine_dims:
+                input_size = input_shape[2] * input_shape[3]
+        self.w = nn.Linear(input_size, n_neurons, bias=bias)
+        self._handle = None
+        self._key = None
+
+    def _sync(self, device):
+        lib = _lib.load()
+        _lib.require_gpu()
+        idx = _lib.dev_index(device)
+        key = (idx, self.w.weight.data_ptr(), self.w.weight._version,
+               None if self.w.bias is None else (self.w.bias.data_ptr(), self.w.bias._version))
+        if self._handle is not None and key == self._key:
+            return
+        if self._handle is None or self._key[0] != idx:
+            if self._handle is not None:
+                lib.svt_linear_destroy(self._handle)
+            h = C.c_void_p()
+            _lib.check(lib.svt_linear_create(self.w.in_features, self.w.out_features, int(self.w.bias is not None), idx,
+                                             C.byref(h)), "svt_linear_create")
+            self._handle = h
+        w = self.w.weight.detach().to("cpu", torch.float32).contiguous()
+        b = None if self.w.bias is None else self.w.bias.detach().to("cpu", torch.float32).contiguous()
+        _lib.check(lib.svt_linear_load(self._handle, C.c_void_p(w.data_ptr()),
+                                       C.c_void_p(b.data_ptr()) if b is not None else None), "svt_linear_load")
+        self._key = key
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().svt_linear_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 4 and self.combine_dims:
+            x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+        if not x.is_cuda:
+            raise _lib.SvtError("svt_speechbrain_amd.Linear needs its input on the GPU; there is no CPU fallback")
+        lib = _lib.load()
+        self._sync(x.device)
+        xf = x.detach().to(torch.float32).contiguous()
+        rows = xf.numel() // xf.shape[-1] if xf.numel() else 0
+        y = torch.empty(xf.shape[:-1] + (self.w.out_features,), dtype=torch.float32, device=x.device)
+        if rows:
+            _lib.check(lib.svt_linear_forward(self._handle, _lib.ptr(xf), rows, _lib.ptr(y), _lib.stream_ptr(x.device)),
+                       "svt_linear_forward")
+        return y
