@@ -1,0 +1,174 @@
+"""Benchmark of the hot path: 10 s @ 16 kHz clips/s through encoder + frame head + per-frame decode.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): wav2vec2-base, 32 x 10 s clips per GPU, bf16 MFMA operands,
+synthetic waveform (seed 1986, 0.1*randn clamped to [-1,1]) already resident in HBM, seeded random weights.
+One step = encoder forward (incl. both whole-batch layer norms) -> 20-way head -> sigmoid/argmax frame
+decode kernel (+ one all-gather of the logits over RCCL when N > 1).  Weak scaling: the per-GPU batch is
+fixed, ranks own disjoint clips.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X dense peaks (MI355X_MICROARCH.md)
+
+
+def synth_wav(B, L, seed=1986):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+
+
+def cpu_baseline(cfg, sd, hd, seconds, budget_s=25.0):
+    """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the host cores."""
+    from oracle import svt_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    wav = synth_wav(B, int(16000 * seconds), seed=1986)
+
+    def one():
+        with torch.no_grad():
+            f = O.encoder_forward(sd, cfg, wav)
+            lg = O.head_forward(f, hd["w.weight"], hd["w.bias"])
+            O.decode_frames(lg)
+
+    t0 = time.perf_counter()
+    one()  # warm-up
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < 3 and (time.perf_counter() - t0) + warm < budget_s:
+        t = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t)
+    if not times:
+        times = [warm]
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/svt_oracle.py fp32, {B} x {seconds:g} s clips per pass, 1 warm-up + {len(times)} timed "
+                      f"passes (median), torch.set_num_threads({cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="wav2vec2-base")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import svt_speechbrain_amd as S
+    from svt_speechbrain_amd import _lib, distributed as D
+    from svt_speechbrain_amd import weights as W
+
+    rank, local, world = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    lib = _lib.load()
+    _lib.require_gpu()
+
+    cfg = S.PRESETS[args.model]
+    L = int(16000 * args.seconds)
+    T = cfg.frames(L)
+    B = args.batch
+    n_total = B * world
+    lo, hi = D.shard_bounds(n_total, rank, world)
+    # every rank generates only its own clips (seeded per clip index range), already on the device
+    wav = synth_wav(n_total, L, seed=1986)[lo:hi].to(dev) if world > 1 else synth_wav(B, L).to(dev)
+
+    enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, seed=1986).to(dev)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=2986)
+    head.load_state_dict(hd)
+    head = head.to(dev)
+    frames = torch.empty((B * T, 4), dtype=torch.int32, device=dev)
+
+    def step():
+        feats = enc(wav)
+        logits = head(feats)
+        _lib.check(lib.svt_decode_frames(_lib.ptr(logits), B * T, 20, 4, 12, _lib.ptr(frames), local,
+                                         _lib.stream_ptr(dev)), "svt_decode_frames")
+        if world > 1:
+            return D.all_gather_rows(logits, n_total, world)
+        return logits
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    lib.svt_prof_reset()
+    lib.svt_prof_enable(1)
+    D.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier(world)
+    elapsed = time.perf_counter() - t0
+    lib.svt_prof_enable(0)
+    elapsed = D.max_over_ranks(elapsed, world, dev)
+    assert out.shape[0] == n_total
+
+    n_launch, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    _lib.check(lib.svt_prof_read(C.byref(n_launch), C.byref(ms), C.byref(fl), C.byref(by)), "svt_prof_read")
+
+    if rank == 0:
+        clips_per_s = n_total * args.steps / elapsed
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        flops_clip = cfg.flops_per_clip(L)
+        res = {
+            "metric": "10s@16kHz clips/sec encoder+CTC forward, wav2vec2-base, 1/2/4/8 MI355X",
+            "value": round(clips_per_s, 3),
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} audio-only AMT forward (encoder + 20-way head + frame decode), "
+                                   f"{B} x {args.seconds:g} s @16 kHz mono clips per GPU",
+                       "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
+                       "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
+                       "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
+            "roofline": {"bound": "mfma", "kernel": "svt::gemm_kernel (all dense contractions of the step)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / max(1, n_launch.value), 5),
+                         "gemm_ms_per_step": round(ms.value / args.steps, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, hd, args.seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

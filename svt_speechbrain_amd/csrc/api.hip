@@ -143,9 +143,19 @@ struct AttnBufs {
 static size_t esize(int prec) { return prec ? 2 : 4; }
 
 // out[b,t,h*dh+d] = softmax(scale * q k^T) v ; q rows at Q + (b*T+t)*ldq + h*dh, likewise K (ldkv), V (ldkv)
+static bool use_flash(int prec, int dh) { return prec == 1 && (dh == 64 || dh == 128); }
+static int attn_tp(int prec, int dh, int T) { return use_flash(prec, dh) ? round_up_int(T, 64) : round_up_int(T, 8); }
+
 static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
                                  long ldo, hipStream_t s) {
+  if (use_flash(prec, dh)) {
+    const int Tp64 = round_up_int(T, 64);
+    if (!vt_ready)
+      if (int r = launch_transpose_v(prec, V, B, T, H, dh, ldkv, 0, Tp64, ab.Vt, s)) return r;
+    return launch_flash_attention(Q, ldq, (long)T * ldq, K, ldkv, (long)T * ldkv, ab.Vt, Tp64, out, ldo, (long)T * ldo,
+                                  B, T, H, dh, scale, s);
+  }
   const int Tp = round_up_int(T, 8);
   GemmArgs g;
   g.A = Q; g.W = K; g.C = ab.S;
@@ -479,7 +489,8 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.convF = c.feat_extract_norm == SVT_NORM_LAYER ? (float*)cv.take(max_f) : nullptr;
   const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
   const size_t rows = (size_t)B * T;
-  const int Tp = round_up_int((int)T, 8);
+  const int Tp = attn_tp(c.precision, dh, (int)T);
+  const bool flash = use_flash(c.precision, dh);
   w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers - 1] * es);
   w.hF = (float*)cv.take(rows * D * 4);
   w.preF = (float*)cv.take(rows * D * 4);
@@ -487,8 +498,8 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.xF = c.precision ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
   w.posg = cv.take((size_t)B * (T + c.pos_conv_kernel) * D * es);
   w.qkv = cv.take(rows * 3 * D * es);
-  w.ab.S = (float*)cv.take((size_t)B * H * T * Tp * 4);
-  w.ab.P = cv.take((size_t)B * H * T * Tp * es);
+  w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * H * T * Tp * 4);
+  w.ab.P = flash ? nullptr : cv.take((size_t)B * H * T * Tp * es);
   w.ab.Vt = cv.take((size_t)B * H * dh * Tp * es);
   w.attn_o = cv.take(rows * D * es);
   w.ffn = cv.take(rows * F * es);
@@ -758,15 +769,16 @@ RcaWs carve_rca(const svt_rca* r, int B, int T, void* base) {
   Carver cv(base);
   RcaWs w;
   const size_t es = esize(r->prec), rows = (size_t)B * T, D = r->D;
-  const int dh = r->D / r->H, Tp = round_up_int(T, 8);
+  const int dh = r->D / r->H, Tp = attn_tp(r->prec, dh, T);
+  const bool flash = use_flash(r->prec, dh);
   w.s1F = (float*)cv.take(rows * D * 4);
   w.s2F = (float*)cv.take(rows * D * 4);
   w.s1T = r->prec ? cv.take(rows * D * es) : (void*)w.s1F;
   w.s2T = r->prec ? cv.take(rows * D * es) : (void*)w.s2F;
   w.qkv = cv.take(rows * 3 * D * es);
   w.qc = cv.take(rows * D * es);
-  w.ab.S = (float*)cv.take((size_t)B * r->H * T * Tp * 4);
-  w.ab.P = cv.take((size_t)B * r->H * T * Tp * es);
+  w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * r->H * T * Tp * 4);
+  w.ab.P = flash ? nullptr : cv.take((size_t)B * r->H * T * Tp * es);
   w.ab.Vt = cv.take((size_t)B * r->H * dh * Tp * es);
   w.att_s = cv.take(rows * D * es);
   w.att_c = cv.take(rows * D * es);

@@ -86,6 +86,11 @@ int launch_softmax_rows(int prec, const float* S, int64_t rows, int T, int Tp, v
 int launch_transpose_v(int prec, const void* qkv, int B, int T, int H, int dh, long ld, long voff, int Tp,
                        void* Vt, hipStream_t s);
 
+// fused attention (bf16, head_dim 64/128): Q/K row-major with row strides ldq/ldk and per-clip strides, V^T padded
+int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, long ldk, long k_bstride,
+                           const void* Vt, int Tp, void* O, long ldo, long o_bstride, int B, int T, int H, int dh,
+                           float scale, hipStream_t s);
+
 // out = a*x + b*y (fp32 or operand type)
 int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s);
 // RCA: s = x + pe[t] (x f32 (B,T,D); x2 may be shorter in T: rows >= T2 read as zero) -> fp32 + operand type

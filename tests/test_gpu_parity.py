@@ -1,0 +1,231 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(ctypes -> libsvt_mi355.so), against the oracle and against the golden vectors captured from the
+reference.  Tolerances: fp32 parity mode — logits within 1e-3 (north star) and identical per-frame
+argmax / note sequences; bf16 throughput mode — reported error bound + decode agreement rate."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import svt_speechbrain_amd as S  # noqa: E402
+from oracle import svt_oracle as O  # noqa: E402
+from svt_speechbrain_amd import weights as W  # noqa: E402
+from svt_speechbrain_amd.config import PRESETS  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def synth_wav(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+
+
+def build(cfg_name, weight_seed, head_seed, precision):
+    cfg = PRESETS[cfg_name]
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision=precision, seed=weight_seed).to(DEV)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict(W.seeded_head_state_dict(cfg.hidden_size, 20, seed=head_seed))
+    return cfg, enc, head.to(DEV)
+
+
+def golden_wav(fx):
+    if "wav" in fx:
+        return fx["wav"]
+    wav = synth_wav(fx["B"], fx["L"], fx["wav_seed"])
+    if fx.get("lens"):
+        for b, n in enumerate(fx["lens"]):
+            wav[b, n:] = 0
+    return wav
+
+
+def check_decode(logits_gpu, fx, exact=True):
+    frames = S.decode_frames(logits_gpu)
+    mism = 0
+    for b, d in enumerate(fx["decode"]):
+        o = torch.from_numpy(frames["octave"][b].astype(np.int64))
+        p = torch.from_numpy(frames["pitch_class"][b].astype(np.int64))
+        mism += int(((o != d["oct"]) | (p != d["pc"])).sum())
+        if exact:
+            assert torch.equal(o, d["oct"]) and torch.equal(p, d["pc"])
+            notes = S.frame2note(S.frames_to_info(frames[b]), 0.4, 0.5)
+            assert notes == d["notes"], f"clip {b}: note sequence differs from the reference"
+    return mism
+
+
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged"])
+def test_tiny_fp32_vs_reference_golden(golden, name):
+    fx = golden(name)
+    cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp32")
+    wav = golden_wav(fx).to(DEV)
+    feats = enc(wav)
+    logits = head(feats)
+    assert feats.shape == fx["feats"].shape
+    assert (feats.cpu() - fx["feats"]).abs().max() < 1e-3
+    assert (logits.cpu() - fx["logits"]).abs().max() < 1e-3
+    check_decode(logits, fx, exact=True)
+
+
+@pytest.mark.parametrize("name", ["base_c1", "base_b2", "large_c1", "hubert_large_c1"])
+def test_full_size_fp32_vs_reference_golden(golden, name):
+    fx = golden(name)
+    cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp32")
+    wav = golden_wav(fx)
+    assert hashlib.sha256(wav.numpy().tobytes()).hexdigest() == fx["wav_sha256"]
+    feats = enc(wav.to(DEV))
+    logits = head(feats)
+    assert feats.shape[1] == fx["T"]
+    assert (feats.cpu()[:, ::25, ::16] - fx["feats_strided"]).abs().max() < 1e-3
+    err = (logits.cpu() - fx["logits"]).abs().max().item()
+    assert err < 1e-3, err
+    check_decode(logits, fx, exact=True)
+
+
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "large_c1"])
+def test_bf16_mode_error_bound(golden, name):
+    """bf16 MFMA operands, fp32 accumulate/residual/norms: bounded error, decode mostly identical."""
+    fx = golden(name)
+    cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "bf16")
+    wav = golden_wav(fx).to(DEV)
+    logits = head(enc(wav))
+    err = (logits.cpu() - fx["logits"]).abs()
+    mism = check_decode(logits, fx, exact=False)
+    total = fx["logits"].shape[0] * fx["logits"].shape[1]
+    print(f"bf16[{name}]: max|dlogit| {err.max():.4f} mean {err.mean():.4f} (logit std {fx['logits'].std():.2f}); "
+          f"frames with a different octave/pitch-class argmax: {mism}/{total}")
+    assert err.max() < 1.5, err.max()
+    assert err.mean() < 0.08, err.mean()
+    assert mism <= max(2, int(0.12 * total)), (mism, total)
+
+
+def test_encoder_flags_and_batch_coupling():
+    """normalize_wav / output_norm off, and the whole-batch norms couple clips."""
+    cfg = PRESETS["tiny-group"]
+    sd = W.seeded_encoder_state_dict(cfg, seed=3)
+    wav = synth_wav(3, 5000, 9)
+    for nw, on in [(False, False), (True, False), (False, True)]:
+        enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32", seed=3, normalize_wav=nw,
+                                    output_norm=on).to(DEV)
+        with torch.no_grad():
+            ref = O.encoder_forward(sd, cfg, wav, normalize_wav=nw, output_norm=on)
+        out = enc(wav.to(DEV)).cpu()
+        assert (out - ref).abs().max() < 1e-3, (nw, on)
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32", seed=3).to(DEV)
+    a = enc(wav.to(DEV))[0].cpu()
+    b = enc(wav[:1].to(DEV))[0].cpu()
+    assert (a - b).abs().max() > 1e-3  # same clip, different batch-mates -> different output, as in the reference
+
+
+def test_state_dict_roundtrip_and_old_weight_norm_keys():
+    cfg = PRESETS["tiny-layer"]
+    enc = S.HuggingFaceWav2Vec2("tiny-layer", None, config=cfg, precision="fp32", seed=1).to(DEV)
+    wav = synth_wav(1, 3000, 2).to(DEV)
+    before = enc(wav).cpu()
+    sd_new = {"model." + k: v for k, v in W.seeded_encoder_state_dict(cfg, seed=77, old_weight_norm_keys=True).items()}
+    enc.load_state_dict(sd_new, strict=True)
+    after = enc(wav).cpu()
+    assert (before - after).abs().max() > 1e-2
+    with torch.no_grad():
+        ref = O.encoder_forward(W.seeded_encoder_state_dict(cfg, seed=77), cfg, wav.cpu())
+    assert (after - ref).abs().max() < 1e-3
+    keys = list(enc.state_dict().keys())
+    assert all(k.startswith("model.") for k in keys) and len(keys) == len(sd_new)
+
+
+@pytest.mark.parametrize("name", ["fusion_eq", "fusion_pad", "fusion_trunc"])
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+def test_fusion_vs_reference_golden(golden, name, prec, tol):
+    fx = golden(name)
+    fus = S.FusionRCA(precision=prec, seed=fx["weight_seed"]).to(DEV)
+    g = torch.Generator().manual_seed(fx["in_seed"])
+    a = torch.randn(fx["B"], fx["T1"], 1024, generator=g)
+    v = torch.randn(fx["B"], fx["T2"], 1024, generator=g)
+    out = fus(a.to(DEV), v.to(DEV)).cpu()
+    assert out.shape == (fx["B"], fx["T1"], 1024)
+    assert (out[:, ::7, ::5] - fx["out_strided"]).abs().max() < tol
+    assert (out[:, :4] - fx["out_first"]).abs().max() < tol
+
+
+def test_fusion_state_dict_keys():
+    fus = S.FusionRCA()
+    want = set(W.fusion_param_shapes().keys())
+    assert set(fus.state_dict().keys()) == want
+
+
+def test_linear_general_and_head():
+    g = torch.Generator().manual_seed(0)
+    for n_in, n_out, rows in [(768, 20, 499), (64, 20, 7), (128, 96, 300), (100, 50, 33)]:
+        lin = S.Linear(n_out, input_size=n_in)
+        x = torch.randn(3, rows, n_in, generator=g)
+        ref = torch.nn.functional.linear(x, lin.w.weight, lin.w.bias)
+        out = lin.to(DEV)(x.to(DEV)).cpu()
+        assert out.shape == ref.shape
+        assert (out - ref).abs().max() < 1e-4, (n_in, n_out)
+    nb = S.Linear(20, input_shape=[2, 5, 64], bias=False)
+    x = torch.randn(2, 5, 64, generator=g)
+    assert (nb.to(DEV)(x.to(DEV)).cpu() - x @ nb.w.weight.detach().cpu().t()).abs().max() < 1e-4
+
+
+def test_decode_frames_first_max_and_sigmoid():
+    lg = torch.zeros(4, 20)
+    lg[0, 2:7] = torch.tensor([1.0, 3.0, 3.0, 0.0, -1.0])  # tie -> first max (index 1)
+    lg[1, 7:] = 5.0                                          # all equal -> 0
+    lg[2, 0], lg[2, 1] = 2.0, -2.0
+    lg[3, 6], lg[3, 19] = 9.0, 9.0
+    fr = S.decode_frames(lg.to(DEV))
+    assert fr["octave"].tolist() == [1, 0, 0, 4]
+    assert fr["pitch_class"].tolist() == [0, 0, 0, 12]
+    assert abs(fr["p_on"][2] - float(torch.sigmoid(torch.tensor(2.0)))) < 1e-6
+    assert abs(fr["p_off"][2] - float(torch.sigmoid(torch.tensor(-2.0)))) < 1e-6
+
+
+def test_ctc_greedy_vs_reference_golden(golden):
+    for k, c in golden("ctc").items():
+        got = S.ctc_greedy_decode(c["probs"].to(DEV), c["lens"].to(DEV), c["blank"])
+        assert got == c["expect"], k
+
+
+def test_fbank_vs_reference_golden(golden):
+    fb = S.Fbank()
+    for k, c in golden("fbank").items():
+        out = fb(c["wav"].to(DEV)).cpu()
+        assert out.shape == c["feats"].shape
+        assert (out - c["feats"]).abs().max() < 5e-3, k
+
+
+def test_errors_are_exceptions():
+    from svt_speechbrain_amd import _lib
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32").to(DEV)
+    with pytest.raises(ValueError):
+        enc(torch.zeros(1, 100, device=DEV))  # shorter than the receptive field
+    with pytest.raises(_lib.SvtError):
+        enc(torch.zeros(1, 4000))  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        enc(torch.zeros(4000, device=DEV))
+
+
+@pytest.mark.parametrize("cfg_name,B,L", [("wav2vec2-base", 4, 160000), ("wav2vec2-base", 3, 52345)])
+def test_full_size_properties(cfg_name, B, L):
+    """Size-independent properties at BASELINE sizes (oracle too slow to run per test):
+    determinism (bitwise), whole-batch output norm (zero mean / unit variance), permutation equivariance
+    over clips (the batch statistics are permutation invariant), fp32 vs bf16 agreement."""
+    cfg = PRESETS[cfg_name]
+    enc32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=5).to(DEV)
+    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=5).to(DEV)
+    wav = synth_wav(B, L, 123).to(DEV)
+    a = enc32(wav)
+    b = enc32(wav)
+    assert a.shape == (B, cfg.frames(L), cfg.hidden_size)
+    assert torch.isfinite(a).all()
+    # fp64 atomics make the two global moments order-dependent in the last bits -> allow 1e-5, not bitwise
+    assert (a - b).abs().max() < 1e-5
+    assert abs(a.mean().item()) < 1e-4 and abs(a.var(unbiased=False).item() - 1.0) < 1e-3
+    perm = torch.arange(B - 1, -1, -1, device=DEV)
+    c = enc32(wav[perm])
+    assert (c[perm] - a).abs().max() < 2e-4
+    d = enc16(wav)
+    print(f"bf16 vs fp32 feats ({cfg_name},B={B},L={L}): mean|d| {(d - a).abs().mean():.4f} max {(d - a).abs().max():.4f}")
+    assert (d - a).abs().mean() < 0.08 and (d - a).abs().max() < 1.5

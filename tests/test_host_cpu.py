@@ -1,0 +1,107 @@
+"""CPU tests (-m "not gpu"): host logic, state-dict schema, C-ABI symbol export, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import svt_speechbrain_amd as S
+from svt_speechbrain_amd import _lib
+from svt_speechbrain_amd import weights as W
+from svt_speechbrain_amd.config import PRESETS, config_from_source
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/svt_mi355.h is exported by the built .so and bound by _lib."""
+    hdr = open(os.path.join(ROOT, "include", "svt_mi355.h")).read()
+    declared = set(re.findall(r"\b(svt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"svt_encoder_config"}
+    assert declared == set(_lib.SYMBOLS.keys()), declared ^ set(_lib.SYMBOLS.keys())
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.svt_abi_version() == 1
+    assert ctypes.sizeof(_lib.FrameC) == 16
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    assert lib.svt_device_count() == 0
+    with pytest.raises(_lib.SvtError):
+        _lib.require_gpu()
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=PRESETS["tiny-group"])
+    with pytest.raises(_lib.SvtError):
+        enc(torch.zeros(1, 4000))
+    with pytest.raises(_lib.SvtError):
+        S.Linear(20, input_size=8)(torch.zeros(1, 8))
+    with pytest.raises(_lib.SvtError):
+        S.FusionRCA(d_model=64, nhead=8, d_ffn=128)(torch.zeros(1, 4, 64), torch.zeros(1, 4, 64))
+    # C-ABI level: create on a machine without a device returns a status + message, never aborts
+    cc = S.huggingface_interface._config_to_c(PRESETS["tiny-group"], True, True, "fp32")
+    h = ctypes.c_void_p()
+    rc = lib.svt_encoder_create(ctypes.byref(cc), 0, ctypes.byref(h))
+    assert rc == -6 and b"no HIP device" in lib.svt_last_error()
+
+
+def test_config_frames_and_flops():
+    base = PRESETS["wav2vec2-base"]
+    assert base.frames(160000) == 499 and base.frames(80000) == 249
+    assert base.frame_counts(160000) == [31999, 15999, 7999, 3999, 1999, 999, 499]
+    assert abs(base.flops_per_clip(160000) / 1e9 - 148.14) < 0.05
+    assert abs(PRESETS["wav2vec2-large-lv60"].flops_per_clip(160000) / 1e9 - 383.86) < 0.1
+    assert config_from_source("facebook/wav2vec2-base").hidden_size == 768
+    assert config_from_source("facebook/wav2vec2-large-lv60").do_stable_layer_norm
+    assert config_from_source("facebook/hubert-large-ll60k").family == "hubert"
+    with pytest.raises(NotImplementedError):
+        config_from_source("microsoft/wavlm-large")
+
+
+def test_state_dict_schema_matches_hf_keys():
+    for name in ["tiny-group", "tiny-layer", "tiny-hubert"]:
+        cfg = PRESETS[name]
+        enc = S.HuggingFaceWav2Vec2(name, None, config=cfg)
+        keys = list(enc.state_dict().keys())
+        assert keys == ["model." + k for k in W.encoder_param_shapes(cfg).keys()]
+        for k, shp in W.encoder_param_shapes(cfg).items():
+            assert tuple(enc.state_dict()["model." + k].shape) == shp
+    assert not any(p.requires_grad for p in enc.parameters())  # freeze=True
+    enc2 = S.HuggingFaceWav2Vec2("tiny-group", None, config=PRESETS["tiny-group"], freeze=False,
+                                 freeze_feature_extractor=True)
+    rg = {n: p.requires_grad for n, p in enc2.named_parameters()}
+    assert not rg["model.feature_extractor.conv_layers.0.conv.weight"] and rg["model.encoder.layer_norm.weight"]
+    lin = S.Linear(20, input_size=64)
+    assert list(lin.state_dict().keys()) == ["w.weight", "w.bias"]
+    fus = S.FusionRCA(d_model=64, nhead=8, d_ffn=128, max_length=50)
+    assert list(fus.state_dict().keys())[0] == "fusion.positional_encoding.pe"
+    assert fus.state_dict()["fusion.layer2.self_att.att.in_proj_weight"].shape == (192, 64)
+
+
+def test_frame2note_matches_reference_golden(golden):
+    for k, c in golden("frame2note").items():
+        info = list(zip(c["p_on"].numpy(), c["p_off"].numpy(), c["oct"].tolist(), c["pc"].tolist()))
+        assert S.frame2note(info, 0.4, 0.5, 1 / 49.8) == c["notes"], k
+    with pytest.raises(ValueError):
+        S.frame2note([(np.float32(0.9), np.float32(0.1), 1, 1)], 0.4, 0.5)
+    assert S.frame2note([], 0.4, 0.5) == []
+
+
+def test_filter_ctc_output_doctest():
+    assert S.filter_ctc_output(['a', 'a', 'blank', 'b', 'b', 'blank', 'c'], blank_id='blank') == ['a', 'b', 'c']
+    with pytest.raises(ValueError):
+        S.filter_ctc_output("aab")
+
+
+def test_shard_bounds_cover_and_order():
+    from svt_speechbrain_amd.distributed import shard_bounds
+    for n in [0, 1, 7, 32, 513]:
+        for w in [1, 2, 3, 8]:
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
