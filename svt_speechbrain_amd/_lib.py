@@ -77,6 +77,9 @@ SYMBOLS = {
     "svt_fbank_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "svt_fbank": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                             C.c_float, C.c_float, C.c_float, _P, _P, C.c_size_t, C.c_int, _P]),
+    "svt_debug_gemm": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                 C.c_int64, C.c_int32, C.c_int32, C.c_int, _P]),
+    "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_prof_enable": (C.c_int, [C.c_int]),
     "svt_prof_reset": (C.c_int, []),
     "svt_prof_read": (C.c_int, [_I64P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -258,6 +258,26 @@ int svt_device_count(void) {
   return ok;
 }
 
+int svt_debug_gemm(int32_t precision, const void* a, const void* w, void* c, const float* bias, const float* resid,
+                   int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int32_t act,
+                   int32_t out_f32, int device, void* stream) {
+  if (!a || !w || !c) { set_error("svt_debug_gemm: null argument"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(device));
+  GemmArgs g;
+  g.A = a; g.W = w; g.C = c; g.bias = bias; g.resid = resid;
+  g.M = m; g.N = n; g.K = k; g.a_rpb = a_rpb; g.a_bstride = a_bstride; g.a_rstride = a_rstride;
+  g.ldw = k; g.ldc = n; g.act = act; g.out_f32 = out_f32;
+  return launch_gemm(precision, g, (hipStream_t)stream) ? SVT_ERR_INVALID : SVT_OK;
+}
+
+int svt_debug_set(int key, int value) {
+  if (key == 0) g_gemm_dbg = value;
+  else if (key == 1) g_gemm_force_bm = value;
+  else if (key == 2) g_gemm_ring = value;
+  else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
+  return SVT_OK;
+}
+
 int svt_prof_enable(int on) { g_prof.on = on != 0; return SVT_OK; }
 int svt_prof_reset(void) { g_prof.used = 0; g_prof.flops = 0; g_prof.bytes = 0; return SVT_OK; }
 int svt_prof_read(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {

@@ -42,11 +42,19 @@ struct GemmArgs {
   float alpha = 1.f;
   int act = ACT_NONE;
   int out_f32 = 0;  // C is fp32 regardless of the operand type
+  int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
 };
 
 // operand type: 0 = fp32 (v_mfma_f32_16x16x4_f32, exact fp32 fma chain), 1 = bf16 (v_mfma_f32_16x16x32_bf16)
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
+
+// large-tile LDS-DMA variant (bf16, K % 64 == 0); launch_gemm dispatches to it
+bool gemm_dma_eligible(const GemmArgs& a);
+int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
+extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debug_set)
+extern int g_gemm_force_bm;
+extern int g_gemm_ring;
 
 // ---- profiling of the dominant kernel (bench.py roofline leg) ----
 void prof_begin(hipStream_t s);

@@ -279,6 +279,7 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
   g.c_vec = mult(a.ldc, cel) && mult(a.c_z1, cel) && mult(a.c_z2, cel) && !((uintptr_t)a.C & 15) &&
             mult(a.ldc, 4) && mult(a.c_z1, 4) && mult(a.c_z2, 4) && !((uintptr_t)a.resid & 15) &&
             mult(a.bias_z2, 4) && !((uintptr_t)a.bias & 15);
+  if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   const bool narrow = a.N <= 64;
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
   return narrow ? launch_one<float, 256, 64>(g, s) : launch_one<float, 128, 128>(g, s);

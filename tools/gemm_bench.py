@@ -1,0 +1,97 @@
+"""Micro-benchmark + correctness check of the dense contraction kernel on the encoder's real shapes
+(random data — zero-filled operands read high on this chip).  Usage: python tools/gemm_bench.py [--check]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from svt_speechbrain_amd import _lib  # noqa: E402
+
+SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f32, resid
+    ("conv1", 32 * 15999, 512, 1536, (31999, 15999, 2, 512), 1, 0, 0),
+    ("conv2", 32 * 7999, 512, 1536, (15999, 7999, 2, 512), 1, 0, 0),
+    ("conv5", 32 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, 0),
+    ("proj", 15968, 768, 512, None, 0, 1, 0),
+    ("qkv", 15968, 2304, 768, None, 0, 0, 0),
+    ("out_proj", 15968, 768, 768, None, 0, 1, 1),
+    ("ffn1", 15968, 3072, 768, None, 1, 0, 0),
+    ("ffn2", 15968, 768, 3072, None, 0, 1, 1),
+    ("large_ffn1", 31936, 4096, 1024, None, 1, 0, 0),
+]
+
+
+def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters):
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if prec else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(1)
+    if conv:
+        T_in, T_out, st, cin = conv
+        B = M // T_out
+        A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(dev, dt)
+        rpb, bstr, rstr = T_out, T_in * cin, st * cin
+    else:
+        A = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, dt)
+        rpb, bstr, rstr = M, 0, K
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
+    bias = torch.randn(N, generator=g).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev) if resid else None
+    C = torch.empty(M, N, device=dev, dtype=torch.float32 if (out_f32 or not prec) else dt)
+    st_ = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(),
+                                      R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, act, out_f32, 0, st_),
+                   "svt_debug_gemm")
+
+    call()
+    torch.cuda.synchronize()
+    err = None
+    if check:
+        if conv:
+            T_in, T_out, st, cin = conv
+            k = K // cin
+            idx = (torch.arange(T_out, device=dev) * st)[:, None] + torch.arange(k, device=dev)[None, :]
+            A2 = A[:2, idx].reshape(2 * T_out, K).float()
+            ref = A2 @ W.float().t() + bias
+            got = C[: 2 * T_out].float()
+        else:
+            rows = min(M, 4096)
+            ref = A[:rows].float() @ W.float().t() + bias
+            got = C[:rows].float()
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if resid:
+            ref = ref + R[: ref.shape[0]]
+        err = (got - ref).abs().max().item()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / ms / 1e9
+    print(f"{name:12s} M={M:7d} N={N:5d} K={K:5d} prec={'bf16' if prec else 'fp32'} {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s"
+          + (f"  max|err|={err:.3e}" if err is not None else ""), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--prec", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--bm", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=1)
+    a = ap.parse_args()
+    _lib.load().svt_debug_set(0, a.dbg)
+    _lib.load().svt_debug_set(1, a.bm)
+    _lib.load().svt_debug_set(2, a.ring)
+    for s in SHAPES:
+        if a.only and a.only not in s[0]:
+            continue
+        run(*s, a.prec, a.check, a.iters)
