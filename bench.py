@@ -34,10 +34,12 @@ def synth_wav(B, L, seed=1986):
 
 
 def cpu_baseline(cfg, sd, hd, seconds, budget_s=25.0):
-    """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the host cores."""
+    """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the host cores.
+    ATen's intra-op threading stops scaling well before 128 cores on this workload (measured on the GPU box:
+    16 threads 3.95 clips/s, 64 threads 2.5, 128 threads 1.1), so a short sweep picks the best thread count
+    and `cores` reports the threads actually used for the quoted number."""
     from oracle import svt_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     B = 4
     wav = synth_wav(B, int(16000 * seconds), seed=1986)
 
@@ -47,21 +49,24 @@ def cpu_baseline(cfg, sd, hd, seconds, budget_s=25.0):
             lg = O.head_forward(f, hd["w.weight"], hd["w.bias"])
             O.decode_frames(lg)
 
-    t0 = time.perf_counter()
-    one()  # warm-up
-    warm = time.perf_counter() - t0
-    times = []
-    while len(times) < 3 and (time.perf_counter() - t0) + warm < budget_s:
+    t_start = time.perf_counter()
+    best = None
+    tried = []
+    for nt in [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]:
+        if time.perf_counter() - t_start > budget_s:
+            break
+        torch.set_num_threads(nt)
+        one()  # warm-up at this thread count
         t = time.perf_counter()
         one()
-        times.append(time.perf_counter() - t)
-    if not times:
-        times = [warm]
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/svt_oracle.py fp32, {B} x {seconds:g} s clips per pass, 1 warm-up + {len(times)} timed "
-                      f"passes (median), torch.set_num_threads({cores})"}
+        dt = time.perf_counter() - t
+        tried.append((nt, round(B / dt, 3)))
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    nt, dt = best
+    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": nt, "kind": "port",
+            "sample": f"oracle/svt_oracle.py fp32 (torch CPU), {B} x {seconds:g} s clips per pass, 1 warm-up + 1 timed pass "
+                      f"per thread count, best of {tried} (threads, clips/s); host has {ncpu} logical CPUs"}
 
 
 def main():
@@ -130,13 +135,18 @@ def main():
     elapsed = D.max_over_ranks(elapsed, world, dev)
     assert out.shape[0] == n_total
 
-    n_launch, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-    _lib.check(lib.svt_prof_read(C.byref(n_launch), C.byref(ms), C.byref(fl), C.byref(by)), "svt_prof_read")
+    def prof(kind):
+        n, ms_, fl_, by_ = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(lib.svt_prof_read(kind, C.byref(n), C.byref(ms_), C.byref(fl_), C.byref(by_)), "svt_prof_read")
+        return n.value, ms_.value, fl_.value, by_.value
+
+    k_dom, k_other, k_attn = prof(0), prof(1), prof(2)
 
     if rank == 0:
         clips_per_s = n_total * args.steps / elapsed
         peak = MFMA_PEAK_TFLOPS[args.precision]
-        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        n_l, ms, fl, _ = k_dom
+        achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         flops_clip = cfg.flops_per_clip(L)
         res = {
             "metric": "10s@16kHz clips/sec encoder+CTC forward, wav2vec2-base, 1/2/4/8 MI355X",
@@ -156,11 +166,16 @@ def main():
                        "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
-            "roofline": {"bound": "mfma", "kernel": "svt::gemm_kernel (all dense contractions of the step)",
+            # dominant kernel = svt::gemm_uring_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
+            # launches / HIP-event time of those launches on their stream, over the timed region
+            "roofline": {"bound": "mfma", "kernel": "svt::gemm_uring_kernel<128|192|256>",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
-                         "launches": int(n_launch.value), "avg_launch_ms": round(ms.value / max(1, n_launch.value), 5),
-                         "gemm_ms_per_step": round(ms.value / args.steps, 4)},
+                         "launches": int(n_l), "avg_launch_ms": round(ms / max(1, n_l), 5),
+                         "ms_per_step": round(ms / args.steps, 4),
+                         "flops_per_launch_avg": round(fl / max(1, n_l), 1),
+                         "other_kernels_ms_per_step": {"small/fp32 gemm": round(k_other[1] / args.steps, 4),
+                                                       "flash_attn": round(k_attn[1] / args.steps, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}

@@ -167,7 +167,9 @@ int svt_debug_set(int key, int value);
  * the launch stream; svt_prof_read returns accumulated launches / milliseconds / algorithmic flops. */
 int svt_prof_enable(int on);
 int svt_prof_reset(void);
-int svt_prof_read(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
+/* kind: 0 = svt::gemm_uring_kernel (the dominant kernel: every large bf16 dense contraction), 1 = the other dense
+ * contraction kernels (fp32 / small-shape GEMM), 2 = fused attention */
+int svt_prof_read(int kind, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ SYMBOLS = {
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_prof_enable": (C.c_int, [C.c_int]),
     "svt_prof_reset": (C.c_int, []),
-    "svt_prof_read": (C.c_int, [_I64P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "svt_prof_read": (C.c_int, [C.c_int, _I64P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -26,7 +26,8 @@ struct ProfState {
   bool on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
-  double flops = 0, bytes = 0;
+  std::vector<int> kind;
+  double flops[3] = {0, 0, 0}, bytes[3] = {0, 0, 0};
   static constexpr size_t kMax = 16384;
 };
 static ProfState g_prof;
@@ -39,12 +40,14 @@ void prof_begin(hipStream_t s) {
   }
   (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
 }
-void prof_end(hipStream_t s, double flops, double bytes) {
+void prof_end(hipStream_t s, double flops, double bytes, int kind) {
   if (!g_prof.on || g_prof.used >= g_prof.ev.size()) return;
   (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
+  if (g_prof.kind.size() <= g_prof.used) g_prof.kind.resize(g_prof.used + 1);
+  g_prof.kind[g_prof.used] = kind;
   g_prof.used++;
-  g_prof.flops += flops;
-  g_prof.bytes += bytes;
+  g_prof.flops[kind] += flops;
+  g_prof.bytes[kind] += bytes;
 }
 
 // ---------------------------------------------------------------- small helpers
@@ -279,19 +282,27 @@ int svt_debug_set(int key, int value) {
 }
 
 int svt_prof_enable(int on) { g_prof.on = on != 0; return SVT_OK; }
-int svt_prof_reset(void) { g_prof.used = 0; g_prof.flops = 0; g_prof.bytes = 0; return SVT_OK; }
-int svt_prof_read(int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
+int svt_prof_reset(void) {
+  g_prof.used = 0;
+  for (int k = 0; k < 3; ++k) g_prof.flops[k] = g_prof.bytes[k] = 0;
+  return SVT_OK;
+}
+int svt_prof_read(int kind, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
+  if (kind < 0 || kind > 2) { set_error("svt_prof_read: kind must be 0..2"); return SVT_ERR_INVALID; }
   double ms = 0;
+  int64_t n = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
+    if (g_prof.kind[i] != kind) continue;
     SVT_HIP(hipEventSynchronize(g_prof.ev[i].second));
     float t = 0;
     SVT_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
     ms += t;
+    ++n;
   }
-  if (launches) *launches = (int64_t)g_prof.used;
+  if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = g_prof.flops;
-  if (total_bytes) *total_bytes = g_prof.bytes;
+  if (total_flops) *total_flops = g_prof.flops[kind];
+  if (total_bytes) *total_bytes = g_prof.bytes[kind];
   return SVT_OK;
 }
 
@@ -734,8 +745,8 @@ int svt_linear_forward(svt_linear* l, const float* x, int64_t rows, float* y, vo
   hipStream_t s = (hipStream_t)stream;
   SVT_HIP(hipSetDevice(l->device));
   const float* b = l->has_bias ? l->b.as<float>() : nullptr;
-  if (l->out_f <= 32) return launch_linear_f32(x, rows, l->in_f, l->w.as<float>(), b, l->out_f, y, s);
-  if (l->in_f % 4) { set_error("svt_linear_forward: in_features must be a multiple of 4 for out_features > 32"); return SVT_ERR_INVALID; }
+  if (l->in_f % 4) {
+    if (l->out_f <= 32) return launch_linear_f32(x, rows, l->in_f, l->w.as<float>(), b, l->out_f, y, s); set_error("svt_linear_forward: in_features must be a multiple of 4 for out_features > 32"); return SVT_ERR_INVALID; }
   if (rows > 2147483647LL) { set_error("svt_linear_forward: too many rows"); return SVT_ERR_INVALID; }
   GemmArgs g;
   g.A = x; g.W = l->w.p; g.C = y; g.bias = b;

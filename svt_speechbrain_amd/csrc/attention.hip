@@ -220,7 +220,7 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
     hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)Vt, Tp, (bf16_t*)O, ldo, o_bstride, T, H, c);
   else { set_error("flash_attention: head_dim must be 64 or 128"); return -1; }
-  prof_end(s, flops, 0.0);
+  prof_end(s, flops, 0.0, 2);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -32,7 +32,7 @@ template <> struct OpTraits<bf16_t> {
   static constexpr int BK = 64;
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_fast(x); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_GELU) return gelu_erf(v);

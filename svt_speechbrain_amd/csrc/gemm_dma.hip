@@ -18,21 +18,7 @@
 namespace svt {
 namespace {
 
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level):
-// one v_rcp + one v_exp + 8 FMAs instead of libm erff's ~40 instructions; the epilogue of the conv / FFN
-// GEMMs evaluates it 1.6e9 times per step.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
-  const float erf_abs = fmaf(-poly * t, e, 1.0f);
-  const float half_x = 0.5f * x;
-  return fmaf(half_x, copysignf(erf_abs, x), half_x);
-}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_fast(x); }
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_GELU) return gelu_erf(v);
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -594,7 +580,7 @@ int launch_uring(const GemmArgs& a, hipStream_t s) {
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   prof_begin(s);
   hipLaunchKernelGGL((gemm_uring_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
-  prof_end(s, flops, bytes);
+  prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -6,7 +6,7 @@
 namespace svt {
 namespace {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_fast(x); }
 
 template <typename V>
 __device__ __forceinline__ V wave_sum(V v) {
@@ -102,6 +102,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int64_t row
     if (gelu) v = gelu_erf(v);
     if (yT) st<TO>(yT, row * D + i, v);
     if (yF) yF[row * D + i] = v;
+  }
+}
+
+// Register-resident variant for D = 64*VPT (512 / 768 / 1024): the row is read ONCE with 16-byte loads
+// (fp32 in) and kept in VPT registers per lane; statistics by two in-register passes + wave shuffles.
+template <int VPT, typename TO>
+__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* x, int64_t rows, const float* gamma,
+                                                                const float* beta, float eps, int gelu, TO* yT,
+                                                                float* yF) {
+  constexpr int D = 64 * VPT, NV = VPT / 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + row * D);
+  float v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float4 t = xr[lane + 64 * j];
+    v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    float o0 = fmaf(v[4 * j] * rstd, g.x, b.x), o1 = fmaf(v[4 * j + 1] * rstd, g.y, b.y);
+    float o2 = fmaf(v[4 * j + 2] * rstd, g.z, b.z), o3 = fmaf(v[4 * j + 3] * rstd, g.w, b.w);
+    if (gelu) { o0 = gelu_erf(o0); o1 = gelu_erf(o1); o2 = gelu_erf(o2); o3 = gelu_erf(o3); }
+    if (yT) {
+      if constexpr (sizeof(TO) == 2) {
+        bf16x4 o;
+        o[0] = (bf16_t)o0; o[1] = (bf16_t)o1; o[2] = (bf16_t)o2; o[3] = (bf16_t)o3;
+        *(bf16x4*)((bf16_t*)yT + row * D + c) = o;
+      } else {
+        *(float4*)((float*)yT + row * D + c) = float4{o0, o1, o2, o3};
+      }
+    }
+    if (yF) *(float4*)(yF + row * D + c) = float4{o0, o1, o2, o3};
   }
 }
 
@@ -554,7 +598,7 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
 }
 
 int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s) {
-  hipLaunchKernelGGL(moments_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, x, n, moments);
+  hipLaunchKernelGGL(moments_kernel, dim3(grid_for(n / 4 + 1, 256, 512)), dim3(256), 0, s, x, n, moments);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -568,6 +612,24 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (x_is_f32 && (D == 512 || D == 768 || D == 1024) && !((uintptr_t)x & 15) && !((uintptr_t)yT & 15) &&
+      !((uintptr_t)yF & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15)) {
+#define SVT_LN_VEC(VPT)                                                                                          \
+  do {                                                                                                           \
+    if (prec)                                                                                                    \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, bf16_t>), grid, block, 0, s, (const float*)x, rows,      \
+                         gamma, beta, eps, gelu, (bf16_t*)yT, yF);                                               \
+    else                                                                                                         \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, float>), grid, block, 0, s, (const float*)x, rows, gamma, \
+                         beta, eps, gelu, (float*)yT, yF);                                                       \
+  } while (0)
+    if (D == 512) SVT_LN_VEC(8);
+    else if (D == 768) SVT_LN_VEC(12);
+    else SVT_LN_VEC(16);
+#undef SVT_LN_VEC
+    SVT_LAUNCH_CHECK();
+    return 0;
+  }
   if (!prec) {
     hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, rows, D, gamma, beta, eps,
                        gelu, (float*)yT, yF);

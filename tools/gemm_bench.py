@@ -19,6 +19,8 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("ffn1", 15968, 3072, 768, None, 1, 0, 0),
     ("ffn2", 15968, 768, 3072, None, 0, 1, 1),
     ("large_ffn1", 31936, 4096, 1024, None, 1, 0, 0),
+    ("sq4096", 4096, 4096, 4096, None, 0, 0, 0),
+    ("sq8192", 8192, 8192, 8192, None, 0, 0, 0),
 ]
 
 
