@@ -262,14 +262,14 @@ int svt_device_count(void) {
 }
 
 int svt_debug_gemm(int32_t precision, const void* a, const void* w, void* c, const float* bias, const float* resid,
-                   int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int32_t act,
-                   int32_t out_f32, int device, void* stream) {
+                   int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int64_t ldw,
+                   int32_t act, int32_t out_f32, int device, void* stream) {
   if (!a || !w || !c) { set_error("svt_debug_gemm: null argument"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(device));
   GemmArgs g;
   g.A = a; g.W = w; g.C = c; g.bias = bias; g.resid = resid;
   g.M = m; g.N = n; g.K = k; g.a_rpb = a_rpb; g.a_bstride = a_bstride; g.a_rstride = a_rstride;
-  g.ldw = k; g.ldc = n; g.act = act; g.out_f32 = out_f32;
+  g.ldw = ldw; g.ldc = n; g.act = act; g.out_f32 = out_f32;
   return launch_gemm(precision, g, (hipStream_t)stream) ? SVT_ERR_INVALID : SVT_OK;
 }
 

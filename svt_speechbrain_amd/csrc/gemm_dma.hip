@@ -424,7 +424,10 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
   const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
   const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
 
-  const int r8 = lane & 7, ch = lane >> 3;
+  // coalesced + swizzled DMA source: 8 consecutive lanes fetch the 8 chunks of ONE 128-byte row (one line request
+  // instead of eight), lane (row r8 = l>>3, slot = l&7) takes chunk (slot ^ r8); the LDS image of a group is then
+  // row-major [row][slot] and the MFMA read of (row, chunk C) goes to slot C ^ row -> conflict-free ds_read_b128.
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
   const bf16_t* asrc[GA];
   const bf16_t* wsrc[GW];
 #pragma unroll
@@ -460,9 +463,12 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
     for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int cq = lane >> 4, r16 = lane & 15;
-  const int frag = (r16 >> 3) * 64 + cq * 8 + (r16 & 7);  // + group*64 + ks*32
-  const int xoff = (wm * (MB * 2)) * 64 + frag;
-  const int woff = (wn * 8) * 64 + frag;
+  // uint4 index inside a slot of fragment (16-row block blk, k-step ks): group (2*blk + (r16>>3)) * 64 + row*8 + slot
+  const int rr8 = r16 & 7;
+  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
+  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
+  const int xoff = (wm * (MB * 2)) * 64;
+  const int woff = (wn * 8) * 64;
 
   const int nk = p.K / BK;
   issue_a(0, 0);
@@ -484,9 +490,9 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 wf[4], xf[MB];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + ks * 32]);
+        for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + ks * 32]);
+        for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

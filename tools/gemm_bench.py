@@ -24,7 +24,7 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
 ]
 
 
-def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters):
+def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0):
     lib = _lib.load()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if prec else torch.float32
@@ -35,9 +35,10 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters):
         A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(dev, dt)
         rpb, bstr, rstr = T_out, T_in * cin, st * cin
     else:
-        A = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, dt)
-        rpb, bstr, rstr = M, 0, K
-    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
+        A = (torch.rand(M, K + pad, generator=g) * 2 - 1).to(dev, dt)
+        rpb, bstr, rstr = M, 0, K + pad
+    W = ((torch.rand(N, K + (0 if conv else pad), generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
+    ldw = W.shape[1]
     bias = torch.randn(N, generator=g).to(dev)
     R = torch.randn(M, N, generator=g).to(dev) if resid else None
     C = torch.empty(M, N, device=dev, dtype=torch.float32 if (out_f32 or not prec) else dt)
@@ -45,7 +46,7 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters):
 
     def call():
         _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(),
-                                      R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, act, out_f32, 0, st_),
+                                      R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, ldw, act, out_f32, 0, st_),
                    "svt_debug_gemm")
 
     call()
@@ -57,11 +58,11 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters):
             k = K // cin
             idx = (torch.arange(T_out, device=dev) * st)[:, None] + torch.arange(k, device=dev)[None, :]
             A2 = A[:2, idx].reshape(2 * T_out, K).float()
-            ref = A2 @ W.float().t() + bias
+            ref = A2 @ W[:, :K].float().t() + bias
             got = C[: 2 * T_out].float()
         else:
             rows = min(M, 4096)
-            ref = A[:rows].float() @ W.float().t() + bias
+            ref = A[:rows, :K].float() @ W[:, :K].float().t() + bias
             got = C[:rows].float()
         if act == 1:
             ref = torch.nn.functional.gelu(ref)
@@ -88,7 +89,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=1)
+    ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
     _lib.load().svt_debug_set(1, a.bm)
@@ -96,4 +98,4 @@ if __name__ == "__main__":
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
-        run(*s, a.prec, a.check, a.iters)
+        run(*s, a.prec, a.check, a.iters, a.pad)
