@@ -52,33 +52,28 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
-  // staging maps
+  // staging maps.  Global side: 8 (DH=64) / 16 (DH=128) consecutive lanes fetch the consecutive 16-byte chunks of ONE
+  // row, so the texture addresser issues one request per 128-byte line (a lane-per-row mapping costs one request
+  // per lane).  K tile in LDS: row-major [key][slot], slot = chunk ^ g(key) (g = (key>>1)&7 for 128-byte rows,
+  // key&15 for 256-byte rows) -> the 32x32x16 A-operand read (32 keys x one chunk) is a conflict-free ds_read_b128.
   const bf16_t* ksrc[KP];
-  int kdst[KP];
+  int kdst[KP], kkey[KP];
 #pragma unroll
   for (int i = 0; i < KP; ++i) {
     const int f = i * 256 + tid;
-    const int r8 = f & 7, cc = (f >> 3) % CPR, rg = f / (8 * CPR);
-    const int kk = rg * 8 + r8;  // key in tile
-    const int d0 = cc * 8;
-    ksrc[i] = Kb + d0;           // + key * ldk at load time (clamped)
-    kdst[i] = ((kk >> 5) * KSD + (d0 >> 4)) * 64 + (kk & 31) + 32 * ((d0 & 15) >> 3);
-    (void)ksrc[i];
-  }
-  int kkey[KP];
-#pragma unroll
-  for (int i = 0; i < KP; ++i) {
-    const int f = i * 256 + tid;
-    kkey[i] = (f / (8 * CPR)) * 8 + (f & 7);
+    const int cc = f % CPR, kk = f / CPR;  // chunk, key in tile
+    ksrc[i] = Kb + cc * 8;                 // + key * ldk at load time (clamped)
+    kkey[i] = kk;
+    const int g = (DH == 64) ? ((kk >> 1) & 7) : (kk & 15);
+    kdst[i] = kk * CPR + (cc ^ g);
   }
   const bf16_t* vsrc[VP];
   int vdst[VP];
 #pragma unroll
   for (int i = 0; i < VP; ++i) {
     const int f = i * 256 + tid;
-    const int r8 = f & 7, cc = (f >> 3) & 7, rg = f >> 6;
-    const int d = rg * 8 + r8;
-    const int k0 = cc * 8;  // key offset in tile
+    const int cc = f & 7, d = f >> 3;      // 16-byte chunk (8 keys) of V^T row d
+    const int k0 = cc * 8;                 // key offset in tile
     vsrc[i] = Vb + (long)d * Tp + k0;
     // two 8-byte runs: keys k0..k0+3 -> lane half 0, k0+4..k0+7 -> lane half 1; jh = (k0 % 16) / 8
     vdst[i] = (((d >> 5) * 4 + (k0 >> 4)) * 64 + (d & 31)) * 2 + ((k0 & 15) >> 3);  // in 8-byte units
@@ -114,6 +109,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m = -1e30f, l = 0.f;
   const int hh = lane >> 5;
+  const int kl = lane & 31;                                     // key within a 32-key block
+  const int kg = (DH == 64) ? ((kl >> 1) & 7) : (kl & 15);      // its swizzle (same for both key blocks: 32 % 16 == 0)
   const int ntiles = (T + 63) / 64;
 
   stage_load(0);
@@ -130,8 +127,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KSD; ++ks)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kf[(kb * KSD + ks) * 64 + lane]),
-                                                        qf[ks], s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb], 0, 0, 0);
     }
     // scaled log2 domain; mask keys >= T (only the last tile can have them)
     const int kbase = tile * 64 + 4 * hh;
