@@ -14,6 +14,7 @@
 //     lane ends up with 16 consecutive output columns (see gemm.hip) -> 16-byte epilogue stores.
 // BM in {128, 192, 256} is picked per problem to minimise idle CUs in the last round of tiles.
 #include "common.h"
+#include <utility>
 
 namespace svt {
 namespace {
@@ -394,6 +395,110 @@ int launch_ring(const GemmArgs& a, hipStream_t s) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Coalesced epilogue.  After the MFMA loop a lane holds, per 16-row block, 16 consecutive columns of ONE row
+// (lane & 15 = row): storing straight from registers makes every lane of a wave-instruction touch a different
+// 128-byte line (one texture-addresser request per lane; measured 10-27 us per tile, ~45 % of the kernel).
+// Instead each wave transposes its 16 x 64 block through a private LDS patch (row pitch 272 B: conflict-free both
+// ways) and stores row-contiguous: 16 (fp32) / 8 (bf16) consecutive lanes cover whole 128-byte lines.  Bias,
+// activation and the fp32 residual are applied on the read-back side with the same coalesced addressing.
+template <int MB, int BM, bool OUT32>
+__device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a0, const f32x4& a1, const f32x4& a2,
+                                               const f32x4& a3, int mb, float* patch, int lane, int wm, int wn, int m0,
+                                               int n0, long coff, const float* bias) {
+  constexpr int PITCH = 68;  // floats
+  const int m16 = lane & 15, q = lane >> 4;
+  constexpr bool out32 = OUT32;
+  {
+    const f32x4 accs[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      f32x4 v = accs[nb];
+      v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+      *(f32x4*)(patch + m16 * PITCH + q * 16 + nb * 4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int mbase = m0 + wm * (BM / 2) + mb * 16;
+    if (out32) {
+      const int c4 = (lane & 15) * 4;
+      const int n = n0 + wn * 64 + c4;
+      float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
+      if (bias && n < p.N) b4 = *(const float4*)(bias + n);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 4 + (lane >> 4);
+        const int m = mbase + r;
+        float4 v = *(const float4*)(patch + r * PITCH + c4);
+        if (m < p.M && n < p.N) {
+          v.x = apply_act(v.x + b4.x, p.act); v.y = apply_act(v.y + b4.y, p.act);
+          v.z = apply_act(v.z + b4.z, p.act); v.w = apply_act(v.w + b4.w, p.act);
+          const long idx = coff + (long)m * p.ldc + n;
+          if (p.resid) {
+            const float4 r4 = *(const float4*)(p.resid + idx);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          *(float4*)((float*)p.C + idx) = v;
+        }
+      }
+    } else {
+      const int c8 = (lane & 7) * 8;
+      const int n = n0 + wn * 64 + c8;
+      float bb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bb[j] = 0.f;
+      if (bias && n < p.N) {
+        const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 8 + (lane >> 3);
+        const int m = mbase + r;
+        const float4 v0 = *(const float4*)(patch + r * PITCH + c8), v1 = *(const float4*)(patch + r * PITCH + c8 + 4);
+        if (m < p.M && n < p.N) {
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const long idx = coff + (long)m * p.ldc + n;
+          if (p.resid) {
+            const float4 r0 = *(const float4*)(p.resid + idx), r1 = *(const float4*)(p.resid + idx + 4);
+            const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bb[j], p.act) + rr[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bb[j], p.act);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+          *(bf16x8*)((bf16_t*)p.C + idx) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int MB, int BM, bool OUT32, int... I>
+__device__ __forceinline__ void epilogue_seq(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[4][MB],
+                                             float* patch, int lane, int wm, int wn, int m0, int n0, long coff,
+                                             const float* bias) {
+  // fold over compile-time block indices: every acc[][] index is static (a runtime-indexed accumulator array
+  // would be demoted to scratch)
+  (epilogue_block<MB, BM, OUT32>(p, acc[0][I], acc[1][I], acc[2][I], acc[3][I], I, patch, lane, wm, wn, m0, n0, coff, bias),
+   ...);
+}
+
+template <int MB, int BM>
+__device__ __forceinline__ void epilogue_coalesced(const GemmArgs& p, f32x4 (&acc)[4][MB], float* patch, int lane, int wm,
+                                                   int wn, int m0, int n0, long coff, const float* bias) {
+  if (p.out_f32)
+    epilogue_seq<MB, BM, true>(std::make_integer_sequence<int, MB>{}, p, acc, patch, lane, wm, wn, m0, n0, coff, bias);
+  else
+    epilogue_seq<MB, BM, false>(std::make_integer_sequence<int, MB>{}, p, acc, patch, lane, wm, wn, m0, n0, coff, bias);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Unit-ring variant: the LDS is a ring of 5 slots of 32 KiB; units alternate A-slab / W-slab of the
 // same 64-deep K step (A_0 W_0 A_1 W_1 ...), each filled by full-line LDS-DMA (8 rows x 128 B per
 // wave-instruction).  While slab j is multiplied, units A_{j+1}, W_{j+1}, A_{j+2} are in flight; a
@@ -470,7 +575,7 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
   const int xoff = (wm * (MB * 2)) * 64;
   const int woff = (wn * 8) * 64;
 
-  const int nk = p.K / BK;
+  const int nk = p.dbg == 4 ? 1 : p.K / BK;
   issue_a(0, 0);
   issue_w(0, 1);
   if (nk > 1) issue_a(1, 2);
@@ -478,26 +583,29 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    // units 2kt+3 (W of slab kt+1) and 2kt+4 (A of slab kt+2) go to the two slots freed by slab kt-1
-    if (p.dbg != 1) {
-      if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
-      if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
-    }
+    // units 2kt+3 (W of slab kt+1) and 2kt+4 (A of slab kt+2) go to the two slots freed by slab kt-1; the W unit is
+    // issued before the first k-step's LDS reads, the A unit before the second's (spreads the VMEM issue).
     const uint4* xa = lds + sa * SLOT + xoff;
     const uint4* wa = lds + sw * SLOT + woff;
-    if (p.dbg != 2) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
+      if (p.dbg != 1) {
+        if (ks == 0) { if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT); }
+        else { if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT); }
+      }
+      if (p.dbg != 2) {
         bf16x8 wf[4], xf[MB];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
             acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     sa = (sa + 2) % NSLOT;
@@ -506,68 +614,159 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
   // ---- epilogue ----
   const long coff = z1 * p.c_z1 + z2 * p.c_z2;
   const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
-  if (nbase >= p.N) return;
-  const bool full = (nbase + 16 <= p.N) && p.c_vec;
-  float bv[16];
+  __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
+  if (p.dbg != 3)
+    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
+  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
+}
+
+
+template <int BM>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
+  constexpr int BN = 256, BK = 64, NSLOT = 5;
+  constexpr int MB = BM / 32;
+  constexpr int GA = BM / 64;       // DMA instructions per wave per A unit (BM/8 groups over 8 waves)
+  constexpr int GW = BN / 64;       // per W unit
+  constexpr int SLOT = 2048;        // uint4 per slot (32 KiB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
+  const int z = blockIdx.y;
+  const int z1 = z / p.nz2, z2 = z % p.nz2;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
+  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
+
+  // coalesced + swizzled DMA source: 8 consecutive lanes fetch the 8 chunks of ONE 128-byte row (one line request
+  // instead of eight), lane (row r8 = l>>3, slot = l&7) takes chunk (slot ^ r8); the LDS image of a group is then
+  // row-major [row][slot] and the MFMA read of (row, chunk C) goes to slot C ^ row -> conflict-free ds_read_b128.
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
+  const bf16_t* asrc[GA];
+  const bf16_t* wsrc[GW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-  if (bias) {
-    if (full) {
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const float4 b4 = *(const float4*)(bias + nbase + j4 * 4);
-        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) if (nbase + j < p.N) bv[j] = bias[nbase + j];
-    }
+  for (int i = 0; i < GA; ++i) {
+    int m = m0 + (wave + 8 * i) * 8 + r8;
+    if (m > p.M - 1) m = p.M - 1;
+    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
   }
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = m0 + wm * (BM / 2) + mb * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nb * 4 + r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
-    const long idx = coff + (long)m * p.ldc + nbase;
-    if (full) {
-      if (p.resid) {
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 r4 = *(const float4*)(p.resid + idx + j4 * 4);
-          v[j4 * 4 + 0] += r4.x; v[j4 * 4 + 1] += r4.y; v[j4 * 4 + 2] += r4.z; v[j4 * 4 + 3] += r4.w;
-        }
-      }
-      if (p.out_f32) {
-        float* c = (float*)p.C + idx;
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4)
-          *(float4*)(c + j4 * 4) = float4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
-      } else {
-        bf16_t* c = (bf16_t*)p.C + idx;
-#pragma unroll
-        for (int j8 = 0; j8 < 2; ++j8) {
-          bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j8 * 8 + j];
-          *(bf16x8*)(c + j8 * 8) = o;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (nbase + j >= p.N) continue;
-        float o = v[j];
-        if (p.resid) o += p.resid[idx + j];
-        if (p.out_f32) ((float*)p.C)[idx + j] = o;
-        else ((bf16_t*)p.C)[idx + j] = (bf16_t)o;
-      }
-    }
+  for (int i = 0; i < GW; ++i) {
+    const int rho = (wave + 8 * i) * 8 + r8;
+    const int i16 = rho & 15;
+    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+    if (n > p.N - 1) n = p.N - 1;
+    wsrc[i] = W + (long)n * p.ldw + ch * 8;
   }
+  // unit u: even -> A slab u/2, odd -> W slab u/2; slot u % 5
+  auto issue_a = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+
+  f32x4 acc[4][MB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cq = lane >> 4, r16 = lane & 15;
+  // uint4 index inside a slot of fragment (16-row block blk, k-step ks): group (2*blk + (r16>>3)) * 64 + row*8 + slot
+  const int rr8 = r16 & 7;
+  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
+  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
+  const int xoff = (wm * (MB * 2)) * 64;
+  const int woff = (wn * 8) * 64;
+
+  const int nk = p.K / BK;
+  const int grp = wave >> 2;  // waves w and w+4 share a SIMD: group 0 multiplies while group 1 reads LDS and vice versa
+  bf16x8 wf[4], xf[MB];
+  auto R = [&](const uint4* xa, const uint4* wa, int fr) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + fr]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + fr]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto M = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  issue_a(0, 0);
+  issue_w(0, 1);
+  if (nk > 1) issue_a(1, 2);
+  int sa = 0, sw = 1;
+  // Two straight-line loops (one per wave group) with the SAME barrier count: group 0 runs R M R M per slab,
+  // group 1 runs M R M R (its first M is skipped, its last M runs after the loop), so on every SIMD one wave
+  // multiplies while its partner reads LDS.
+  if (grp == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();  // slab kt landed for everyone; group 1 finished reading slab kt-1
+      if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
+      if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
+      const uint4* xa = lds + sa * SLOT + xoff;
+      const uint4* wa = lds + sw * SLOT + woff;
+      R(xa, wa, frag0);
+      __builtin_amdgcn_s_barrier();
+      M();
+      __builtin_amdgcn_s_barrier();
+      R(xa, wa, frag1);
+      __builtin_amdgcn_s_barrier();
+      M();
+      sa = (sa + 2) % NSLOT;
+      sw = (sw + 2) % NSLOT;
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
+      if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
+      const uint4* xa = lds + sa * SLOT + xoff;
+      const uint4* wa = lds + sw * SLOT + woff;
+      if (kt > 0) M();
+      __builtin_amdgcn_s_barrier();
+      R(xa, wa, frag0);
+      __builtin_amdgcn_s_barrier();
+      M();
+      __builtin_amdgcn_s_barrier();
+      R(xa, wa, frag1);
+      sa = (sa + 2) % NSLOT;
+      sw = (sw + 2) % NSLOT;
+    }
+    M();
+  }
+
+  // ---- epilogue ----
+  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
+  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
+  __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
+  if (p.dbg != 3)
+    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
+  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
 }
 
 
@@ -586,6 +785,26 @@ int launch_uring(const GemmArgs& a, hipStream_t s) {
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   prof_begin(s);
   hipLaunchKernelGGL((gemm_uring_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
+  prof_end(s, flops, bytes, 0);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BM>
+int launch_pp(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  dim3 grid(tiles_m * tiles_n, a.nz, 1);
+  const size_t lds_bytes = 5 * 32768;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+    attr_set = true;
+  }
+  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
+  prof_begin(s);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -613,7 +832,7 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128; }
+bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128 && a.c_vec && a.N % 8 == 0; }
 
 // pick BM to minimise (rounds of 256 CUs) x (rows per tile); ties -> larger tile (higher intensity)
 int g_gemm_dbg = 0;
@@ -634,6 +853,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
   }
   if (g_gemm_force_bm) best = g_gemm_force_bm;
+  if (g_gemm_ring == 3) {
+    if (best == 256) return launch_pp<256>(a, s);
+    if (best == 192) return launch_pp<192>(a, s);
+    return launch_pp<128>(a, s);
+  }
   if (g_gemm_ring == 2) {
     if (best == 256) return launch_uring<256>(a, s);
     if (best == 192) return launch_uring<192>(a, s);
