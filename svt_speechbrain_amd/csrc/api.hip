@@ -659,6 +659,10 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     return launch_gemm(prec, g, s);
   };
   float* final_x = nullptr;
+  // The residual add lives in the LayerNorm kernel (LN(x + branch)), not in the GEMM epilogue: the GEMM epilogue
+  // is then store-only (fire-and-forget under the next tile's MFMAs in the persistent kernel).  tmp = w.hF is free
+  // after the positional conv.
+  float* tmp = w.hF;
   if (!c.stable_layer_norm) {
     if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.xb,
                                  prec ? w.xF : nullptr, s)) return r;
@@ -666,30 +670,36 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
       const EncLayerW& Lw = e->layers[l];
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
       if (int r = attention()) return r;
-      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, w.preF, 1, ACT_NONE, w.xF)) return r;
-      if (int r = launch_layernorm(prec, w.preF, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
-                                   prec ? w.xF : nullptr, s)) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
+                                   prec ? w.xF : nullptr, s, w.xF)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
-      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, w.preF, 1, ACT_NONE, w.xF)) return r;
-      if (int r = launch_layernorm(prec, w.preF, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb,
-                                   prec ? w.xF : nullptr, s)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb,
+                                   prec ? w.xF : nullptr, s, w.xF)) return r;
     }
     final_x = w.xF;
   } else {
     float* h = w.preF;
+    const float* pending = nullptr;  // branch output not yet added to h
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
-      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb, nullptr, s)) return r;
+      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb, nullptr, s,
+                                   pending, pending ? h : nullptr)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
       if (int r = attention()) return r;
-      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, h, 1, ACT_NONE, h)) return r;
-      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb, nullptr, s)) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb, nullptr, s,
+                                   tmp, h)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
-      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, h, 1, ACT_NONE, h)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      pending = tmp;
     }
-    // final LN -> fp32 (hF is free by now)
-    if (int r = launch_layernorm(0, h, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.hF, nullptr, s)) return r;
-    final_x = w.hF;
+    // final LN(h + last FFN branch) -> fp32 (xF is unused in this family when prec == 0 it aliases xb: use qkv space)
+    float* fin = (float*)w.qkv;
+    if (int r = launch_layernorm(0, h, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, fin, nullptr, s,
+                                 pending, nullptr)) return r;
+    final_x = fin;
   }
   // ---- wrapper's whole-batch output LayerNorm ----
   const int64_t n_out = rows * D;
@@ -930,12 +940,12 @@ int svt_rca_forward(svt_rca* r, const float* audio, int32_t T1, const float* vid
     if (int rc = attention_scores_path(prec, w.qc, D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, true, w.att_c, D, s)) return rc;
     // out_proj is linear: alpha*Wo(a_s) + (1-alpha)*Wo(a_c) + bo = Wo(alpha*a_s + (1-alpha)*a_c) + bo
     if (int rc = launch_axpby(prec, w.att_s, w.att_c, r->alpha, 1.f - r->alpha, w.blend, rows * D, s)) return rc;
-    if (int rc = gemm_rows(w.blend, D, L.wo.p, L.bo.as<float>(), D, w.preF, 1, ACT_NONE, kvF)) return rc;
+    if (int rc = gemm_rows(w.blend, D, L.wo.p, L.bo.as<float>(), D, w.preF, 1, ACT_NONE, nullptr)) return rc;
     if (int rc = launch_layernorm(prec, w.preF, 1, rows, D, L.n1g.as<float>(), L.n1b.as<float>(), 1e-6f, 0, w.xT,
-                                  prec ? w.xF : nullptr, s)) return rc;
+                                  prec ? w.xF : nullptr, s, kvF)) return rc;
     if (int rc = gemm_rows(w.xT, D, L.w1.p, L.b1.as<float>(), F, w.ffn, 0, ACT_RELU, nullptr)) return rc;
-    if (int rc = gemm_rows(w.ffn, F, L.w2.p, L.b2.as<float>(), D, w.preF, 1, ACT_NONE, w.xF)) return rc;
-    return launch_layernorm(0, w.preF, 1, rows, D, L.n2g.as<float>(), L.n2b.as<float>(), 1e-6f, 0, outF, nullptr, s);
+    if (int rc = gemm_rows(w.ffn, F, L.w2.p, L.b2.as<float>(), D, w.preF, 1, ACT_NONE, nullptr)) return rc;
+    return launch_layernorm(0, w.preF, 1, rows, D, L.n2g.as<float>(), L.n2b.as<float>(), 1e-6f, 0, outF, nullptr, s, w.xF);
   };
   if (int rc = layer(r->L[0], w.s1T, w.s1F, w.s2T, w.o1)) return rc;
   if (int rc = layer(r->L[1], w.s2T, w.s2F, w.s1T, w.o2)) return rc;

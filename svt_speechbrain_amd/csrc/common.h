@@ -87,8 +87,11 @@ int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s);
 int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s);
 
 // row LayerNorm over D: in fp32 or operand type; outputs: yT (operand type, may be null) and yF (fp32, may be null)
+// optional `add` (fp32, same shape) is summed into x before the statistics (residual add fused into the norm);
+// `sumF` (optional) receives x + add (the updated residual stream of the pre-LN encoder)
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
-                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s);
+                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s,
+                     const float* add = nullptr, float* sumF = nullptr);
 
 // conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
 int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,

@@ -770,6 +770,226 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant of the unit-ring kernel.  One workgroup per CU walks a list of output tiles; the
+// (tile, k-slab) pairs form ONE stream for the LDS-DMA ring, so the first slabs of tile i+1 are already
+// in flight while tile i runs its epilogue, and the epilogue's global stores (fire-and-forget) drain
+// while the next tile multiplies.  Without this every CU of a single-round launch reaches its epilogue
+// at the same moment and the 50-100 MB store burst is pure serial time (measured: 40 % of out_proj).
+// The epilogue uses buffer stores with hardware bounds checking (rows >= M are dropped by the memory
+// pipeline, never by a branch), so the number of VMEM operations a wave has in flight after an epilogue
+// is a compile-time constant and the counted s_waitcnt vmcnt of the ring stays exact.
+template <int BM>
+__global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n, int ntiles) {
+  constexpr int BN = 256, BK = 64, NSLOT = 5;
+  constexpr int MB = BM / 32;
+  constexpr int GA = BM / 64;
+  constexpr int GW = BN / 64;
+  constexpr int SLOT = 2048;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nblk = gridDim.x, b = blockIdx.x;
+  // blocks b and b+8 share an XCD: in every round an XCD works on nblk/8 consecutive logical tiles (n fastest)
+  const int per = nblk >> 3;
+  const int lbase = (b & 7) * per + (b >> 3);
+  int my_tiles = 0;
+  while (my_tiles * nblk + lbase < ntiles) ++my_tiles;
+  if (my_tiles == 0) return;
+
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* W = (const bf16_t*)p.W;
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
+
+  const bf16_t* asrc[GA];
+  const bf16_t* wsrc[GW];
+  const bf16_t* asrc2[GA];
+  const bf16_t* wsrc2[GW];
+  auto setup = [&](int logical, const bf16_t* (&as)[GA], const bf16_t* (&ws)[GW]) {
+    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      int m = m0 + (wave + 8 * i) * 8 + r8;
+      if (m > p.M - 1) m = p.M - 1;
+      as[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+      const int rho = (wave + 8 * i) * 8 + r8;
+      const int i16 = rho & 15;
+      int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+      if (n > p.N - 1) n = p.N - 1;
+      ws[i] = W + (long)n * p.ldw + ch * 8;
+    }
+  };
+  auto issue_a = [&](const bf16_t* const (&as)[GA], int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(as[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+  auto issue_w = [&](const bf16_t* const (&ws)[GW], int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+
+  f32x4 acc[4][MB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
+  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + (cq ^ rr8);
+  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);
+  const int xoff = (wm * (MB * 2)) * 64;
+  const int woff = (wn * 8) * 64;
+
+  const int nk = p.K / BK;            // >= 2 (checked by the launcher)
+  const int G = my_tiles * nk;        // slabs in this workgroup's stream
+  int ti = 0;                         // index of the tile being multiplied
+  setup(lbase, asrc, wsrc);
+  if (my_tiles > 1) setup(nblk + lbase, asrc2, wsrc2);
+  issue_a(asrc, 0, 0);
+  issue_w(wsrc, 0, 1);
+  issue_a(asrc, 1, 2);
+  int sa = 0, sw = 1, kt = 0;
+  bool after_epilogue = false;
+  const int n_store = MB * (p.out_f32 ? 4 : 2);  // buffer stores per wave per epilogue
+  for (int g = 0; g < G; ++g) {
+    // retire slab g: allowed in flight = A unit of slab g+1 (+ the previous tile's epilogue stores, which are younger)
+    if (g + 1 < G) {
+      if (!after_epilogue) wait_vm<GA>();
+      else if (p.out_f32) wait_vm<GA + MB * 4>();
+      else wait_vm<GA + MB * 2>();
+    } else {
+      wait_vm<0>();
+    }
+    after_epilogue = false;
+    __builtin_amdgcn_s_barrier();
+    const uint4* xa = lds + sa * SLOT + xoff;
+    const uint4* wa = lds + sw * SLOT + woff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0) {
+        if (g + 1 < G) {  // W unit of slab g+1
+          if (kt + 1 < nk) issue_w(wsrc, kt + 1, (2 * g + 3) % NSLOT);
+          else issue_w(wsrc2, 0, (2 * g + 3) % NSLOT);
+        }
+      } else {
+        if (g + 2 < G) {  // A unit of slab g+2
+          if (kt + 2 < nk) issue_a(asrc, kt + 2, (2 * g + 4) % NSLOT);
+          else issue_a(asrc2, kt + 2 - nk, (2 * g + 4) % NSLOT);
+        }
+      }
+      bf16x8 wf[4], xf[MB];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sa = (sa + 2) % NSLOT;
+    sw = (sw + 2) % NSLOT;
+    if (++kt == nk) {
+      // ---- epilogue of tile ti (registers -> global, bounds-checked buffer stores) ----
+      kt = 0;
+      const int logical = ti * nblk + lbase;
+      const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+      const int m0 = tile_m * BM, n0 = tile_n * BN;
+      const int esz = p.out_f32 ? 4 : 2;
+      // descriptor over the rows [m0, M) of C (and of the residual): a row >= M lands beyond num_records
+      const long rows_left = (long)p.M - m0;
+      const unsigned long nbytes = (unsigned long)rows_left * p.ldc * esz;
+      const unsigned nrec = nbytes > 0xFFFFFFF0ul ? 0xFFFFFFF0u : (unsigned)nbytes;
+      char* cbase = (char*)p.C + (long)m0 * p.ldc * esz;
+      const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);
+      const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
+      float bv[16];
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *(const float4*)(p.bias + nbase + j4 * 4);
+        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
+      }
+      if (p.out_f32) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int ml = wm * (BM / 2) + mb * 16 + (lane & 15);
+          const unsigned off = (unsigned)(((long)ml * p.ldc + nbase) * 4);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), crsrc, off + nb * 16, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int ml = wm * (BM / 2) + mb * 16 + (lane & 15);
+          const unsigned off = (unsigned)(((long)ml * p.ldc + nbase) * 2);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int nbr = h * 8 + j;
+              o[j] = (bf16_t)apply_act(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr], p.act);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), crsrc, off + h * 16, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      after_epilogue = true;
+      ++ti;
+      // rotate the pointer sets: next tile becomes current, precompute the one after
+#pragma unroll
+      for (int i = 0; i < GA; ++i) asrc[i] = asrc2[i];
+#pragma unroll
+      for (int i = 0; i < GW; ++i) wsrc[i] = wsrc2[i];
+      if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, asrc2, wsrc2);
+    }
+  }
+  (void)n_store;
+}
+
+template <int BM>
+int launch_pers(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  const size_t lds_bytes = 5 * 32768;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pers_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+    attr_set = true;
+  }
+  const double flops = 2.0 * a.M * (double)a.N * a.K;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
+  prof_begin(s);
+  hipLaunchKernelGGL((gemm_pers_kernel<BM>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  prof_end(s, flops, bytes, 0);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int BM>
 int launch_uring(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
@@ -834,10 +1054,13 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
 
 bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128 && a.c_vec && a.N % 8 == 0; }
 
-// pick BM to minimise (rounds of 256 CUs) x (rows per tile); ties -> larger tile (higher intensity)
+// Dispatch.  Tile height BM minimises (rounds of 256 CUs) x BM; ties go to the larger tile (higher arithmetic
+// intensity against the L2->LDS fill rate).  Problems with at least two full rounds of tiles run the persistent
+// kernel (epilogue stores and the next tile's fills overlap the MFMAs); single-round problems run the
+// one-tile-per-workgroup kernel, whose LDS-transposed epilogue stores whole 128-byte lines.
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
-int g_gemm_ring = 2;
+int g_gemm_ring = 0;  // 0 = auto; 2 = unit-ring, 3 = ping-pong, 4 = persistent, 1 = k32 ring, 5 = legacy (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   a.dbg = g_gemm_dbg;
@@ -853,24 +1076,36 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
   }
   if (g_gemm_force_bm) best = g_gemm_force_bm;
-  if (g_gemm_ring == 3) {
+  const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
+  const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
+                       a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
+  int mode = g_gemm_ring;
+  if (mode == 0) mode = (pers_ok && ntiles >= 512) ? 4 : 2;
+  if (mode == 4 && pers_ok) {
+    if (best == 256) return launch_pers<256>(a, s);
+    if (best == 192) return launch_pers<192>(a, s);
+    if (best == 128) return launch_pers<128>(a, s);
+    return launch_pers<64>(a, s);
+  }
+  if (best == 64) best = 128;
+  if (mode == 3) {
     if (best == 256) return launch_pp<256>(a, s);
     if (best == 192) return launch_pp<192>(a, s);
     return launch_pp<128>(a, s);
   }
-  if (g_gemm_ring == 2) {
-    if (best == 256) return launch_uring<256>(a, s);
-    if (best == 192) return launch_uring<192>(a, s);
-    return launch_uring<128>(a, s);
-  }
-  if (g_gemm_ring) {
+  if (mode == 1) {
     if (best == 256) return launch_ring<256, 4>(a, s);
     if (best == 192) return launch_ring<192, 5>(a, s);
     return launch_ring<128, 6>(a, s);
   }
-  if (best == 256) return launch_dma<256>(a, s);
-  if (best == 192) return launch_dma<192>(a, s);
-  return launch_dma<128>(a, s);
+  if (mode == 5) {
+    if (best == 256) return launch_dma<256>(a, s);
+    if (best == 192) return launch_dma<192>(a, s);
+    return launch_dma<128>(a, s);
+  }
+  if (best == 256) return launch_uring<256>(a, s);
+  if (best == 192) return launch_uring<192>(a, s);
+  return launch_uring<128>(a, s);
 }
 
 }  // namespace svt

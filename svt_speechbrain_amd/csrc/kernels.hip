@@ -85,20 +85,24 @@ __global__ void global_norm_kernel(const float* x, float* y, int64_t n, const do
 // Row LayerNorm: one wave per row, two-pass statistics from registers-free re-reads (rows <= 4 KB
 // stay in L1/L2).  Optional exact-erf GELU (conv "layer" mode).
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int64_t rows, int D, const float* gamma,
-                                                        const float* beta, float eps, int gelu, TO* yT, float* yF) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const float* add, float* sumF, int64_t rows, int D,
+                                                        const float* gamma, const float* beta, float eps, int gelu,
+                                                        TO* yT, float* yF) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const TI* xr = x + row * D;
+  const float* ar = add ? add + row * D : nullptr;
   float s = 0.f;
-  for (int i = lane; i < D; i += 64) s += ld<TI>(xr, i);
+  for (int i = lane; i < D; i += 64) s += ld<TI>(xr, i) + (ar ? ar[i] : 0.f);
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
-  for (int i = lane; i < D; i += 64) { const float d = ld<TI>(xr, i) - mean; q += d * d; }
+  for (int i = lane; i < D; i += 64) { const float d = ld<TI>(xr, i) + (ar ? ar[i] : 0.f) - mean; q += d * d; }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
   for (int i = lane; i < D; i += 64) {
-    float v = (ld<TI>(xr, i) - mean) * rstd * gamma[i] + beta[i];
+    const float xv = ld<TI>(xr, i) + (ar ? ar[i] : 0.f);
+    if (sumF) sumF[row * D + i] = xv;
+    float v = (xv - mean) * rstd * gamma[i] + beta[i];
     if (gelu) v = gelu_erf(v);
     if (yT) st<TO>(yT, row * D + i, v);
     if (yF) yF[row * D + i] = v;
@@ -108,9 +112,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, int64_t row
 // Register-resident variant for D = 64*VPT (512 / 768 / 1024): the row is read ONCE with 16-byte loads
 // (fp32 in) and kept in VPT registers per lane; statistics by two in-register passes + wave shuffles.
 template <int VPT, typename TO>
-__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* x, int64_t rows, const float* gamma,
-                                                                const float* beta, float eps, int gelu, TO* yT,
-                                                                float* yF) {
+__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* x, const float* add, float* sumF,
+                                                                int64_t rows, const float* gamma, const float* beta,
+                                                                float eps, int gelu, TO* yT, float* yF) {
   constexpr int D = 64 * VPT, NV = VPT / 4;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -120,7 +124,12 @@ __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* x, 
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const float4 t = xr[lane + 64 * j];
+    float4 t = xr[lane + 64 * j];
+    if (add) {
+      const float4 a = ((const float4*)(add + row * D))[lane + 64 * j];
+      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    }
+    if (sumF) ((float4*)(sumF + row * D))[lane + 64 * j] = t;
     v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
     s += (t.x + t.y) + (t.z + t.w);
   }
@@ -610,18 +619,21 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 }
 
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
-                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s) {
+                     const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s, const float* add,
+                     float* sumF) {
+  if (add && !x_is_f32) { set_error("layernorm: the addend form needs an fp32 input"); return -1; }
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (x_is_f32 && (D == 512 || D == 768 || D == 1024) && !((uintptr_t)x & 15) && !((uintptr_t)yT & 15) &&
-      !((uintptr_t)yF & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15)) {
+      !((uintptr_t)yF & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15) && !((uintptr_t)add & 15) &&
+      !((uintptr_t)sumF & 15)) {
 #define SVT_LN_VEC(VPT)                                                                                          \
   do {                                                                                                           \
     if (prec)                                                                                                    \
-      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, bf16_t>), grid, block, 0, s, (const float*)x, rows,      \
-                         gamma, beta, eps, gelu, (bf16_t*)yT, yF);                                               \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, bf16_t>), grid, block, 0, s, (const float*)x, add, sumF, \
+                         rows, gamma, beta, eps, gelu, (bf16_t*)yT, yF);                                         \
     else                                                                                                         \
-      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, float>), grid, block, 0, s, (const float*)x, rows, gamma, \
-                         beta, eps, gelu, (float*)yT, yF);                                                       \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, float>), grid, block, 0, s, (const float*)x, add, sumF,  \
+                         rows, gamma, beta, eps, gelu, (float*)yT, yF);                                          \
   } while (0)
     if (D == 512) SVT_LN_VEC(8);
     else if (D == 768) SVT_LN_VEC(12);
@@ -631,14 +643,14 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
     return 0;
   }
   if (!prec) {
-    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, rows, D, gamma, beta, eps,
-                       gelu, (float*)yT, yF);
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, add, sumF, rows, D, gamma,
+                       beta, eps, gelu, (float*)yT, yF);
   } else if (x_is_f32) {
-    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, rows, D, gamma, beta,
-                       eps, gelu, (bf16_t*)yT, yF);
+    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, add, sumF, rows, D, gamma,
+                       beta, eps, gelu, (bf16_t*)yT, yF);
   } else {
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, rows, D, gamma, beta,
-                       eps, gelu, (bf16_t*)yT, yF);
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, add, sumF, rows, D,
+                       gamma, beta, eps, gelu, (bf16_t*)yT, yF);
   }
   SVT_LAUNCH_CHECK();
   return 0;

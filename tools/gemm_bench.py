@@ -15,9 +15,9 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("conv5", 32 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, 0),
     ("proj", 15968, 768, 512, None, 0, 1, 0),
     ("qkv", 15968, 2304, 768, None, 0, 0, 0),
-    ("out_proj", 15968, 768, 768, None, 0, 1, 1),
+    ("out_proj", 15968, 768, 768, None, 0, 1, 0),
     ("ffn1", 15968, 3072, 768, None, 1, 0, 0),
-    ("ffn2", 15968, 768, 3072, None, 0, 1, 1),
+    ("ffn2", 15968, 768, 3072, None, 0, 1, 0),
     ("large_ffn1", 31936, 4096, 1024, None, 1, 0, 0),
     ("sq4096", 4096, 4096, 4096, None, 0, 0, 0),
     ("sq8192", 8192, 8192, 8192, None, 0, 0, 0),
@@ -89,7 +89,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
