@@ -121,8 +121,6 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    lib.svt_prof_reset()
-    lib.svt_prof_enable(1)
     D.barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -131,9 +129,18 @@ def main():
     torch.cuda.synchronize()
     D.barrier(world)
     elapsed = time.perf_counter() - t0
-    lib.svt_prof_enable(0)
     elapsed = D.max_over_ranks(elapsed, world, dev)
     assert out.shape[0] == n_total
+
+    # roofline leg: the SAME K steps again with a HIP-event pair around every launch of the dense-contraction kernels
+    # (on the stream they are launched on).  Kept out of the throughput timing above because 2 event records per
+    # launch x ~70 launches per step add ~5 % of GPU idle time.
+    lib.svt_prof_reset()
+    lib.svt_prof_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    lib.svt_prof_enable(0)
 
     def prof(kind):
         n, ms_, fl_, by_ = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
