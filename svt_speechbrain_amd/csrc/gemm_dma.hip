@@ -463,6 +463,13 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
             const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bb[j], p.act) + rr[j];
+          } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const f32x2_t g = gelu_fast2(f32x2_t{v[j] + bb[j], v[j + 1] + bb[j + 1]});
+              v[j] = g.x;
+              v[j + 1] = g.y;
+            }
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bb[j], p.act);
@@ -943,10 +950,21 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             bf16x8 o;
+            if (p.act == ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int nbr = h * 8 + j;
-              o[j] = (bf16_t)apply_act(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr], p.act);
+              for (int j = 0; j < 8; j += 2) {
+                const int n0r = h * 8 + j, n1r = n0r + 1;
+                const f32x2_t g = gelu_fast2(f32x2_t{acc[n0r >> 2][mb][n0r & 3] * p.alpha + bv[n0r],
+                                                     acc[n1r >> 2][mb][n1r & 3] * p.alpha + bv[n1r]});
+                o[j] = (bf16_t)g.x;
+                o[j + 1] = (bf16_t)g.y;
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int nbr = h * 8 + j;
+                o[j] = (bf16_t)apply_act(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr], p.act);
+              }
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), crsrc, off + h * 16, 0, 0);
           }

@@ -275,11 +275,13 @@ __global__ __launch_bounds__(256) void conv0_group_apply_kernel(const float* wav
     for (int j = 0; j < K0; ++j) xv[j] = xs[wave][f * stride + j];
     float o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float a = cf[i][K0];
+    for (int i = 0; i < 8; i += 2) {
+      f32x2_t a = {cf[i][K0], cf[i + 1][K0]};
 #pragma unroll
-      for (int j = 0; j < K0; ++j) a = fmaf(cf[i][j], xv[j], a);
-      o[i] = gelu_erf(a);
+      for (int j = 0; j < K0; ++j) a = f32x2_t{cf[i][j], cf[i + 1][j]} * xv[j] + a;
+      const f32x2_t g = gelu_fast2(a);
+      o[i] = g.x;
+      o[i + 1] = g.y;
     }
     TO* dst = out + ((int64_t)b * T1 + t0 + f) * C + c0;
     if constexpr (sizeof(TO) == 2) {
