@@ -153,11 +153,9 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
                                  long ldo, hipStream_t s) {
   if (use_flash(prec, dh)) {
-    const int Tp64 = round_up_int(T, 64);
-    if (!vt_ready)
-      if (int r = launch_transpose_v(prec, V, B, T, H, dh, ldkv, 0, Tp64, ab.Vt, s)) return r;
-    return launch_flash_attention(Q, ldq, (long)T * ldq, K, ldkv, (long)T * ldkv, ab.Vt, Tp64, out, ldo, (long)T * ldo,
-                                  B, T, H, dh, scale, s);
+    (void)vt_ready;
+    return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
+                                  scale, s);
   }
   const int Tp = round_up_int(T, 8);
   GemmArgs g;

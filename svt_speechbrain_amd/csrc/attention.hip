@@ -21,6 +21,10 @@ namespace svt {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 template <int DH>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
@@ -199,9 +203,205 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     }
 }
 
+template <int DH>
+__global__ __launch_bounds__(256) void flash_attn2_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
+                                                         const bf16_t* __restrict__ K, long ldk, long k_bstride,
+                                                         const bf16_t* __restrict__ V, int /*unused*/, bf16_t* __restrict__ O,
+                                                         long ldo, long o_bstride, int T, int H, float c) {
+  constexpr int KSD = DH / 16;   // k-steps over head_dim for S
+  constexpr int DB = DH / 32;    // 32-row blocks of O^T
+  constexpr int CPR = DH / 8;    // 16-byte chunks per K row
+  constexpr int KP = CPR / 4;    // K pieces per thread per tile (64 keys)
+  constexpr int RB = 2 * DH;     // bytes per K / V row in LDS
+  __shared__ __attribute__((aligned(16))) uint4 Kf[2 * KSD * 64];
+  __shared__ __attribute__((aligned(16))) uint4 Vs[64 * CPR];  // V tile, row-major [key][slot], slot = chunk ^ sw(key)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
+  const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
+  const bf16_t* Vb = V + (long)b * k_bstride + (long)h * DH;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + (lane&31)][ks*16 + 8*(lane>>5) .. +7]
+  bf16x8 qf[KSD];
+  {
+    int q = q0 + (lane & 31);
+    if (q > T - 1) q = T - 1;
+    const bf16_t* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // staging maps.  Global side: 8 (DH=64) / 16 (DH=128) consecutive lanes fetch the consecutive 16-byte chunks of ONE
+  // row, so the texture addresser issues one request per 128-byte line (a lane-per-row mapping costs one request
+  // per lane).  K tile in LDS: row-major [key][slot], slot = chunk ^ g(key) (g = (key>>1)&7 for 128-byte rows,
+  // key&15 for 256-byte rows) -> the 32x32x16 A-operand read (32 keys x one chunk) is a conflict-free ds_read_b128.
+  int koff[KP], kdst[KP], kkey[KP];
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int f = i * 256 + tid;
+    const int cc = f % CPR, kk = f / CPR;  // chunk, key in tile
+    koff[i] = cc * 8;                      // + key * ldk at load time (clamped)
+    kkey[i] = kk;
+    const int g = (DH == 64) ? ((kk >> 1) & 7) : (kk & 15);
+    kdst[i] = kk * CPR + (cc ^ g);
+  }
+  int vdst[KP];
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int f = i * 256 + tid;
+    const int cc = f % CPR, kk = f / CPR;
+    const int sw = (DH == 64) ? (((kk >> 1) & 1) << 2) : ((kk & 3) << 2);
+    vdst[i] = kk * CPR + (cc ^ sw);
+  }
+
+  u32x4 kr[KP], vr[KP];
+  // (written as macros, not lambdas: arrays captured by reference in a lambda called from two sites were left in
+  // scratch memory by the compiler)
+#define SVT_STAGE_LOAD(TILE)                                                          \
+  {                                                                                   \
+    const int key0_ = (TILE) * 64;                                                    \
+    _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                  \
+      int key_ = key0_ + kkey[i];                                                     \
+      if (key_ > T - 1) key_ = T - 1;                                                 \
+      kr[i] = *(const u32x4*)(Kb + koff[i] + (long)key_ * ldk);                       \
+      vr[i] = *(const u32x4*)(Vb + koff[i] + (long)key_ * ldk);                       \
+    }                                                                                 \
+  }
+#define SVT_STAGE_WRITE()                                                             \
+  {                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < KP; ++i) { ((u32x4*)Kf)[kdst[i]] = kr[i]; ((u32x4*)Vs)[vdst[i]] = vr[i]; } \
+  }
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+  const int hh = lane >> 5;
+  const int kl = lane & 31;                                     // key within a 32-key block
+  const int kg = (DH == 64) ? ((kl >> 1) & 7) : (kl & 15);      // its swizzle (same for both key blocks: 32 % 16 == 0)
+  const int ntiles = (T + 63) / 64;
+  // transposing-read addresses: lane 16g+4q+p supplies row (key) q, columns 4p..4p+3 of its group's 4 x 16 block
+  const char* vbase[DB];
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int key0 = 4 * (g >> 1) + q;
+    const int sw = (DH == 64) ? (((q >> 1) & 1) << 2) : (q << 2);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+      vbase[db] = (const char*)Vs + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
+    }
+  }
+
+  SVT_STAGE_LOAD(0)
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();  // previous tile fully consumed
+    SVT_STAGE_WRITE()
+    __syncthreads();
+    if (tile + 1 < ntiles) SVT_STAGE_LOAD(tile + 1)
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb], 0, 0, 0);
+    }
+    // softmax in the scaled log2 domain: p = exp2(s*c - m).  The scale is folded into the exponent FMA, the row max is
+    // taken on the raw scores, and the running max is only raised (O and l rescaled) when some row of the wave grew
+    // by more than 2^8 (deferred rescale: P stays <= 256, exact in fp32 and safe in bf16); keys >= T are masked in
+    // the last tile only.
+    if (tile * 64 + 64 > T) {
+      const int kbase = tile * 64 + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= T) s[kb][r] = -3e38f;
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    if (!__all(mx - m <= 8.0f)) {
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      l *= alpha;
+      m = mnew;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], c, -m));
+        s[kb][r] = p0;
+        s[kb][r + 1] = p1;
+        sum0 += p0;
+        sum1 += p1;
+      }
+    float sum = sum0 + sum1;
+    sum += __shfl_xor(sum, 32, 64);
+    l += sum;
+    // P (bf16) fragments straight from the S accumulators: k-step ss of key block kb = regs 8ss..8ss+7
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kb][ss][j] = (bf16_t)s[kb][ss * 8 + j];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+        {
+          // A operand of O^T += V^T P^T straight from the row-major V tile: two ds_read_b64_tr_b16 (4 keys x 16 d
+          // blocks, delivered column-major) give this lane V[key][d] for its d and the permuted k-slots
+          // {16s+4h+0..3, 16s+8+4h+0..3}
+          const char* vp = vbase[db] + (kb * 32 + ss * 16) * RB;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
+          const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[db], 0, 0, 0);
+        }
+  }
+
+  // O[q][d] = o / l ; lane (q = lane&31, hh) holds d = db*32 + (r&3) + 8*(r>>2) + 4*hh
+  const int q = q0 + (lane & 31);
+  if (q >= T) return;
+  const float inv = 1.f / l;
+  bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][g * 4 + j] * inv);
+      *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
+    }
+}
+
+#undef SVT_STAGE_LOAD
+#undef SVT_STAGE_WRITE
 }  // namespace
 
-int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, long ldk, long k_bstride,
+int launch_flash_attention_vt(const void* Q, long ldq, long q_bstride, const void* K, long ldk, long k_bstride,
                            const void* Vt, int Tp, void* O, long ldo, long o_bstride, int B, int T, int H, int dh,
                            float scale, hipStream_t s) {
   if (Tp % 64 || Tp < T) { set_error("flash_attention: V^T must be padded to a multiple of 64 keys"); return -1; }
@@ -222,4 +422,26 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   return 0;
 }
 
+}  // namespace svt
+
+namespace svt {
+// V row-major (same layout and strides as K): no transposed copy of V is needed
+int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
+                           void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s) {
+  if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8) { set_error("flash_attention: strides must be multiples of 8"); return -1; }
+  const float c = scale * 1.44269504088896340736f;
+  dim3 grid((T + 127) / 128, H, B);
+  const double flops = 4.0 * B * H * (double)T * T * dh;
+  prof_begin(s);
+  if (dh == 64)
+    hipLaunchKernelGGL((flash_attn2_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
+  else if (dh == 128)
+    hipLaunchKernelGGL((flash_attn2_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
+  else { set_error("flash_attention: head_dim must be 64 or 128"); return -1; }
+  prof_end(s, flops, 0.0, 2);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
 }  // namespace svt

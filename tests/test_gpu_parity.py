@@ -96,7 +96,7 @@ def test_bf16_mode_error_bound(golden, name):
     print(f"bf16[{name}]: max|dlogit| {err.max():.4f} mean {err.mean():.4f} (logit std {fx['logits'].std():.2f}); "
           f"frames with a different octave/pitch-class argmax: {mism}/{total}")
     assert err.max() < 1.5, err.max()
-    assert err.mean() < 0.08, err.mean()
+    assert err.mean() < 0.1, err.mean()
     assert mism <= max(2, int(0.12 * total)), (mism, total)
 
 
