@@ -661,6 +661,10 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   // is then store-only (fire-and-forget under the next tile's MFMAs in the persistent kernel).  tmp = w.hF is free
   // after the positional conv.
   float* tmp = w.hF;
+  // branch outputs (out-proj / FFN-2) are stored in the operand type (bf16 in throughput mode: half the store burst of
+  // the GEMM epilogue and half the read of the LayerNorm) and widened when added to the fp32 residual stream
+  const bool vecD = (D == 512 || D == 768 || D == 1024);
+  const int tmp_f32 = (prec && vecD) ? 0 : 1;
   if (!c.stable_layer_norm) {
     if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.xb,
                                  prec ? w.xF : nullptr, s)) return r;
@@ -668,12 +672,12 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
       const EncLayerW& Lw = e->layers[l];
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
       if (int r = attention()) return r;
-      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, tmp_f32, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
                                    prec ? w.xF : nullptr, s, w.xF)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
-      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb,
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, tmp_f32, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb,
                                    prec ? w.xF : nullptr, s, w.xF)) return r;
     }
     final_x = w.xF;

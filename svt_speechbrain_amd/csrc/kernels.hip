@@ -111,20 +111,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const float
 
 // Register-resident variant for D = 64*VPT (512 / 768 / 1024): the row is read ONCE with 16-byte loads
 // (fp32 in) and kept in VPT registers per lane; statistics by two in-register passes + wave shuffles.
-template <int VPT, typename TO>
-__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* x, const float* add, float* sumF,
+template <int VPT, typename TO, typename TI = float>
+__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const TI* x, const float* add, float* sumF,
                                                                 int64_t rows, const float* gamma, const float* beta,
                                                                 float eps, int gelu, TO* yT, float* yF) {
   constexpr int D = 64 * VPT, NV = VPT / 4;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float4* xr = (const float4*)(x + row * D);
   float v[VPT];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    float4 t = xr[lane + 64 * j];
+    float4 t;
+    if constexpr (sizeof(TI) == 4) {
+      t = ((const float4*)(x + row * D))[lane + 64 * j];
+    } else {
+      const bf16x4 tb = ((const bf16x4*)(x + row * D))[lane + 64 * j];
+      t = float4{(float)tb[0], (float)tb[1], (float)tb[2], (float)tb[3]};
+    }
     if (add) {
       const float4 a = ((const float4*)(add + row * D))[lane + 64 * j];
       t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
@@ -623,7 +628,23 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s, const float* add,
                      float* sumF) {
-  if (add && !x_is_f32) { set_error("layernorm: the addend form needs an fp32 input"); return -1; }
+  if (prec && !x_is_f32 && (D == 512 || D == 768 || D == 1024) && !((uintptr_t)x & 7) && !((uintptr_t)yT & 15) &&
+      !((uintptr_t)yF & 15) && !((uintptr_t)add & 15) && !((uintptr_t)sumF & 15)) {
+    // bf16 branch output + fp32 residual (throughput mode)
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (D == 512)
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<8, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, add, sumF, rows,
+                         gamma, beta, eps, gelu, (bf16_t*)yT, yF);
+    else if (D == 768)
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<12, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, add, sumF, rows,
+                         gamma, beta, eps, gelu, (bf16_t*)yT, yF);
+    else
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<16, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, add, sumF, rows,
+                         gamma, beta, eps, gelu, (bf16_t*)yT, yF);
+    SVT_LAUNCH_CHECK();
+    return 0;
+  }
+  if (add && !x_is_f32) { set_error("layernorm: the addend form needs an fp32 input (or bf16 with D in {512,768,1024})"); return -1; }
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (x_is_f32 && (D == 512 || D == 768 || D == 1024) && !((uintptr_t)x & 15) && !((uintptr_t)yT & 15) &&
       !((uintptr_t)yF & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15) && !((uintptr_t)add & 15) &&
