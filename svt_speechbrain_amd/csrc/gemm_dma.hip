@@ -1,18 +1,19 @@
-// bf16 dense contraction, large-tile variant for gfx950: BM x 256 output tile per 512-thread workgroup
-// (8 waves as 2(M) x 4(N), wave tile BM/2 x 64), K consumed in 64-element (128-byte) slabs that are
-// moved global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), double
-// buffered.  Same contract as gemm.hip (GemmArgs: overlapping A rows for implicit conv, batches,
-// bias / activation / fp32 residual epilogue).
+// bf16 dense contraction for gfx950, LDS-DMA variant: BM x 256 output tile per 512-thread workgroup (8 waves as
+// 2(M) x 4(N), wave tile BM/2 x 64, v_mfma_f32_16x16x32_bf16), K consumed in 64-element (128-byte) slabs that are
+// moved global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write).  Same contract as
+// gemm.hip (GemmArgs: overlapping A rows for implicit conv, bias / activation epilogue).
 //
-// LDS image of a slab: rows in groups of 8; one group = 1 KiB = [16-byte chunk c (8)][row r (8)].
-//   * one wave-instruction of LDS-DMA fills one group: lane l fetches 16 B of row (l & 7), chunk (l >> 3)
-//     -> 8 rows x 128 B full lines from memory, linear (lane x 16 B) in LDS as the DMA requires;
-//   * an MFMA 16x16x32 operand (16 rows x 32 k) is read by one ds_read_b128 per lane at
-//     group(row >> 3) * 1024 + (4*ks + (l >> 4)) * 128 + (row & 7) * 16 — conflict-free for the four
-//     16-lane groups of ds_read_b128 (each covers all 64 banks once).
-//   * W rows are fetched in MFMA order (per-lane source addresses make any row order free), permuted so a
-//     lane ends up with 16 consecutive output columns (see gemm.hip) -> 16-byte epilogue stores.
-// BM in {128, 192, 256} is picked per problem to minimise idle CUs in the last round of tiles.
+// LDS is a ring of five 32 KiB slots holding alternating A / W units of successive K slabs; three units are in
+// flight while a slab is multiplied, retired by a counted s_waitcnt vmcnt across ONE raw s_barrier per slab.
+//   * DMA source mapping: 8 consecutive lanes fetch the 8 16-byte chunks of one 128-byte row (one request per line
+//     for the texture addresser; a lane-per-row mapping costs one request per lane and halves the fill rate), lane
+//     (row r, slot s) takes chunk s ^ r, so the row-major LDS image is XOR-swizzled and the MFMA operand read of
+//     (row, chunk C) at slot C ^ row is a conflict-free ds_read_b128.
+//   * W rows are fetched in MFMA order, permuted (free with per-lane DMA source addresses) so a lane ends up with
+//     16 consecutive output columns of one row.
+//   * two kernels share this pipeline: gemm_uring_kernel (one tile per workgroup, LDS-transposed coalesced epilogue)
+//     and gemm_pers_kernel (one workgroup per CU walks a tile list; the next tile's fills and the epilogue stores
+//     overlap the MFMAs).  launch_gemm_dma picks BM in {128,192,256} and the kernel per problem.
 #include "common.h"
 #include <utility>
 
@@ -29,370 +30,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-template <int BM>
-__global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs p) {
-  constexpr int BN = 256, BK = 64;
-  constexpr int MB = BM / 32;              // 16-row blocks per wave (wave tile BM/2 x 64)
-  constexpr int XG = BM / 8, WG = BN / 8;  // 8-row groups per slab
-  constexpr int NG = XG + WG;              // groups (= DMA instructions) per slab
-  constexpr int GPW = NG / 8;              // groups per wave per slab
-  constexpr int STAGE = NG * 64;           // uint4 per stage
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  // XCD-aware block -> tile map: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
-  // contiguous run of logical tiles, n fastest, so the tiles that share an A panel meet in one L2.
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int z = blockIdx.y;
-  const int z1 = z / p.nz2, z2 = z % p.nz2;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
-  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
-
-  // DMA sources: wave w fills groups w*GPW .. w*GPW+GPW-1 of every slab
-  const bf16_t* src[GPW];
-  const int r8 = lane & 7, ch = lane >> 3;
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    const int g = wave * GPW + i;
-    if (g < XG) {
-      int m = m0 + g * 8 + r8;
-      if (m > p.M - 1) m = p.M - 1;
-      src[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
-    } else {
-      const int rho = (g - XG) * 8 + r8;  // LDS (MFMA-order) row of the W tile
-      const int i16 = rho & 15;
-      int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
-      if (n > p.N - 1) n = p.N - 1;
-      src[i] = W + (long)n * p.ldw + ch * 8;
-    }
-  }
-  auto issue = [&](int kt, int buf) {
-#pragma unroll
-    for (int i = 0; i < GPW; ++i) {
-      uint4* dst = lds + buf * STAGE + (wave * GPW + i) * 64;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * BK), (lptr_t)dst, 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][MB];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (uint4 units) inside a stage
-  const int cq = lane >> 4, r16 = lane & 15;
-  const int frag = (r16 >> 3) * 64 + cq * 8 + (r16 & 7);  // + group*64 + ks*32
-  const int xbase = (wm * (MB * 2)) * 64 + frag;
-  const int wbase = (XG + wn * 8) * 64 + frag;
-
-  const int nk = p.K / BK;
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk && p.dbg != 1) issue(kt + 1, buf ^ 1);
-    const uint4* st = lds + buf * STAGE;
-    if (p.dbg != 2)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4];
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, st[wbase + nb * 128 + ks * 32]);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, st[xbase + mb * 128 + ks * 32]);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf, acc[nb][mb], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue (same register layout as gemm.hip) ----
-  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
-  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
-  if (nbase >= p.N) return;
-  const bool full = (nbase + 16 <= p.N) && p.c_vec;
-  float bv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-  if (bias) {
-    if (full) {
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const float4 b4 = *(const float4*)(bias + nbase + j4 * 4);
-        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) if (nbase + j < p.N) bv[j] = bias[nbase + j];
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = m0 + wm * (BM / 2) + mb * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nb * 4 + r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
-    const long idx = coff + (long)m * p.ldc + nbase;
-    if (full) {
-      if (p.resid) {
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 r4 = *(const float4*)(p.resid + idx + j4 * 4);
-          v[j4 * 4 + 0] += r4.x; v[j4 * 4 + 1] += r4.y; v[j4 * 4 + 2] += r4.z; v[j4 * 4 + 3] += r4.w;
-        }
-      }
-      if (p.out_f32) {
-        float* c = (float*)p.C + idx;
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4)
-          *(float4*)(c + j4 * 4) = float4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
-      } else {
-        bf16_t* c = (bf16_t*)p.C + idx;
-#pragma unroll
-        for (int j8 = 0; j8 < 2; ++j8) {
-          bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j8 * 8 + j];
-          *(bf16x8*)(c + j8 * 8) = o;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (nbase + j >= p.N) continue;
-        float o = v[j];
-        if (p.resid) o += p.resid[idx + j];
-        if (p.out_f32) ((float*)p.C)[idx + j] = o;
-        else ((bf16_t*)p.C)[idx + j] = (bf16_t)o;
-      }
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Ring-buffered variant: K is consumed in 32-element stages (one MFMA k-step); NSTAGE LDS slots,
-// NSTAGE-1 stages of LDS-DMA in flight across raw s_barriers, retired with a COUNTED s_waitcnt
-// vmcnt (never 0 in the steady state).  One group = 16 rows x 64 B = [chunk (4)][row (16)] x 16 B:
-// lane l of the DMA instruction fetches row (l & 15), chunk (l >> 4); the MFMA operand read of lane
-// l is the same linear slot (group * 64 + l) -> one conflict-free ds_read_b128.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int BM, int NSTAGE>
-__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs p) {
-  constexpr int BN = 256, BK = 32;
-  constexpr int MB = BM / 32;                // 16-row blocks per wave (wave tile BM/2 x 64)
-  constexpr int XG = BM / 16, WG = BN / 16;  // 16-row groups per stage
-  constexpr int NG = XG + WG;
-  constexpr int GPW = (NG + 7) / 8;          // max groups per wave per stage
-  constexpr int NFULL = NG % 8 == 0 ? 8 : NG % 8;  // waves [0,NFULL) own GPW groups, the rest GPW-1
-  constexpr int STAGE = NG * 64;             // uint4 per stage
-  constexpr int D = NSTAGE - 1;              // prefetch distance
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int z = blockIdx.y;
-  const int z1 = z / p.nz2, z2 = z % p.nz2;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
-  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
-
-  // group ownership: wave w owns groups g = w + 8*i (interleaved so X and W groups spread over waves)
-  const bool full_wave = wave < NFULL;
-  const bf16_t* src[GPW];
-  const int r16 = lane & 15, cq = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    const int g = wave + 8 * i;
-    src[i] = A;
-    if (g < XG) {
-      int m = m0 + g * 16 + r16;
-      if (m > p.M - 1) m = p.M - 1;
-      src[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + cq * 8;
-    } else if (g < NG) {
-      const int rho = (g - XG) * 16 + r16;  // MFMA-order row of the W tile
-      int n = n0 + (rho >> 6) * 64 + (r16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (r16 & 3);
-      if (n > p.N - 1) n = p.N - 1;
-      src[i] = W + (long)n * p.ldw + cq * 8;
-    }
-  }
-  auto issue = [&](int kt) {
-    uint4* slot = lds + (kt % NSTAGE) * STAGE;
-#pragma unroll
-    for (int i = 0; i < GPW; ++i) {
-      if (i < GPW - 1 || full_wave)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * BK), (lptr_t)(slot + (wave + 8 * i) * 64), 16, 0, 0);
-    }
-  };
-  // retire stage kt while allowing `r` younger stages of this wave to stay in flight
-  auto retire = [&](int r) {
-    if (full_wave) {
-      if (r >= 3 && D >= 4) wait_vm<3 * GPW>();
-      else if (r == 2 && D >= 3) wait_vm<2 * GPW>();
-      else if (r == 1 && D >= 2) wait_vm<GPW>();
-      else wait_vm<0>();
-    } else {
-      if (r >= 3 && D >= 4) wait_vm<3 * (GPW - 1)>();
-      else if (r == 2 && D >= 3) wait_vm<2 * (GPW - 1)>();
-      else if (r == 1 && D >= 2) wait_vm<(GPW - 1)>();
-      else wait_vm<0>();
-    }
-  };
-
-  f32x4 acc[4][MB];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int xbase = (wm * MB) * 64 + lane;
-  const int wbase = (XG + wn * 4) * 64 + lane;
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < nk) issue(s);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    int r = nk - 1 - kt;
-    if (r > D - 1) r = D - 1;
-    if (r > 3) r = 3;
-    retire(r);
-    __builtin_amdgcn_s_barrier();
-    if (kt + D < nk && p.dbg != 1) issue(kt + D);
-    const uint4* st = lds + (kt % NSTAGE) * STAGE;
-    if (p.dbg != 2) {
-      bf16x8 wf[4], xf[MB];
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, st[wbase + nb * 64]);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, st[xbase + mb * 64]);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-
-  // ---- epilogue ----
-  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
-  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
-  if (nbase >= p.N) return;
-  const bool full = (nbase + 16 <= p.N) && p.c_vec;
-  float bv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-  if (bias) {
-    if (full) {
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const float4 b4 = *(const float4*)(bias + nbase + j4 * 4);
-        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) if (nbase + j < p.N) bv[j] = bias[nbase + j];
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = m0 + wm * (BM / 2) + mb * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nb * 4 + r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
-    const long idx = coff + (long)m * p.ldc + nbase;
-    if (full) {
-      if (p.resid) {
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 r4 = *(const float4*)(p.resid + idx + j4 * 4);
-          v[j4 * 4 + 0] += r4.x; v[j4 * 4 + 1] += r4.y; v[j4 * 4 + 2] += r4.z; v[j4 * 4 + 3] += r4.w;
-        }
-      }
-      if (p.out_f32) {
-        float* c = (float*)p.C + idx;
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4)
-          *(float4*)(c + j4 * 4) = float4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
-      } else {
-        bf16_t* c = (bf16_t*)p.C + idx;
-#pragma unroll
-        for (int j8 = 0; j8 < 2; ++j8) {
-          bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j8 * 8 + j];
-          *(bf16x8*)(c + j8 * 8) = o;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (nbase + j >= p.N) continue;
-        float o = v[j];
-        if (p.resid) o += p.resid[idx + j];
-        if (p.out_f32) ((float*)p.C)[idx + j] = o;
-        else ((bf16_t*)p.C)[idx + j] = (bf16_t)o;
-      }
-    }
-  }
-}
-
-template <int BM, int NSTAGE>
-int launch_ring(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
-  dim3 grid(tiles_m * tiles_n, a.nz, 1);
-  const size_t lds_bytes = (size_t)NSTAGE * (BM + 256) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<BM, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
-  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL((gemm_ring_kernel<BM, NSTAGE>), grid, dim3(512), lds_bytes, s, a);
-  prof_end(s, flops, bytes);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Coalesced epilogue.  After the MFMA loop a lane holds, per 16-row block, 16 consecutive columns of ONE row
@@ -626,156 +264,6 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
     epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
   else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
 }
-
-
-template <int BM>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
-  constexpr int BN = 256, BK = 64, NSLOT = 5;
-  constexpr int MB = BM / 32;
-  constexpr int GA = BM / 64;       // DMA instructions per wave per A unit (BM/8 groups over 8 waves)
-  constexpr int GW = BN / 64;       // per W unit
-  constexpr int SLOT = 2048;        // uint4 per slot (32 KiB)
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int z = blockIdx.y;
-  const int z1 = z / p.nz2, z2 = z % p.nz2;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
-  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
-
-  // coalesced + swizzled DMA source: 8 consecutive lanes fetch the 8 chunks of ONE 128-byte row (one line request
-  // instead of eight), lane (row r8 = l>>3, slot = l&7) takes chunk (slot ^ r8); the LDS image of a group is then
-  // row-major [row][slot] and the MFMA read of (row, chunk C) goes to slot C ^ row -> conflict-free ds_read_b128.
-  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
-  const bf16_t* asrc[GA];
-  const bf16_t* wsrc[GW];
-#pragma unroll
-  for (int i = 0; i < GA; ++i) {
-    int m = m0 + (wave + 8 * i) * 8 + r8;
-    if (m > p.M - 1) m = p.M - 1;
-    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < GW; ++i) {
-    const int rho = (wave + 8 * i) * 8 + r8;
-    const int i16 = rho & 15;
-    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
-    if (n > p.N - 1) n = p.N - 1;
-    wsrc[i] = W + (long)n * p.ldw + ch * 8;
-  }
-  // unit u: even -> A slab u/2, odd -> W slab u/2; slot u % 5
-  auto issue_a = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
-  };
-  auto issue_w = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < GW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
-  };
-
-  f32x4 acc[4][MB];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int cq = lane >> 4, r16 = lane & 15;
-  // uint4 index inside a slot of fragment (16-row block blk, k-step ks): group (2*blk + (r16>>3)) * 64 + row*8 + slot
-  const int rr8 = r16 & 7;
-  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
-  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
-  const int xoff = (wm * (MB * 2)) * 64;
-  const int woff = (wn * 8) * 64;
-
-  const int nk = p.K / BK;
-  const int grp = wave >> 2;  // waves w and w+4 share a SIMD: group 0 multiplies while group 1 reads LDS and vice versa
-  bf16x8 wf[4], xf[MB];
-  auto R = [&](const uint4* xa, const uint4* wa, int fr) {
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + fr]);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + fr]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto M = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  issue_a(0, 0);
-  issue_w(0, 1);
-  if (nk > 1) issue_a(1, 2);
-  int sa = 0, sw = 1;
-  // Two straight-line loops (one per wave group) with the SAME barrier count: group 0 runs R M R M per slab,
-  // group 1 runs M R M R (its first M is skipped, its last M runs after the loop), so on every SIMD one wave
-  // multiplies while its partner reads LDS.
-  if (grp == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();  // slab kt landed for everyone; group 1 finished reading slab kt-1
-      if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
-      if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
-      const uint4* xa = lds + sa * SLOT + xoff;
-      const uint4* wa = lds + sw * SLOT + woff;
-      R(xa, wa, frag0);
-      __builtin_amdgcn_s_barrier();
-      M();
-      __builtin_amdgcn_s_barrier();
-      R(xa, wa, frag1);
-      __builtin_amdgcn_s_barrier();
-      M();
-      sa = (sa + 2) % NSLOT;
-      sw = (sw + 2) % NSLOT;
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
-      if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
-      const uint4* xa = lds + sa * SLOT + xoff;
-      const uint4* wa = lds + sw * SLOT + woff;
-      if (kt > 0) M();
-      __builtin_amdgcn_s_barrier();
-      R(xa, wa, frag0);
-      __builtin_amdgcn_s_barrier();
-      M();
-      __builtin_amdgcn_s_barrier();
-      R(xa, wa, frag1);
-      sa = (sa + 2) % NSLOT;
-      sw = (sw + 2) % NSLOT;
-    }
-    M();
-  }
-
-  // ---- epilogue ----
-  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
-  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
-  if (p.dbg != 3)
-    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
-  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
-}
-
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1028,46 +516,6 @@ int launch_uring(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int BM>
-int launch_pp(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
-  dim3 grid(tiles_m * tiles_n, a.nz, 1);
-  const size_t lds_bytes = 5 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
-  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL((gemm_pp_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
-  prof_end(s, flops, bytes, 0);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int BM>
-int launch_dma(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
-  dim3 grid(tiles_m * tiles_n, a.nz, 1);
-  const size_t lds_bytes = 2 * (size_t)(BM + 256) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_dma_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
-  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL((gemm_dma_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
-  prof_end(s, flops, bytes);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128 && a.c_vec && a.N % 8 == 0; }
@@ -1078,7 +526,7 @@ bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 &
 // one-tile-per-workgroup kernel, whose LDS-transposed epilogue stores whole 128-byte lines.
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
-int g_gemm_ring = 0;  // 0 = auto; 2 = unit-ring, 3 = ping-pong, 4 = persistent, 1 = k32 ring, 5 = legacy (diagnostics)
+int g_gemm_ring = 0;  // 0 = auto; 2 = force one-tile-per-workgroup kernel, 4 = force persistent kernel (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   a.dbg = g_gemm_dbg;
@@ -1106,21 +554,6 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     return launch_pers<64>(a, s);
   }
   if (best == 64) best = 128;
-  if (mode == 3) {
-    if (best == 256) return launch_pp<256>(a, s);
-    if (best == 192) return launch_pp<192>(a, s);
-    return launch_pp<128>(a, s);
-  }
-  if (mode == 1) {
-    if (best == 256) return launch_ring<256, 4>(a, s);
-    if (best == 192) return launch_ring<192, 5>(a, s);
-    return launch_ring<128, 6>(a, s);
-  }
-  if (mode == 5) {
-    if (best == 256) return launch_dma<256>(a, s);
-    if (best == 192) return launch_dma<192>(a, s);
-    return launch_dma<128>(a, s);
-  }
   if (best == 256) return launch_uring<256>(a, s);
   if (best == 192) return launch_uring<192>(a, s);
   return launch_uring<128>(a, s);

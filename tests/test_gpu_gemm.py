@@ -1,0 +1,84 @@
+"""GPU unit tests of the dense contraction kernels through the C-ABI test hook (svt_debug_gemm): every dispatch path
+(persistent LDS-DMA, one-tile LDS-DMA, register-staged bf16 / exact-fp32) against a torch fp32 reference of the same
+op, including implicit-conv row addressing, M / N / K tails, bias, GELU / ReLU and the fp32 residual epilogue."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from svt_speechbrain_amd import _lib  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def run_gemm(prec, M, N, K, conv=None, act=0, out_f32=0, resid=False, bias=True, seed=0):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16 if prec else torch.float32
+    if conv:
+        T_in, T_out, st, cin = conv
+        B = M // T_out
+        A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(DEV, dt)
+        rpb, bstr, rstr = T_out, T_in * cin, st * cin
+        k = K // cin
+        idx = (torch.arange(T_out) * st)[:, None] + torch.arange(k)[None, :]
+        A_rows = A.cpu().float()[:, idx].reshape(M, K)
+    else:
+        A = (torch.rand(M, K, generator=g) * 2 - 1).to(DEV, dt)
+        rpb, bstr, rstr = M, 0, K
+        A_rows = A.cpu().float()
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(DEV, dt)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    R = torch.randn(M, N, generator=g).to(DEV) if resid else None
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if (out_f32 or not prec) else dt)
+    _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), b.data_ptr() if bias else None,
+                                  R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, K, act, out_f32, 0,
+                                  torch.cuda.current_stream().cuda_stream), "svt_debug_gemm")
+    torch.cuda.synchronize()
+    ref = A_rows @ W.cpu().float().t()
+    if bias:
+        ref = ref + b.cpu()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    if resid:
+        ref = ref + R.cpu()
+    return C.cpu().float(), ref
+
+
+CASES = [
+    # name, prec, M, N, K, conv, act, out_f32, resid
+    ("pers_bf16_gelu", 1, 70000, 512, 1536, None, 1, 0, False),        # >= 512 tiles -> persistent kernel, M tail
+    ("pers_conv", 1, 8 * 15999, 512, 1536, (31999, 15999, 2, 512), 1, 0, False),
+    ("pers_f32out", 1, 66000, 768, 768, None, 0, 1, False),
+    ("uring_f32out_resid", 1, 15968, 768, 768, None, 0, 1, True),      # single round -> one-tile kernel
+    ("uring_bf16", 1, 4999, 2304, 768, None, 0, 0, False),
+    ("uring_relu", 1, 998, 3072, 1024, None, 2, 0, False),
+    ("v1_bf16_small_k", 1, 300, 256, 96, None, 1, 0, False),           # K % 64 != 0 -> register-staged kernel
+    ("v1_bf16_narrow", 1, 499, 48, 6144, None, 1, 1, True),            # grouped pos-conv shape (N = 48)
+    ("v1_bf16_ntail", 1, 777, 200, 128, None, 0, 0, False),
+    ("fp32_exact", 0, 1000, 768, 512, None, 1, 0, True),
+    ("fp32_conv", 0, 2 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, False),
+    ("fp32_tiny", 0, 24, 64, 32, None, 0, 0, False),
+    ("fp32_head", 0, 499, 20, 768, None, 0, 0, False),
+]
+
+
+@pytest.mark.parametrize("name,prec,M,N,K,conv,act,out_f32,resid", CASES, ids=[c[0] for c in CASES])
+def test_gemm_vs_torch(name, prec, M, N, K, conv, act, out_f32, resid):
+    got, ref = run_gemm(prec, M, N, K, conv, act, out_f32, resid)
+    assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
+    err = (got - ref).abs().max().item()
+    # bf16 output rounding dominates in bf16 mode (values O(1..3)); fp32 path is an exact fp32 fma chain
+    tol = 3e-2 if (prec and not out_f32) else (2e-4 if prec else 1e-4)
+    assert err < tol, (name, err)
+
+
+def test_gemm_rejects_unaligned():
+    lib = _lib.load()
+    A = torch.zeros(64, 36, device=DEV, dtype=torch.bfloat16)
+    W = torch.zeros(64, 36, device=DEV, dtype=torch.bfloat16)
+    C = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    rc = lib.svt_debug_gemm(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, 64, 64, 36, 64, 0, 36, 36, 0, 0, 0, None)
+    assert rc != 0 and b"multiple" in lib.svt_last_error()
