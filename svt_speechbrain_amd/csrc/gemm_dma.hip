@@ -331,6 +331,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
     for (int i = 0; i < GW; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(ws[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
   };
+  // one DMA instruction of a unit (the steady-state loop spreads a unit's instructions between MFMA groups: a burst
+  // of 8 per wave right after the barrier queues 64 requests on the CU's texture addresser in front of every wave)
+  auto issue_a1 = [&](const bf16_t* const (&as)[GA], int i, int kt, int slot) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(as[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+  auto issue_w1 = [&](const bf16_t* const (&ws)[GW], int i, int kt, int slot) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(ws[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
 
   f32x4 acc[4][MB];
 #pragma unroll
@@ -368,31 +376,44 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
     __builtin_amdgcn_s_barrier();
     const uint4* xa = lds + sa * SLOT + xoff;
     const uint4* wa = lds + sw * SLOT + woff;
+    const bool have_w = g + 1 < G, have_a = g + 2 < G;
+    const bool w_cur = kt + 1 < nk, a_cur = kt + 2 < nk;
+    const int wslot = (2 * g + 3) % NSLOT, aslot = (2 * g + 4) % NSLOT;
+    const int wkt = w_cur ? kt + 1 : 0, akt = a_cur ? kt + 2 : kt + 2 - nk;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 0) {
-        if (g + 1 < G) {  // W unit of slab g+1
-          if (kt + 1 < nk) issue_w(wsrc, kt + 1, (2 * g + 3) % NSLOT);
-          else issue_w(wsrc2, 0, (2 * g + 3) % NSLOT);
-        }
-      } else {
-        if (g + 2 < G) {  // A unit of slab g+2
-          if (kt + 2 < nk) issue_a(asrc, kt + 2, (2 * g + 4) % NSLOT);
-          else issue_a(asrc2, kt + 2 - nk, (2 * g + 4) % NSLOT);
-        }
-      }
       bf16x8 wf[4], xf[MB];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+      for (int half = 0; half < 2; ++half) {
+        // two DMA instructions, then half of this k-step's MFMAs
+        if (ks == 0) {
+          if (have_w) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+            for (int i = half * 2; i < half * 2 + 2; ++i) {
+              if (w_cur) issue_w1(wsrc, i, wkt, wslot); else issue_w1(wsrc2, i, wkt, wslot);
+            }
+          }
+        } else {
+          if (have_a) {
+#pragma unroll
+            for (int i = half * ((GA + 1) / 2); i < (half ? GA : (GA + 1) / 2); ++i) {
+              if (a_cur) issue_a1(asrc, i, akt, aslot); else issue_a1(asrc2, i, akt, aslot);
+            }
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mb = half * (MB / 2); mb < (half + 1) * (MB / 2); ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+            acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     sa = (sa + 2) % NSLOT;
     sw = (sw + 2) % NSLOT;
