@@ -86,10 +86,10 @@ def main():
     from svt_speechbrain_amd import _lib, distributed as D
     from svt_speechbrain_amd import weights as W
 
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # before the process group: RCCL binds to it
     rank, local, world = D.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     lib = _lib.load()
     _lib.require_gpu()
@@ -100,8 +100,12 @@ def main():
     B = args.batch
     n_total = B * world
     lo, hi = D.shard_bounds(n_total, rank, world)
-    # every rank generates only its own clips (seeded per clip index range), already on the device
-    wav = synth_wav(n_total, L, seed=1986)[lo:hi].to(dev) if world > 1 else synth_wav(B, L).to(dev)
+    # rank r owns clips [lo, hi) of the global batch; each clip is seeded by its global index, so no rank ever
+    # materialises another rank's clips and the union over ranks is the same for every N
+    if world > 1:
+        wav = torch.cat([synth_wav(1, L, seed=1986 + i) for i in range(lo, hi)]).to(dev)
+    else:
+        wav = synth_wav(B, L).to(dev)
 
     enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, seed=1986).to(dev)
     head = S.Linear(20, input_size=cfg.hidden_size)

@@ -1,0 +1,79 @@
+"""Song-level driver either side of the hot path.
+
+* utterance slicing of a song — the rule of ``MIR_ST500/prepare_benchmarks.py:117-126`` (``utter_num =
+  round(duration / 5 s)``, last utterance takes the remainder, up to 7.5 s) and of the recipe's audio pipeline
+  (``MIR_ST500/train_audio_ssl.py:373-390``: sample bounds ``round((i-1) * sr * dur)`` .. ``round(i * sr * dur)``);
+* per-utterance forward with batch = 1 (the reference asserts it, ``train_audio_ssl.py:90``), frame predictions
+  concatenated over the song, ``frame2note`` once at the last utterance (``:85-107``);
+* the stage-1 feature writer of ``N20EMv2/audio_only/extract_ssl_feats.py:102-116``: per-utterance ``feats[0]``
+  concatenated along time and ``torch.save``d as ``<folder>/noise_data/clean_feats.pt`` (or
+  ``noise_data/<type>/SNR_<db>dB_feats.pt``) — the input of the audio-visual recipe.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+from .decode import decode_frames, frame2note, frames_to_info
+
+
+def utterance_bounds(n_samples: int, sample_rate: int = 16000, dur_threshold: float = 5.0) -> List[Tuple[int, int]]:
+    """Sample ranges of the utterances of one song (1-based ids ``1..utter_num`` in the reference's CSV)."""
+    duration = n_samples / sample_rate
+    utter_num = round(duration / dur_threshold)
+    if utter_num < 1:
+        utter_num = 1
+    out = []
+    for i in range(1, utter_num + 1):
+        lo = round((i - 1) * sample_rate * dur_threshold)
+        hi = n_samples if i == utter_num else round(i * sample_rate * dur_threshold)
+        out.append((lo, hi))
+    return out
+
+
+class SongTranscriber:
+    """waveform of a whole song -> (notes, per-song features), utterance by utterance like the reference's eval loop."""
+
+    def __init__(self, encoder, head, pitch_octave_num: int = 4, pitch_class_num: int = 12, onset_threshold: float = 0.4,
+                 offset_threshold: float = 0.5, frame_rate: float = 49.8, sample_rate: int = 16000,
+                 dur_threshold: float = 5.0):
+        self.encoder, self.head = encoder, head
+        self.pitch_octave_num, self.pitch_class_num = pitch_octave_num, pitch_class_num
+        self.onset_threshold, self.offset_threshold = onset_threshold, offset_threshold
+        self.frame_rate, self.sample_rate, self.dur_threshold = frame_rate, sample_rate, dur_threshold
+
+    @torch.no_grad()
+    def transcribe(self, song: torch.Tensor, return_feats: bool = False):
+        """song: 1-D waveform on the GPU.  Returns notes [[on_s, off_s, midi], ...] (and the (T_song, D) features)."""
+        if song.dim() != 1:
+            raise ValueError("expected a mono 1-D waveform")
+        pred: list = []
+        feats_all = []
+        for lo, hi in utterance_bounds(song.shape[0], self.sample_rate, self.dur_threshold):
+            feats = self.encoder(song[lo:hi].unsqueeze(0))  # batch of one utterance, as in the reference eval
+            logits = self.head(feats)
+            pred.extend(frames_to_info(decode_frames(logits[0], self.pitch_octave_num, self.pitch_class_num)))
+            if return_feats:
+                feats_all.append(feats[0])
+        notes = frame2note(pred, self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
+        if return_feats:
+            return notes, torch.cat(feats_all, dim=0)
+        return notes
+
+
+def feature_path(song_folder: str, add_noise: bool = False, noise_type: Optional[str] = None,
+                 snr_db: Optional[int] = None) -> str:
+    """Where the reference's extract pass stores the per-song features (extract_ssl_feats.py:108-115)."""
+    if add_noise:
+        return os.path.join(song_folder, "noise_data", str(noise_type), f"SNR_{snr_db}dB_feats.pt")
+    return os.path.join(song_folder, "noise_data", "clean_feats.pt")
+
+
+def save_song_features(feats: torch.Tensor, song_folder: str, add_noise: bool = False, noise_type: Optional[str] = None,
+                       snr_db: Optional[int] = None) -> str:
+    path = feature_path(song_folder, add_noise, noise_type, snr_db)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(feats.detach().cpu(), path)
+    return path

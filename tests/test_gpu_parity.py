@@ -229,3 +229,32 @@ def test_full_size_properties(cfg_name, B, L):
     d = enc16(wav)
     print(f"bf16 vs fp32 feats ({cfg_name},B={B},L={L}): mean|d| {(d - a).abs().mean():.4f} max {(d - a).abs().max():.4f}")
     assert (d - a).abs().mean() < 0.08 and (d - a).abs().max() < 1.5
+
+
+def test_song_transcriber_matches_oracle_per_utterance(tmp_path):
+    """Song-level path: 12.3 s song -> 2 utterances (5 s + 7.3 s), batch-1 forwards, frames
+    concatenated, one frame2note; features concatenated and written like extract_ssl_feats.py."""
+    cfg = PRESETS["tiny-group"]
+    sd = W.seeded_encoder_state_dict(cfg, seed=31)
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=32)
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32", seed=31).to(DEV)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict(hd)
+    head = head.to(DEV)
+    song = synth_wav(1, int(12.3 * 16000), 99)[0]
+    notes, feats = S.SongTranscriber(enc, head).transcribe(song.to(DEV), return_feats=True)
+    bounds = S.utterance_bounds(song.shape[0])
+    assert len(bounds) == 2
+    info, ref_feats = [], []
+    with torch.no_grad():
+        for lo, hi in bounds:
+            f = O.encoder_forward(sd, cfg, song[lo:hi][None])
+            lg = O.head_forward(f, hd["w.weight"], hd["w.bias"])
+            p_on, p_off, octv, pc = O.decode_frames(lg)
+            info += list(zip(p_on[0].numpy(), p_off[0].numpy(), octv[0].tolist(), pc[0].tolist()))
+            ref_feats.append(f[0])
+    assert notes == O.frame2note(info, 0.4, 0.5)
+    ref_feats = torch.cat(ref_feats)
+    assert feats.shape == ref_feats.shape and (feats.cpu() - ref_feats).abs().max() < 1e-3
+    path = S.save_song_features(feats, str(tmp_path / "song"))
+    assert path.endswith("noise_data/clean_feats.pt") and torch.load(path).shape == ref_feats.shape

@@ -105,3 +105,20 @@ def test_shard_bounds_cover_and_order():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_utterance_bounds_match_reference_rule():
+    """MIR_ST500/prepare_benchmarks.py:117-126 + train_audio_ssl.py:373-390: round(duration/5) utterances, the last one
+    takes the remainder (2.5 .. 7.5 s), bounds are round((i-1)*sr*5) .. round(i*sr*5)."""
+    sr = 16000
+    for dur in [5.0, 7.4, 7.6, 12.49, 12.51, 31.3, 2.6]:
+        n = int(dur * sr)
+        b = S.utterance_bounds(n, sr, 5.0)
+        assert len(b) == max(1, round(n / sr / 5.0))
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        assert all(hi - lo == 5 * sr for lo, hi in b[:-1])
+        if len(b) > 1 or n / sr >= 2.5:
+            assert 0 < (b[-1][1] - b[-1][0]) / sr <= 7.5 + 1e-9
+    assert S.feature_path("/x/song1") == "/x/song1/noise_data/clean_feats.pt"
+    assert S.feature_path("/x/song1", True, "babble", -5) == "/x/song1/noise_data/babble/SNR_-5dB_feats.pt"
