@@ -363,6 +363,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
   int sa = 0, sw = 1, kt = 0;
   bool after_epilogue = false;
   const int n_store = MB * (p.out_f32 ? 4 : 2);  // buffer stores per wave per epilogue
+  // static priority for the younger half of the workgroup (waves 4-7 share SIMDs with 0-3 and lose issue arbitration
+  // by age: measured 39 % vs 7 % of the time parked at the barrier)
+  if (wave >= 4 && p.dbg == 8) __builtin_amdgcn_s_setprio(1);
   for (int g = 0; g < G; ++g) {
     // retire slab g: allowed in flight = A unit of slab g+1 (+ the previous tile's epilogue stores, which are younger)
     if (g + 1 < G) {
@@ -380,39 +383,51 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
     const bool w_cur = kt + 1 < nk, a_cur = kt + 2 < nk;
     const int wslot = (2 * g + 3) % NSLOT, aslot = (2 * g + 4) % NSLOT;
     const int wkt = w_cur ? kt + 1 : 0, akt = a_cur ? kt + 2 : kt + 2 - nk;
+    {
+      // Quarter-phase software pipeline: the slab is multiplied in four groups of 4 x MB/2 MFMAs ((k-step, M half));
+      // the fragments of group q+1 are requested BEFORE the MFMAs of group q (two register sets, static indices), so
+      // only the first group's LDS latency is exposed after the barrier.  The ring's DMA instructions are spread two
+      // per group.
+      constexpr int HM = MB / 2;
+      bf16x8 wfr[2][4], xfr[2][HM];
+      auto rd_w = [&](int ks, bf16x8 (&w)[4]) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4], xf[MB];
+        for (int nb = 0; nb < 4; ++nb) w[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
+      };
+      auto rd_x = [&](int ks, int half, bf16x8 (&x)[HM]) {
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
+        for (int j = 0; j < HM; ++j) x[j] = __builtin_bit_cast(bf16x8, xa[(half * HM + j) * 128 + (ks ? frag1 : frag0)]);
+      };
+      rd_w(0, wfr[0]);
+      rd_x(0, 0, xfr[0]);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        // two DMA instructions, then half of this k-step's MFMAs
+      for (int q = 0; q < 4; ++q) {
+        const int ks = q >> 1, half = q & 1;
+        // DMA: W unit during k-step 0, A unit during k-step 1
         if (ks == 0) {
           if (have_w) {
 #pragma unroll
-            for (int i = half * 2; i < half * 2 + 2; ++i) {
-              if (w_cur) issue_w1(wsrc, i, wkt, wslot); else issue_w1(wsrc2, i, wkt, wslot);
+            for (int i2 = half * 2; i2 < half * 2 + 2; ++i2) {
+              if (w_cur) issue_w1(wsrc, i2, wkt, wslot); else issue_w1(wsrc2, i2, wkt, wslot);
             }
           }
         } else {
           if (have_a) {
 #pragma unroll
-            for (int i = half * ((GA + 1) / 2); i < (half ? GA : (GA + 1) / 2); ++i) {
-              if (a_cur) issue_a1(asrc, i, akt, aslot); else issue_a1(asrc2, i, akt, aslot);
+            for (int i2 = half * ((GA + 1) / 2); i2 < (half ? GA : (GA + 1) / 2); ++i2) {
+              if (a_cur) issue_a1(asrc, i2, akt, aslot); else issue_a1(asrc2, i2, akt, aslot);
             }
           }
         }
-        __builtin_amdgcn_s_setprio(1);
+        // request the next group's fragments
+        if (q == 0) rd_x(0, 1, xfr[1]);
+        if (q == 1) { rd_w(1, wfr[1]); rd_x(1, 0, xfr[0]); }
+        if (q == 2) rd_x(1, 1, xfr[1]);
 #pragma unroll
-        for (int mb = half * (MB / 2); mb < (half + 1) * (MB / 2); ++mb)
+        for (int j = 0; j < HM; ++j)
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
-            acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+            acc[nb][half * HM + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[ks][nb], xfr[half][j], acc[nb][half * HM + j], 0, 0, 0);
       }
     }
     sa = (sa + 2) % NSLOT;
