@@ -257,16 +257,28 @@ __global__ __launch_bounds__(256) void flash_attn2_kernel(const bf16_t* __restri
   }
 
   u32x4 kr[KP], vr[KP];
+  const bf16_t* kptr[KP];
+  const long vdelta = Vb - Kb;  // V rows sit at a fixed distance from the K rows (same packed buffer / same strides)
+#pragma unroll
+  for (int i = 0; i < KP; ++i) kptr[i] = Kb + koff[i] + (long)kkey[i] * ldk;
   // (written as macros, not lambdas: arrays captured by reference in a lambda called from two sites were left in
   // scratch memory by the compiler)
 #define SVT_STAGE_LOAD(TILE)                                                          \
   {                                                                                   \
     const int key0_ = (TILE) * 64;                                                    \
-    _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                  \
-      int key_ = key0_ + kkey[i];                                                     \
-      if (key_ > T - 1) key_ = T - 1;                                                 \
-      kr[i] = *(const u32x4*)(Kb + koff[i] + (long)key_ * ldk);                       \
-      vr[i] = *(const u32x4*)(Vb + koff[i] + (long)key_ * ldk);                       \
+    if (key0_ + 64 <= T) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                \
+        kr[i] = *(const u32x4*)(kptr[i]);                                             \
+        vr[i] = *(const u32x4*)(kptr[i] + vdelta);                                    \
+        kptr[i] += 64 * ldk;                                                          \
+      }                                                                               \
+    } else {                                                                          \
+      _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                \
+        int key_ = key0_ + kkey[i];                                                   \
+        if (key_ > T - 1) key_ = T - 1;                                               \
+        kr[i] = *(const u32x4*)(Kb + koff[i] + (long)key_ * ldk);                     \
+        vr[i] = *(const u32x4*)(Vb + koff[i] + (long)key_ * ldk);                     \
+      }                                                                               \
     }                                                                                 \
   }
 #define SVT_STAGE_WRITE()                                                             \
@@ -318,13 +330,16 @@ __global__ __launch_bounds__(256) void flash_attn2_kernel(const bf16_t* __restri
     // taken on the raw scores, and the running max is only raised (O and l rescaled) when some row of the wave grew
     // by more than 2^8 (deferred rescale: P stays <= 256, exact in fp32 and safe in bf16); keys >= T are masked in
     // the last tile only.
-    if (tile * 64 + 64 > T) {
+    if (__builtin_expect(tile * 64 + 64 > T, 0)) {  // wave-uniform, last tile only
       const int kbase = tile * 64 + 4 * hh;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= T) s[kb][r] = -3e38f;
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+          asm volatile("" : "+v"(s[kb][r]));  // keep the masking inside this (rare) branch instead of 32 selects per tile
+          if (key >= T) s[kb][r] = -3e38f;
+        }
     }
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
