@@ -5,16 +5,19 @@
 //
 // Mapping (wave64, v_mfma_f32_32x32x16_bf16):
 //   * block = 4 waves = 128 queries of one (clip, head); each wave owns 32 queries for the whole sweep.
-//   * K and V^T tiles of 64 keys are staged global -> registers -> LDS in MFMA *fragment order* (every
-//     operand read is a linear 1 KiB ds_read_b128); next tile's global loads are issued before the
-//     current tile's MFMAs and written after them (one LDS buffer, two barriers per tile; several
-//     blocks per CU cover the rest of the latency).
+//   * K and V tiles of 64 keys are staged global -> registers -> LDS row-major with an XOR swizzle of the
+//     16-byte chunks (8 consecutive lanes fetch one 128-byte row: one request per line); next tile's global
+//     loads are issued before the current tile's MFMAs and written after them (one LDS buffer, two barriers
+//     per tile; several blocks per CU cover the rest of the latency).
 //   * S^T = K Q^T is computed with keys on the MFMA rows, so a lane holds 16 keys x 1 query per 32-key
 //     block: the row max / row sum are in-register reductions plus ONE cross-lane exchange
 //     (lane ^ 32).  The S accumulator, converted pairwise to bf16, is directly the B operand of
-//     O^T += V^T P^T (k order permuted consistently on the V^T side) — P never touches LDS.
-//   * V is consumed transposed (V^T (B,H,dh,Tp), zero padded to a multiple of 64 keys) so that the
-//     4-key runs of the permuted k order are contiguous 8-byte pieces.
+//     O^T += V^T P^T (k order permuted consistently on the V side) — P never touches LDS.
+//   * V is read TRANSPOSED out of its row-major LDS tile by ds_read_b64_tr_b16 (4 keys x 16 d blocks delivered
+//     column-major): the 4-key runs of the permuted k order are exactly two such blocks per operand, so no
+//     transposed copy of V ever exists in memory.
+//   * softmax: scale folded into the exponent FMA, running max raised only when a row grows by > 2^8 (deferred
+//     rescale), MFMA accumulators kept in VGPRs (-mllvm -amdgpu-mfma-vgpr-form, see Makefile).
 #include "common.h"
 
 namespace svt {
@@ -28,183 +31,6 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 template <int DH>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
-                                                         const bf16_t* __restrict__ K, long ldk, long k_bstride,
-                                                         const bf16_t* __restrict__ Vt, int Tp, bf16_t* __restrict__ O,
-                                                         long ldo, long o_bstride, int T, int H, float c) {
-  constexpr int KSD = DH / 16;   // k-steps over head_dim for S
-  constexpr int DB = DH / 32;    // 32-row blocks of O^T
-  constexpr int CPR = DH / 8;    // 16-byte chunks per K row
-  constexpr int KP = CPR / 4;    // K pieces per thread per tile (64 keys)
-  constexpr int VP = DH / 32;    // V^T pieces per thread per tile (DH rows x 8 chunks / 256)
-  __shared__ __attribute__((aligned(16))) uint4 Kf[2 * KSD * 64];
-  __shared__ __attribute__((aligned(16))) uint4 Vf[DB * 4 * 64];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
-  const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
-  const bf16_t* Vb = Vt + ((long)b * H + h) * DH * (long)Tp;
-
-  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + (lane&31)][ks*16 + 8*(lane>>5) .. +7]
-  bf16x8 qf[KSD];
-  {
-    int q = q0 + (lane & 31);
-    if (q > T - 1) q = T - 1;
-    const bf16_t* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
-#pragma unroll
-    for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-
-  // staging maps.  Global side: 8 (DH=64) / 16 (DH=128) consecutive lanes fetch the consecutive 16-byte chunks of ONE
-  // row, so the texture addresser issues one request per 128-byte line (a lane-per-row mapping costs one request
-  // per lane).  K tile in LDS: row-major [key][slot], slot = chunk ^ g(key) (g = (key>>1)&7 for 128-byte rows,
-  // key&15 for 256-byte rows) -> the 32x32x16 A-operand read (32 keys x one chunk) is a conflict-free ds_read_b128.
-  const bf16_t* ksrc[KP];
-  int kdst[KP], kkey[KP];
-#pragma unroll
-  for (int i = 0; i < KP; ++i) {
-    const int f = i * 256 + tid;
-    const int cc = f % CPR, kk = f / CPR;  // chunk, key in tile
-    ksrc[i] = Kb + cc * 8;                 // + key * ldk at load time (clamped)
-    kkey[i] = kk;
-    const int g = (DH == 64) ? ((kk >> 1) & 7) : (kk & 15);
-    kdst[i] = kk * CPR + (cc ^ g);
-  }
-  const bf16_t* vsrc[VP];
-  int vdst[VP];
-#pragma unroll
-  for (int i = 0; i < VP; ++i) {
-    const int f = i * 256 + tid;
-    const int cc = f & 7, d = f >> 3;      // 16-byte chunk (8 keys) of V^T row d
-    const int k0 = cc * 8;                 // key offset in tile
-    vsrc[i] = Vb + (long)d * Tp + k0;
-    // two 8-byte runs: keys k0..k0+3 -> lane half 0, k0+4..k0+7 -> lane half 1; jh = (k0 % 16) / 8
-    vdst[i] = (((d >> 5) * 4 + (k0 >> 4)) * 64 + (d & 31)) * 2 + ((k0 & 15) >> 3);  // in 8-byte units
-  }
-
-  uint4 kr[KP], vr[VP];
-  auto stage_load = [&](int tile) {
-    const int key0 = tile * 64;
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      int key = key0 + kkey[i];
-      if (key > T - 1) key = T - 1;
-      kr[i] = *(const uint4*)(ksrc[i] + (long)key * ldk);
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) vr[i] = *(const uint4*)(vsrc[i] + key0);
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int i = 0; i < KP; ++i) Kf[kdst[i]] = kr[i];
-    uint2* v2 = (uint2*)Vf;
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      v2[vdst[i]] = uint2{vr[i].x, vr[i].y};
-      v2[vdst[i] + 64] = uint2{vr[i].z, vr[i].w};  // lane + 32 -> +32 slots of 16 B = +64 units of 8 B
-    }
-  };
-
-  f32x16 o[DB];
-#pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m = -1e30f, l = 0.f;
-  const int hh = lane >> 5;
-  const int kl = lane & 31;                                     // key within a 32-key block
-  const int kg = (DH == 64) ? ((kl >> 1) & 7) : (kl & 15);      // its swizzle (same for both key blocks: 32 % 16 == 0)
-  const int ntiles = (T + 63) / 64;
-
-  stage_load(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();  // previous tile fully consumed
-    stage_write();
-    __syncthreads();
-    if (tile + 1 < ntiles) stage_load(tile + 1);
-
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KSD; ++ks)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb], 0, 0, 0);
-    }
-    // scaled log2 domain; mask keys >= T (only the last tile can have them)
-    const int kbase = tile * 64 + 4 * hh;
-    const bool tail = (tile * 64 + 64 > T);
-    float mx = -3e38f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = s[kb][r] * c;
-        if (tail) {
-          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= T) t = -3e38f;
-        }
-        s[kb][r] = t;
-        mx = fmaxf(mx, t);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mnew = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb][r] - mnew);
-        s[kb][r] = pv;
-        sum += pv;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    l = l * alpha + sum;
-    m = mnew;
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    // P (bf16) fragments straight from the S accumulators: k-step ss of key block kb = regs 8ss..8ss+7
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[kb][ss][j] = (bf16_t)s[kb][ss * 8 + j];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, Vf[(db * 4 + kb * 2 + ss) * 64 + lane]), pf[kb][ss], o[db], 0, 0, 0);
-  }
-
-  // O[q][d] = o / l ; lane (q = lane&31, hh) holds d = db*32 + (r&3) + 8*(r>>2) + 4*hh
-  const int q = q0 + (lane & 31);
-  if (q >= T) return;
-  const float inv = 1.f / l;
-  bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][g * 4 + j] * inv);
-      *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
-    }
-}
-
-template <int DH>
-__global__ __launch_bounds__(256) void flash_attn2_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
                                                          const bf16_t* __restrict__ K, long ldk, long k_bstride,
                                                          const bf16_t* __restrict__ V, int /*unused*/, bf16_t* __restrict__ O,
                                                          long ldo, long o_bstride, int T, int H, float c) {
@@ -416,30 +242,6 @@ __global__ __launch_bounds__(256) void flash_attn2_kernel(const bf16_t* __restri
 #undef SVT_STAGE_WRITE
 }  // namespace
 
-int launch_flash_attention_vt(const void* Q, long ldq, long q_bstride, const void* K, long ldk, long k_bstride,
-                           const void* Vt, int Tp, void* O, long ldo, long o_bstride, int B, int T, int H, int dh,
-                           float scale, hipStream_t s) {
-  if (Tp % 64 || Tp < T) { set_error("flash_attention: V^T must be padded to a multiple of 64 keys"); return -1; }
-  if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8) { set_error("flash_attention: strides must be multiples of 8"); return -1; }
-  const float c = scale * 1.44269504088896340736f;
-  dim3 grid((T + 127) / 128, H, B);
-  const double flops = 4.0 * B * H * (double)T * T * dh;
-  prof_begin(s);
-  if (dh == 64)
-    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
-                       ldk, k_bstride, (const bf16_t*)Vt, Tp, (bf16_t*)O, ldo, o_bstride, T, H, c);
-  else if (dh == 128)
-    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
-                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)Vt, Tp, (bf16_t*)O, ldo, o_bstride, T, H, c);
-  else { set_error("flash_attention: head_dim must be 64 or 128"); return -1; }
-  prof_end(s, flops, 0.0, 2);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
-}  // namespace svt
-
-namespace svt {
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s) {
@@ -449,10 +251,10 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   const double flops = 4.0 * B * H * (double)T * T * dh;
   prof_begin(s);
   if (dh == 64)
-    hipLaunchKernelGGL((flash_attn2_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+    hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
   else if (dh == 128)
-    hipLaunchKernelGGL((flash_attn2_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+    hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
   else { set_error("flash_attention: head_dim must be 64 or 128"); return -1; }
   prof_end(s, flops, 0.0, 2);

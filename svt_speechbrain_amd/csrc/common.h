@@ -135,9 +135,6 @@ int launch_transpose_v(int prec, const void* qkv, int B, int T, int H, int dh, l
                        void* Vt, hipStream_t s);
 
 // fused attention (bf16, head_dim 64/128): Q/K row-major with row strides ldq/ldk and per-clip strides, V^T padded
-int launch_flash_attention_vt(const void* Q, long ldq, long q_bstride, const void* K, long ldk, long k_bstride,
-                              const void* Vt, int Tp, void* O, long ldo, long o_bstride, int B, int T, int H, int dh,
-                              float scale, hipStream_t s);  // older variant: V pre-transposed
 // Q/K/V row-major (K and V share row / clip strides); V is transposed on the fly by ds_read_b64_tr_b16
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s);
