@@ -266,6 +266,174 @@ __global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
 }
 
 
+template <int BM>
+__global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
+  constexpr int BN = 256, BK = 64, NSLOT = 5;
+  constexpr int MB = BM / 32;
+  constexpr int GA = BM / 64;       // DMA instructions per wave per A unit (BM/8 groups over 8 waves)
+  constexpr int GW = BN / 64;       // per W unit
+  constexpr int SLOT = 2048;        // uint4 per slot (32 KiB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
+  const int z = blockIdx.y;
+  const int z1 = z / p.nz2, z2 = z % p.nz2;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
+  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
+
+  // coalesced + swizzled DMA source: 8 consecutive lanes fetch the 8 chunks of ONE 128-byte row (one line request
+  // instead of eight), lane (row r8 = l>>3, slot = l&7) takes chunk (slot ^ r8); the LDS image of a group is then
+  // row-major [row][slot] and the MFMA read of (row, chunk C) goes to slot C ^ row -> conflict-free ds_read_b128.
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
+  const bf16_t* asrc[GA];
+  const bf16_t* wsrc[GW];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    int m = m0 + (wave + 8 * i) * 8 + r8;
+    if (m > p.M - 1) m = p.M - 1;
+    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < GW; ++i) {
+    const int rho = (wave + 8 * i) * 8 + r8;
+    const int i16 = rho & 15;
+    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+    if (n > p.N - 1) n = p.N - 1;
+    wsrc[i] = W + (long)n * p.ldw + ch * 8;
+  }
+  // unit u: even -> A slab u/2, odd -> W slab u/2; slot u % 5
+  auto issue_a = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < GW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+  };
+
+  f32x4 acc[4][MB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cq = lane >> 4, r16 = lane & 15;
+  // uint4 index inside a slot of fragment (16-row block blk, k-step ks): group (2*blk + (r16>>3)) * 64 + row*8 + slot
+  const int rr8 = r16 & 7;
+  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
+  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
+  const int xoff = (wm * (MB * 2)) * 64;
+  const int woff = (wn * 8) * 64;
+
+  // Staggered quarter-phase schedule ("8-phase"): the slab is multiplied in four groups of 4 x MB/2 MFMAs, each preceded
+  // by a LOAD slot (its LDS fragment reads + two DMA instructions of the ring).  Slots are separated by raw barriers and
+  // waves 4-7 run one slot behind waves 0-3, so on every SIMD one wave is in an MFMA slot while its partner is in a
+  // LOAD slot: the matrix pipe never waits for LDS latency or DMA issue of its own wave.
+  const int nk = p.K / BK;
+  constexpr int HM = MB / 2;
+  bf16x8 wfr[4], xfr[HM];
+  const int grp = wave >> 2;
+  issue_a(0, 0);
+  issue_w(0, 1);
+  if (nk > 1) issue_a(1, 2);
+  if (nk > 1) wait_vm<GA>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  int sa = 0, sw = 1;
+#define SVT_LOAD(Q)                                                                                              \
+  {                                                                                                              \
+    constexpr int ks_ = (Q) >> 1, half_ = (Q)&1;                                                                 \
+    if (half_ == 0) {                                                                                            \
+      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) wfr[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks_ ? frag1 : frag0)]); \
+    }                                                                                                            \
+    _Pragma("unroll") for (int jj = 0; jj < HM; ++jj)                                                            \
+        xfr[jj] = __builtin_bit_cast(bf16x8, xa[(half_ * HM + jj) * 128 + (ks_ ? frag1 : frag0)]);               \
+    if (ks_ == 0) {                                                                                              \
+      if (kt + 1 < nk) {                                                                                         \
+        _Pragma("unroll") for (int i2 = half_ * 2; i2 < half_ * 2 + 2; ++i2)                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i2] + (kt + 1) * BK),                                 \
+                                             (lptr_t)(lds + ((2 * kt + 3) % NSLOT) * SLOT + (wave + 8 * i2) * 64), 16, 0, 0); \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      if (kt + 2 < nk) {                                                                                         \
+        _Pragma("unroll") for (int i2 = half_ * ((GA + 1) / 2); i2 < (half_ ? GA : (GA + 1) / 2); ++i2)          \
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i2] + (kt + 2) * BK),                                 \
+                                             (lptr_t)(lds + ((2 * kt + 4) % NSLOT) * SLOT + (wave + 8 * i2) * 64), 16, 0, 0); \
+      }                                                                                                          \
+    }                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  }
+#define SVT_MMA(Q)                                                                                               \
+  {                                                                                                              \
+    constexpr int half_ = (Q)&1;                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int jj = 0; jj < HM; ++jj)                                                            \
+      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                           \
+        acc[nb][half_ * HM + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nb], xfr[jj], acc[nb][half_ * HM + jj], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  }
+#define SVT_RETIRE_NEXT()                                                                                        \
+  {                                                                                                              \
+    if (kt + 2 < nk) wait_vm<GA>();                                                                              \
+    else if (kt + 1 < nk) wait_vm<0>();                                                                          \
+  }
+  if (grp == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint4* xa = lds + sa * SLOT + xoff;
+      const uint4* wa = lds + sw * SLOT + woff;
+      SVT_LOAD(0) __builtin_amdgcn_s_barrier(); SVT_MMA(0) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(1) __builtin_amdgcn_s_barrier(); SVT_MMA(1) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(2) __builtin_amdgcn_s_barrier(); SVT_MMA(2) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(3) __builtin_amdgcn_s_barrier(); SVT_MMA(3)
+      SVT_RETIRE_NEXT()
+      __builtin_amdgcn_s_barrier();
+      sa = (sa + 2) % NSLOT;
+      sw = (sw + 2) % NSLOT;
+    }
+  } else {
+    __builtin_amdgcn_s_barrier();  // one slot behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint4* xa = lds + sa * SLOT + xoff;
+      const uint4* wa = lds + sw * SLOT + woff;
+      SVT_LOAD(0) __builtin_amdgcn_s_barrier(); SVT_MMA(0) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(1) __builtin_amdgcn_s_barrier(); SVT_MMA(1) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(2) __builtin_amdgcn_s_barrier(); SVT_MMA(2) __builtin_amdgcn_s_barrier();
+      SVT_LOAD(3)
+      SVT_RETIRE_NEXT()
+      __builtin_amdgcn_s_barrier();
+      SVT_MMA(3)
+      if (kt + 1 < nk) __builtin_amdgcn_s_barrier();
+      sa = (sa + 2) % NSLOT;
+      sw = (sw + 2) % NSLOT;
+    }
+  }
+#undef SVT_LOAD
+#undef SVT_MMA
+#undef SVT_RETIRE_NEXT
+  // ---- epilogue ----
+  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
+  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
+  __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
+  if (p.dbg != 3)
+    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
+  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Persistent variant of the unit-ring kernel.  One workgroup per CU walks a list of output tiles; the
 // (tile, k-slab) pairs form ONE stream for the LDS-DMA ring, so the first slabs of tile i+1 are already
@@ -533,6 +701,26 @@ int launch_pers(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int BM>
+int launch_pp8(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  dim3 grid(tiles_m * tiles_n, a.nz, 1);
+  const size_t lds_bytes = 5 * 32768;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes));
+    attr_set = true;
+  }
+  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
+  prof_begin(s);
+  hipLaunchKernelGGL((gemm_pp8_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
+  prof_end(s, flops, bytes, 0);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BM>
 int launch_uring(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
@@ -590,6 +778,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     return launch_pers<64>(a, s);
   }
   if (best == 64) best = 128;
+  if (mode == 8) {
+    if (best == 256) return launch_pp8<256>(a, s);
+    if (best == 192) return launch_pp8<192>(a, s);
+    return launch_pp8<128>(a, s);
+  }
   if (best == 256) return launch_uring<256>(a, s);
   if (best == 192) return launch_uring<192>(a, s);
   return launch_uring<128>(a, s);
