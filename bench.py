@@ -201,9 +201,9 @@ def main():
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
-            # dominant kernel = svt::gemm_uring_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
+            # dominant kernel = svt::gemm_pp8_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
             # launches / HIP-event time of those launches on their stream, over the timed region
-            "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_uring_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, persistent or one tile per workgroup)",
+            "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, persistent or one tile per workgroup)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "launches": int(n_l), "avg_launch_ms": round(ms / max(1, n_l), 5),

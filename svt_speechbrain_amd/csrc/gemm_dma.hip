@@ -11,7 +11,7 @@
 //     (row, chunk C) at slot C ^ row is a conflict-free ds_read_b128.
 //   * W rows are fetched in MFMA order, permuted (free with per-lane DMA source addresses) so a lane ends up with
 //     16 consecutive output columns of one row.
-//   * two kernels share this pipeline: gemm_uring_kernel (one tile per workgroup, LDS-transposed coalesced epilogue)
+//   * two kernels share this pipeline: gemm_pp8_kernel (one tile per workgroup, LDS-transposed coalesced epilogue)
 //     and gemm_pers_kernel (one workgroup per CU walks a tile list; the next tile's fills and the epilogue stores
 //     overlap the MFMAs).  launch_gemm_dma picks BM in {128,192,256} and the kernel per problem.
 #include "common.h"
@@ -144,128 +144,9 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmArgs& p, f32x4 (&ac
 }
 
 // ---------------------------------------------------------------------------------------------
-// Unit-ring variant: the LDS is a ring of 5 slots of 32 KiB; units alternate A-slab / W-slab of the
-// same 64-deep K step (A_0 W_0 A_1 W_1 ...), each filled by full-line LDS-DMA (8 rows x 128 B per
-// wave-instruction).  While slab j is multiplied, units A_{j+1}, W_{j+1}, A_{j+2} are in flight; a
-// counted vmcnt lets the youngest unit stay in flight across the single raw barrier of the step.
-template <int BM>
-__global__ __launch_bounds__(512) void gemm_uring_kernel(GemmArgs p) {
-  constexpr int BN = 256, BK = 64, NSLOT = 5;
-  constexpr int MB = BM / 32;
-  constexpr int GA = BM / 64;       // DMA instructions per wave per A unit (BM/8 groups over 8 waves)
-  constexpr int GW = BN / 64;       // per W unit
-  constexpr int SLOT = 2048;        // uint4 per slot (32 KiB)
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int z = blockIdx.y;
-  const int z1 = z / p.nz2, z2 = z % p.nz2;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const bf16_t* A = (const bf16_t*)p.A + (z1 * p.a_z1 + z2 * p.a_z2);
-  const bf16_t* W = (const bf16_t*)p.W + (z1 * p.w_z1 + z2 * p.w_z2);
-
-  // coalesced + swizzled DMA source: 8 consecutive lanes fetch the 8 chunks of ONE 128-byte row (one line request
-  // instead of eight), lane (row r8 = l>>3, slot = l&7) takes chunk (slot ^ r8); the LDS image of a group is then
-  // row-major [row][slot] and the MFMA read of (row, chunk C) goes to slot C ^ row -> conflict-free ds_read_b128.
-  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
-  const bf16_t* asrc[GA];
-  const bf16_t* wsrc[GW];
-#pragma unroll
-  for (int i = 0; i < GA; ++i) {
-    int m = m0 + (wave + 8 * i) * 8 + r8;
-    if (m > p.M - 1) m = p.M - 1;
-    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < GW; ++i) {
-    const int rho = (wave + 8 * i) * 8 + r8;
-    const int i16 = rho & 15;
-    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
-    if (n > p.N - 1) n = p.N - 1;
-    wsrc[i] = W + (long)n * p.ldw + ch * 8;
-  }
-  // unit u: even -> A slab u/2, odd -> W slab u/2; slot u % 5
-  auto issue_a = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
-  };
-  auto issue_w = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < GW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
-  };
-
-  f32x4 acc[4][MB];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int cq = lane >> 4, r16 = lane & 15;
-  // uint4 index inside a slot of fragment (16-row block blk, k-step ks): group (2*blk + (r16>>3)) * 64 + row*8 + slot
-  const int rr8 = r16 & 7;
-  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
-  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
-  const int xoff = (wm * (MB * 2)) * 64;
-  const int woff = (wn * 8) * 64;
-
-  const int nk = p.dbg == 4 ? 1 : p.K / BK;
-  issue_a(0, 0);
-  issue_w(0, 1);
-  if (nk > 1) issue_a(1, 2);
-  int sa = 0, sw = 1;  // slots of the current slab's A and W units
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wait_vm<GA>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    // units 2kt+3 (W of slab kt+1) and 2kt+4 (A of slab kt+2) go to the two slots freed by slab kt-1; the W unit is
-    // issued before the first k-step's LDS reads, the A unit before the second's (spreads the VMEM issue).
-    const uint4* xa = lds + sa * SLOT + xoff;
-    const uint4* wa = lds + sw * SLOT + woff;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (p.dbg != 1) {
-        if (ks == 0) { if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT); }
-        else { if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT); }
-      }
-      if (p.dbg != 2) {
-        bf16x8 wf[4], xf[MB];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) wf[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) xf[mb] = __builtin_bit_cast(bf16x8, xa[mb * 128 + (ks ? frag1 : frag0)]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb)
-            acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-    sa = (sa + 2) % NSLOT;
-    sw = (sw + 2) % NSLOT;
-  }
-  // ---- epilogue ----
-  const long coff = z1 * p.c_z1 + z2 * p.c_z2;
-  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
-  if (p.dbg != 3)
-    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
-  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
-}
-
-
+// One tile per workgroup.  The LDS is a ring of 5 slots of 32 KiB; units alternate A-slab / W-slab of the same
+// 64-deep K step (A_0 W_0 A_1 W_1 ...), each filled by full-line LDS-DMA (8 rows x 128 B per wave-instruction).
+// While slab j is multiplied, units A_{j+1}, W_{j+1}, A_{j+2} are in flight, retired by a counted vmcnt.
 template <int BM>
 __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
@@ -720,26 +601,6 @@ int launch_pp8(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int BM>
-int launch_uring(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
-  dim3 grid(tiles_m * tiles_n, a.nz, 1);
-  const size_t lds_bytes = 5 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_uring_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
-  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL((gemm_uring_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
-  prof_end(s, flops, bytes, 0);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128 && a.c_vec && a.N % 8 == 0; }
@@ -750,7 +611,7 @@ bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 &
 // one-tile-per-workgroup kernel, whose LDS-transposed epilogue stores whole 128-byte lines.
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
-int g_gemm_ring = 0;  // 0 = auto; 2 = force one-tile-per-workgroup kernel, 4 = force persistent kernel (diagnostics)
+int g_gemm_ring = 0;  // 0 = auto; 2 = force the one-tile-per-workgroup kernel, 4 = force the persistent kernel (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   a.dbg = g_gemm_dbg;
@@ -778,14 +639,9 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     return launch_pers<64>(a, s);
   }
   if (best == 64) best = 128;
-  if (mode == 8) {
-    if (best == 256) return launch_pp8<256>(a, s);
-    if (best == 192) return launch_pp8<192>(a, s);
-    return launch_pp8<128>(a, s);
-  }
-  if (best == 256) return launch_uring<256>(a, s);
-  if (best == 192) return launch_uring<192>(a, s);
-  return launch_uring<128>(a, s);
+  if (best == 256) return launch_pp8<256>(a, s);
+  if (best == 192) return launch_pp8<192>(a, s);
+  return launch_pp8<128>(a, s);
 }
 
 }  // namespace svt
