@@ -160,6 +160,13 @@ int svt_debug_gemm(int32_t precision, const void* a_dev, const void* w_dev, void
 
 /* diagnostic knobs for tools/gemm_bench.py: key 0 = kernel variant (0 normal, 1 no DMA after prologue, 2 no MFMA),
  * key 1 = force the M tile (0 auto, 128/192/256).  Never set in the product path. */
+/* Fused attention kernel alone (bf16, head_dim 64 or 128): o[b,t,h*dh+d] = softmax(scale q k^T) v with q rows at
+ * q + (b*t_len + t)*ldq + h*dh, k / v rows likewise with ldkv, o with ldo (element strides).  Replaces the eager
+ * attention of transformers' Wav2Vec2Attention / torch.nn.MultiheadAttention inside the encoder and the RCA layers
+ * (N20EMv2/audio_visual/fusion.py:102-117); exposed for the parity tests and tools/attn_bench.py. */
+int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
+                        int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
+                        void* stream);
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

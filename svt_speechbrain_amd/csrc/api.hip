@@ -271,10 +271,24 @@ int svt_debug_gemm(int32_t precision, const void* a, const void* w, void* c, con
   return launch_gemm(precision, g, (hipStream_t)stream) ? SVT_ERR_INVALID : SVT_OK;
 }
 
+int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
+                        int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
+                        void* stream) {
+  if (!q || !k || !v || !o) { set_error("svt_debug_attention: null argument"); return SVT_ERR_INVALID; }
+  if (precision != 1 || !(head_dim == 64 || head_dim == 128)) {
+    set_error("svt_debug_attention: only the fused bf16 kernel (head_dim 64 / 128) is exposed"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  if (launch_flash_attention(q, ldq, (long)t * ldq, k, v, ldkv, (long)t * ldkv, o, ldo, (long)t * ldo, batch, t, heads,
+                             head_dim, scale, (hipStream_t)stream)) return SVT_ERR_INVALID;
+  return SVT_OK;
+}
+
 int svt_debug_set(int key, int value) {
   if (key == 0) g_gemm_dbg = value;
   else if (key == 1) g_gemm_force_bm = value;
   else if (key == 2) g_gemm_ring = value;
+  else if (key == 3) g_gemm_variant = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -757,6 +771,7 @@ int svt_linear_forward(svt_linear* l, const float* x, int64_t rows, float* y, vo
   hipStream_t s = (hipStream_t)stream;
   SVT_HIP(hipSetDevice(l->device));
   const float* b = l->has_bias ? l->b.as<float>() : nullptr;
+  if (linear_head_eligible(l->in_f, l->out_f)) return launch_linear_head(x, rows, l->in_f, l->w.as<float>(), b, l->out_f, y, s);
   if (l->in_f % 4) {
     if (l->out_f <= 32) return launch_linear_f32(x, rows, l->in_f, l->w.as<float>(), b, l->out_f, y, s); set_error("svt_linear_forward: in_features must be a multiple of 4 for out_features > 32"); return SVT_ERR_INVALID; }
   if (rows > 2147483647LL) { set_error("svt_linear_forward: too many rows"); return SVT_ERR_INVALID; }

@@ -45,6 +45,59 @@ __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
   const f32x2_t sg = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
   return hx * sg + hx;
 }
+// GELU for results that are stored as bf16 (the LDS-DMA contraction kernels' epilogues: conv 1-6, FFN-1): erf by an
+// odd degree-17 polynomial on |z| <= 3 (z = x / sqrt 2), saturated outside -- no transcendental issue slots (rcp / exp
+// are quarter rate), 17 issue slots per PAIR instead of ~33.  |error| <= 1.5e-4 absolute, <= 4e-5 relative for
+// x > 0.01: 50x below the bf16 rounding of the stored value (2^-9 relative).  fp32 outputs keep gelu_fast.
+__device__ __forceinline__ f32x2_t gelu_bf16x2(f32x2_t x) {
+  f32x2_t z = x * 0.70710678118654752440f;
+  z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
+  z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
+  const f32x2_t u = z * z;
+  f32x2_t q = u * 4.074456683e-08f + (-1.944940095e-06f);
+  q = q * u + 4.106299457e-05f;
+  q = q * u + (-5.110675702e-04f);
+  q = q * u + 4.235681612e-03f;
+  q = q * u + (-2.510436811e-02f);
+  q = q * u + 1.110860035e-01f;
+  q = q * u + (-3.753373921e-01f);
+  q = q * u + 1.128336072e+00f;
+  f32x2_t pe = z * q;
+  pe.x = __builtin_amdgcn_fmed3f(pe.x, -1.0f, 1.0f);
+  pe.y = __builtin_amdgcn_fmed3f(pe.y, -1.0f, 1.0f);
+  const f32x2_t hx = x * 0.5f;
+  return hx * pe + hx;
+}
+// four pairs at once, Horner steps interleaved across the pairs: hipcc otherwise emits the four dependent chains one
+// after the other (a v_pk_fma every ~8 cycles behind an s_nop), i.e. latency-bound with ILP 1
+__device__ __forceinline__ void gelu_bf16x2_x4(f32x2_t (&x)[4]) {
+  f32x2_t z[4], u[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    z[i] = x[i] * 0.70710678118654752440f;
+    z[i].x = __builtin_amdgcn_fmed3f(z[i].x, -3.0f, 3.0f);
+    z[i].y = __builtin_amdgcn_fmed3f(z[i].y, -3.0f, 3.0f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = z[i] * z[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = u[i] * 4.074456683e-08f + (-1.944940095e-06f);
+  constexpr float c[7] = {4.106299457e-05f, -5.110675702e-04f, 4.235681612e-03f, -2.510436811e-02f,
+                          1.110860035e-01f, -3.753373921e-01f, 1.128336072e+00f};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = q[i] * u[i] + c[k];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2_t pe = z[i] * q[i];
+    pe.x = __builtin_amdgcn_fmed3f(pe.x, -1.0f, 1.0f);
+    pe.y = __builtin_amdgcn_fmed3f(pe.y, -1.0f, 1.0f);
+    const f32x2_t hx = x[i] * 0.5f;
+    x[i] = hx * pe + hx;
+  }
+}
 #endif
 
 void set_error(const std::string& msg);
@@ -80,6 +133,7 @@ struct GemmArgs {
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
+  long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
 };
 
 // operand type: 0 = fp32 (v_mfma_f32_16x16x4_f32, exact fp32 fma chain), 1 = bf16 (v_mfma_f32_16x16x32_bf16)
@@ -91,6 +145,7 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
 extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debug_set)
 extern int g_gemm_force_bm;
 extern int g_gemm_ring;
+extern int g_gemm_variant;  // diagnostics: replaces dbg inside the kernel while the trace pointer stays set
 
 // ---- profiling of the dominant kernel (bench.py roofline leg) ----
 void prof_begin(hipStream_t s);
@@ -149,6 +204,9 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
 // frame head (fp32 GEMV, N small) and per-frame decode
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
                       hipStream_t s);
+// frame head for K in {512,768,1024}, N <= 32: weight in LDS, four rows per wave (HBM-bound)
+bool linear_head_eligible(int K, int N);
+int launch_linear_head(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y, hipStream_t s);
 struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };
 int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
                          hipStream_t s);

@@ -102,11 +102,14 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bb[j], p.act) + rr[j];
           } else if (p.act == ACT_GELU) {
+            f32x2_t g[4];
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              const f32x2_t g = gelu_fast2(f32x2_t{v[j] + bb[j], v[j + 1] + bb[j + 1]});
-              v[j] = g.x;
-              v[j + 1] = g.y;
+            for (int j = 0; j < 4; ++j) g[j] = f32x2_t{v[2 * j] + bb[2 * j], v[2 * j + 1] + bb[2 * j + 1]};
+            gelu_bf16x2_x4(g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] = g[j].x;
+              v[2 * j + 1] = g[j].y;
             }
           } else {
 #pragma unroll
@@ -227,11 +230,15 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   constexpr int HM = MB / 2;
   bf16x8 wfr[4], xfr[HM];
   const int grp = wave >> 2;
+  const bool tr = p.trace != nullptr;
+  long long t_begin = 0, t_first = 0, t_main = 0;
+  if (tr) t_begin = wall_clock64();
   issue_a(0, 0);
   issue_w(0, 1);
   if (nk > 1) issue_a(1, 2);
   if (nk > 1) wait_vm<GA>(); else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+  if (tr) t_first = wall_clock64();
   int sa = 0, sw = 1;
 #define SVT_LOAD(Q)                                                                                              \
   {                                                                                                              \
@@ -308,10 +315,15 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   // ---- epilogue ----
   const long coff = z1 * p.c_z1 + z2 * p.c_z2;
   const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
+  if (tr) t_main = wall_clock64();
   __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
   if (p.dbg != 3)
     epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
   else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
+  if (tr && lane == 0 && (wave & 3) == 0) {
+    long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
+    o[0] = t_begin; o[1] = t_first; o[2] = t_main - t_first; o[3] = wall_clock64() - t_main; o[4] = wall_clock64(); o[5] = 1;
+  }
 }
 
 
@@ -401,6 +413,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
   const int xoff = (wm * (MB * 2)) * 64;
   const int woff = (wn * 8) * 64;
 
+  const bool tr = p.trace != nullptr;
+  long long t_begin = 0, t_first = 0, t_main = 0, t_epi = 0, t_mark = 0;
+  if (tr) t_begin = wall_clock64();
   const int nk = p.K / BK;            // >= 2 (checked by the launcher)
   const int G = my_tiles * nk;        // slabs in this workgroup's stream
   int ti = 0;                         // index of the tile being multiplied
@@ -426,6 +441,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
     }
     after_epilogue = false;
     __builtin_amdgcn_s_barrier();
+    if (tr && g == 0) t_first = t_mark = wall_clock64();
     const uint4* xa = lds + sa * SLOT + xoff;
     const uint4* wa = lds + sw * SLOT + woff;
     const bool have_w = g + 1 < G, have_a = g + 2 < G;
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
     if (++kt == nk) {
       // ---- epilogue of tile ti (registers -> global, bounds-checked buffer stores) ----
       kt = 0;
+      if (tr) { const long long t = wall_clock64(); t_main += t - t_mark; t_mark = t; }
       const int logical = ti * nblk + lbase;
       const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
       const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -524,13 +541,17 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
           for (int h = 0; h < 2; ++h) {
             bf16x8 o;
             if (p.act == ACT_GELU) {
+              f32x2_t g[4];
 #pragma unroll
-              for (int j = 0; j < 8; j += 2) {
-                const int n0r = h * 8 + j, n1r = n0r + 1;
-                const f32x2_t g = gelu_fast2(f32x2_t{acc[n0r >> 2][mb][n0r & 3] * p.alpha + bv[n0r],
-                                                     acc[n1r >> 2][mb][n1r & 3] * p.alpha + bv[n1r]});
-                o[j] = (bf16_t)g.x;
-                o[j + 1] = (bf16_t)g.y;
+              for (int j = 0; j < 4; ++j) {
+                const int n0r = h * 8 + 2 * j, n1r = n0r + 1;
+                g[j] = f32x2_t{acc[n0r >> 2][mb][n0r & 3] * p.alpha + bv[n0r], acc[n1r >> 2][mb][n1r & 3] * p.alpha + bv[n1r]};
+              }
+              gelu_bf16x2_x4(g);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                o[2 * j] = (bf16_t)g[j].x;
+                o[2 * j + 1] = (bf16_t)g[j].y;
               }
             } else {
 #pragma unroll
@@ -539,7 +560,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
                 o[j] = (bf16_t)apply_act(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr], p.act);
               }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), crsrc, off + h * 16, 0, 0);
+            if (p.dbg != 10) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), crsrc, off + h * 16, 0, 0);
+            else asm volatile("" ::"v"(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o)));
           }
         }
       }
@@ -547,6 +569,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tr) { const long long t = wall_clock64(); t_epi += t - t_mark; t_mark = t; }
       after_epilogue = true;
       ++ti;
       // rotate the pointer sets: next tile becomes current, precompute the one after
@@ -554,10 +577,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
       for (int i = 0; i < GA; ++i) asrc[i] = asrc2[i];
 #pragma unroll
       for (int i = 0; i < GW; ++i) wsrc[i] = wsrc2[i];
-      if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, asrc2, wsrc2);
+      if (ti + 1 < my_tiles && p.dbg != 11) setup((ti + 1) * nblk + lbase, asrc2, wsrc2);
     }
   }
   (void)n_store;
+  if (tr && lane == 0 && (wave & 3) == 0) {
+    wait_vm<0>();
+    long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
+    o[0] = t_begin; o[1] = t_first; o[2] = t_main; o[3] = t_epi; o[4] = wall_clock64(); o[5] = my_tiles;
+  }
 }
 
 template <int BM>
@@ -611,10 +639,12 @@ bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 &
 // one-tile-per-workgroup kernel, whose LDS-transposed epilogue stores whole 128-byte lines.
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
+int g_gemm_variant = 0;
 int g_gemm_ring = 0;  // 0 = auto; 2 = force the one-tile-per-workgroup kernel, 4 = force the persistent kernel (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   a.dbg = g_gemm_dbg;
+  if (a.dbg == 9) { a.trace = (long long*)a.resid; a.resid = nullptr; if (g_gemm_variant) a.dbg = g_gemm_variant; }
   const int tiles_n = (a.N + 255) / 256;
   const int cands[3] = {256, 192, 128};
   long best_cost = -1;

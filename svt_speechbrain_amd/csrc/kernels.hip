@@ -481,6 +481,63 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* x, int64
   }
 }
 
+// Frame head for the encoder widths (K = 256 * KC): the N x K weight is staged once per workgroup in LDS, a wave
+// handles four rows at a time (x read once from HBM with 16-byte accesses, every weight fragment reused by the four
+// rows), and the 4 x N partial sums are folded across the wave with a halving exchange (7 shuffles per output column
+// instead of 24).  HBM-bound: rows * K * 4 bytes in, rows * N * 4 bytes out.
+template <int KC>
+__global__ __launch_bounds__(256) void linear_head_kernel(const float* __restrict__ x, int64_t rows,
+                                                          const float* __restrict__ w, const float* __restrict__ b, int N,
+                                                          float* __restrict__ y) {
+  constexpr int K = KC * 256;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  for (int i = threadIdx.x * 4; i < N * K; i += 1024) *(float4*)(wl + i) = *(const float4*)(w + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+  const int myrow = (hi32 ? 2 : 0) + (hi16 ? 1 : 0);
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
+    float4 xv[4][KC];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t row = r0 + rr < rows ? r0 + rr : rows - 1;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) xv[rr][c] = *(const float4*)(x + row * K + c * 256 + lane * 4);
+    }
+    float out0 = 0.f, out1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float4 wv = *(const float4*)(wl + n * K + c * 256 + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          s[rr] = fmaf(xv[rr][c].x, wv.x, s[rr]);
+          s[rr] = fmaf(xv[rr][c].y, wv.y, s[rr]);
+          s[rr] = fmaf(xv[rr][c].z, wv.z, s[rr]);
+          s[rr] = fmaf(xv[rr][c].w, wv.w, s[rr]);
+        }
+      }
+      // lanes 0-31 end up with rows {0,1}, lanes 32-63 with rows {2,3}; then bit 4 of the lane picks the row
+      float k0 = hi32 ? s[2] : s[0], k1 = hi32 ? s[3] : s[1];
+      const float g0 = hi32 ? s[0] : s[2], g1 = hi32 ? s[1] : s[3];
+      k0 += __shfl_xor(g0, 32, 64);
+      k1 += __shfl_xor(g1, 32, 64);
+      float v = hi16 ? k1 : k0;
+      v += __shfl_xor(hi16 ? k0 : k1, 16, 64);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((lane & 15) == (n & 15)) { if (n < 16) out0 = v; else out1 = v; }
+    }
+    const int64_t row = r0 + myrow;
+    if (row < rows) {
+      const int n0 = lane & 15;
+      if (n0 < N) y[row * N + n0] = out0 + (b ? b[n0] : 0.f);
+      if (n0 + 16 < N) y[row * N + n0 + 16] = out1 + (b ? b[n0 + 16] : 0.f);
+    }
+  }
+}
+
 __global__ void decode_frames_kernel(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls,
                                      FrameOut* out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -792,6 +849,30 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
   hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
   SVT_LAUNCH_CHECK();
   return 0;
+}
+
+template <int KC>
+static int launch_linear_head_kc(const float* x, int64_t rows, const float* w, const float* b, int N, float* y, hipStream_t s) {
+  const size_t lds = (size_t)N * KC * 256 * 4;
+  static size_t attr = 0;
+  if (lds > 65536 && lds > attr) {
+    SVT_HIP(hipFuncSetAttribute((const void*)linear_head_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  const int64_t groups = (rows + 15) / 16;
+  const unsigned grid = (unsigned)(groups < 512 ? groups : 512);
+  hipLaunchKernelGGL((linear_head_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, b, N, y);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+bool linear_head_eligible(int K, int N) { return N >= 1 && N <= 32 && (K == 512 || K == 768 || K == 1024); }
+int launch_linear_head(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y, hipStream_t s) {
+  if (K == 512) return launch_linear_head_kc<2>(x, rows, w, b, N, y, s);
+  if (K == 768) return launch_linear_head_kc<3>(x, rows, w, b, N, y, s);
+  if (K == 1024) return launch_linear_head_kc<4>(x, rows, w, b, N, y, s);
+  set_error("linear_head: unsupported K");
+  return -1;
 }
 
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,

@@ -168,6 +168,23 @@ def test_linear_general_and_head():
     assert (nb.to(DEV)(x.to(DEV)).cpu() - x @ nb.w.weight.detach().cpu().t()).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("n_in", [512, 768, 1024])
+def test_frame_head_kernel_rows_and_widths(n_in):
+    # the LDS-resident frame-head kernel (K in {512,768,1024}, N <= 32): row counts around its 4-rows-per-wave /
+    # 16-rows-per-workgroup blocking and output widths around the 16-lane result packing
+    g = torch.Generator().manual_seed(n_in)
+    for n_out in (1, 15, 16, 17, 20, 32):
+        lin = S.Linear(n_out, input_size=n_in)
+        wt, bs = lin.w.weight.detach().cpu().double(), lin.w.bias.detach().cpu().double()
+        dl = lin.to(DEV)
+        for rows in (1, 3, 4, 5, 16, 17, 8191 + 16 * 512):
+            x = torch.randn(rows, n_in, generator=g)
+            ref = torch.nn.functional.linear(x.double(), wt, bs).float()
+            out = dl(x.to(DEV)).cpu()
+            assert out.shape == ref.shape
+            assert (out - ref).abs().max() < 2e-5, (n_in, n_out, rows)
+
+
 def test_decode_frames_first_max_and_sigmoid():
     lg = torch.zeros(4, 20)
     lg[0, 2:7] = torch.tensor([1.0, 3.0, 3.0, 0.0, -1.0])  # tie -> first max (index 1)

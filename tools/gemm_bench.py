@@ -24,7 +24,7 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
 ]
 
 
-def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0):
+def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nobias=False):
     lib = _lib.load()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if prec else torch.float32
@@ -40,12 +40,14 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0):
     W = ((torch.rand(N, K + (0 if conv else pad), generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
     ldw = W.shape[1]
     bias = torch.randn(N, generator=g).to(dev)
+    if nobias:
+        bias.zero_()
     R = torch.randn(M, N, generator=g).to(dev) if resid else None
     C = torch.empty(M, N, device=dev, dtype=torch.float32 if (out_f32 or not prec) else dt)
     st_ = torch.cuda.current_stream().cuda_stream
 
     def call():
-        _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(),
+        _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), None if nobias else bias.data_ptr(),
                                       R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, ldw, act, out_f32, 0, st_),
                    "svt_debug_gemm")
 
@@ -90,6 +92,7 @@ if __name__ == "__main__":
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--nobias", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
@@ -98,4 +101,4 @@ if __name__ == "__main__":
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
-        run(*s, a.prec, a.check, a.iters, a.pad)
+        run(*s, a.prec, a.check, a.iters, a.pad, a.nobias)

@@ -1,0 +1,79 @@
+"""Per-workgroup phase timeline of the LDS-DMA dense-contraction kernels (dbg = 9: the kernels stamp s_memrealtime,
+100 MHz, at entry / first slab / tile ends / exit; the `resid` argument carries the trace buffer).
+Usage: python tools/gemm_trace.py [--only qkv] [--ring 2|4] [--bm N]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+from svt_speechbrain_amd import _lib  # noqa: E402
+from gemm_bench import SHAPES  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="qkv")
+    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--bm", type=int, default=0)
+    ap.add_argument("--nobias", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="extra diagnostic variant: 10 = no stores, 11 = no pointer setup")
+    a = ap.parse_args()
+    lib = _lib.load()
+    lib.svt_debug_set(1, a.bm)
+    lib.svt_debug_set(2, a.ring)
+    dev = torch.device("cuda:0")
+    for name, M, N, K, conv, act, out_f32, resid in SHAPES:
+        if a.only not in name:
+            continue
+        g = torch.Generator().manual_seed(1)
+        if conv:
+            T_in, T_out, st, cin = conv
+            B = M // T_out
+            A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(dev, torch.bfloat16)
+            rpb, bstr, rstr = T_out, T_in * cin, st * cin
+        else:
+            A = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, torch.bfloat16)
+            rpb, bstr, rstr = M, 0, K
+        W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(dev)
+        C = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        trace = torch.zeros(65536 * 16, dtype=torch.int64, device=dev)
+        st_ = torch.cuda.current_stream().cuda_stream
+
+        def call(dbg):
+            lib.svt_debug_set(0, dbg)
+            _lib.check(lib.svt_debug_gemm(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None if a.nobias else bias.data_ptr(),
+                                          trace.data_ptr() if dbg == 9 else None, M, N, K, rpb, bstr, rstr, W.shape[1], act,
+                                          out_f32, 0, st_), "svt_debug_gemm")
+        for _ in range(3):
+            call(0)
+        torch.cuda.synchronize()
+        call(9)
+        torch.cuda.synchronize()
+        if a.variant:
+            # the trace pointer travels in `resid`, the variant in dbg: dbg 9 is needed for the trace, so the library
+            # treats key 3 as "extra variant while tracing"
+            lib.svt_debug_set(3, a.variant)
+            call(9)
+            torch.cuda.synchronize()
+            lib.svt_debug_set(3, 0)
+        t = trace.view(-1, 8).cpu()
+        t = t[t[:, 5] > 0].double()
+        t0 = t[:, 0].min()
+        us = 0.01
+        span = (t[:, 4].max() - t0) * us
+        print(f"{name}: {t.shape[0]} wave-records, kernel span {span:.1f} us")
+        print(f"  entry skew  (begin - first begin): mean {((t[:,0]-t0)*us).mean():.2f}  max {((t[:,0]-t0)*us).max():.2f} us")
+        print(f"  prologue    (first slab ready)   : mean {((t[:,1]-t[:,0])*us).mean():.2f}  max {((t[:,1]-t[:,0])*us).max():.2f} us")
+        print(f"  main loop   (sum over tiles)     : mean {(t[:,2]*us).mean():.2f}  max {(t[:,2]*us).max():.2f} us   per tile {(t[:,2]/t[:,5]*us).mean():.2f}")
+        print(f"  epilogue    (sum over tiles)     : mean {(t[:,3]*us).mean():.2f}  max {(t[:,3]*us).max():.2f} us   per tile {(t[:,3]/t[:,5]*us).mean():.2f}")
+        print(f"  exit        (end - first begin)  : mean {((t[:,4]-t0)*us).mean():.2f}  min {((t[:,4]-t0)*us).min():.2f} max {((t[:,4]-t0)*us).max():.2f} us")
+        print(f"  tiles per workgroup: min {int(t[:,5].min())} max {int(t[:,5].max())}")
+        lib.svt_debug_set(0, 0)
+
+
+if __name__ == "__main__":
+    main()
