@@ -182,6 +182,19 @@ def main():
         n_l, ms, fl, _ = k_dom
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         flops_clip = cfg.flops_per_clip(L)
+        # HBM bytes per launch of the dominant kernel family from the committed PMC passes (separate rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 read correction applied: tools/pmc_summary.py);
+        # null when that file is absent or the workload is not the default one
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_file) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
+            try:
+                pm = json.load(open(pmc_file))
+                fam = [v for k, v in pm.items() if k.startswith("gemm_pers_kernel") or k.startswith("gemm_pp8_kernel")]
+                tot_n = sum(v["launches"] for v in fam)
+                traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
+            except Exception:
+                traffic = None
         res = {
             "metric": "10s@16kHz clips/sec encoder+CTC forward, wav2vec2-base, 1/2/4/8 MI355X",
             "value": round(clips_per_s, 3),
@@ -205,7 +218,9 @@ def main():
             # launches / HIP-event time of those launches on their stream, over the timed region
             "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, persistent or one tile per workgroup)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_unit": "GB of HBM traffic per launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
+                         "algorithmic_gb_per_launch": round(k_dom[3] / max(1, n_l) / 1e9, 4),
                          "launches": int(n_l), "avg_launch_ms": round(ms / max(1, n_l), 5),
                          "ms_per_step": round(ms / args.steps, 4),
                          "flops_per_launch_avg": round(fl / max(1, n_l), 1),

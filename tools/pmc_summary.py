@@ -1,11 +1,49 @@
-import csv, glob, sys, collections
-d = sys.argv[1]
-for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
-    rows = list(csv.DictReader(open(f)))
+"""Summarise rocprofv3 --pmc passes (one directory per pass) per kernel: mean counter value per launch.
+Usage: python tools/pmc_summary.py <dir> [<dir> ...] [--json out.json]
+FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE counts a wide coalesced 128-byte read request as 64 bytes
+(MI355X_MICROARCH.md, HBM section): `hbm_bytes_per_launch` = 2 * FETCH_SIZE + WRITE_SIZE, in bytes."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(gemm_pers_kernel|gemm_pp8_kernel|gemm_kernel|flash_attn_kernel|layernorm_f32_vec_kernel|"
+                  r"conv0_group_apply_kernel|conv0_window_moments_kernel|conv0_group_coef_kernel|posconv_gather_kernel|"
+                  r"linear_head_kernel|moments_kernel|global_norm_kernel|f32_to_bf16_kernel|decode_frames_kernel)", name)
+    if not m:
+        return name[:48]
+    t = re.search(r"(?:ILi|<)(\d+)", name[m.end():m.end() + 12])
+    return m.group(1) + (f"<{t.group(1)}>" if t and m.group(1).startswith("gemm_p") else "")
+
+
+def main():
+    args = sys.argv[1:]
+    out = None
+    if "--json" in args:
+        i = args.index("--json")
+        out = args[i + 1]
+        del args[i:i + 2]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in rows:
-        agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, c in agg.items():
-        print(k)
+    for d in args:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, c in sorted(agg.items()):
+        e = {"launches": max(len(v) for v in c.values())}
         for n, v in c.items():
-            print(f"   {n:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
+            e[n + "_mean"] = sum(v) / len(v)
+        if "FETCH_SIZE_mean" in e and "WRITE_SIZE_mean" in e:
+            e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_mean"] + e["WRITE_SIZE_mean"]) * 1024
+        res[k] = e
+        print(f"{k:36s} n={e['launches']:4d} " + " ".join(f"{n}={v:.4g}" for n, v in e.items() if n != "launches"))
+    if out:
+        json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
