@@ -160,6 +160,24 @@ int svt_debug_gemm(int32_t precision, const void* a_dev, const void* w_dev, void
 
 /* diagnostic knobs for tools/gemm_bench.py: key 0 = kernel variant (0 normal, 1 no DMA after prologue, 2 no MFMA),
  * key 1 = force the M tile (0 auto, 128/192/256).  Never set in the product path. */
+/* ---- validation losses: replace speechbrain.nnet.losses.bce_loss / nll_loss (losses.py:402-519) over
+ * compute_masked_loss (:624-684), truncate (:594-621) and length_to_mask (dataio/dataio.py:661-706); forward only ----
+ * logits (B,t_pred) f32, targets (B,t_tgt) f32; the longer of the two is truncated when |t_pred - t_tgt| <=
+ * allowed_len_diff, otherwise SVT_ERR_INVALID with the reference's message.  rel_len (B,) f32 relative lengths or
+ * NULL; pos_weight: device pointer to ONE float or NULL.  reduction: 0 mean, 1 batchmean, 2 batch ((B,) outputs),
+ * 3 none ((B,T) masked per-frame losses).  workspace: batch*24+8 bytes of device memory. */
+int svt_bce_loss(const float* logits_dev, int64_t batch, int64_t t_pred, const float* targets_dev, int64_t t_tgt,
+                 const float* rel_len_dev, const float* pos_weight_dev, int32_t allowed_len_diff, int32_t reduction,
+                 float* out_dev, void* workspace_dev, size_t workspace_bytes, int device, void* stream);
+/* log_probs (B,t_pred,n_class) f32, targets (B,t_tgt) i64 (-100 = ignored, as torch.nn.functional.nll_loss).  After the
+ * call the int32 at workspace + batch*24 is non-zero if a target was outside [0, n_class). */
+int svt_nll_loss(const float* log_probs_dev, int64_t batch, int64_t t_pred, int32_t n_class, const int64_t* targets_dev,
+                 int64_t t_tgt, const float* rel_len_dev, float label_smoothing, int32_t allowed_len_diff,
+                 int32_t reduction, float* out_dev, void* workspace_dev, size_t workspace_bytes, int device, void* stream);
+/* y = softmax(x) or log_softmax(x) over the last axis of (rows, n): replaces speechbrain.nnet.activations.Softmax
+ * (activations.py:22-75) as the recipes use it (hparams log_softmax, apply_log=True) */
+int svt_softmax(const float* x_dev, int64_t rows, int32_t n, int32_t apply_log, float* y_dev, int device, void* stream);
+
 /* Fused attention kernel alone (bf16, head_dim 64 or 128): o[b,t,h*dh+d] = softmax(scale q k^T) v with q rows at
  * q + (b*t_len + t)*ldq + h*dh, k / v rows likewise with ldkv, o with ldo (element strides).  Replaces the eager
  * attention of transformers' Wav2Vec2Attention / torch.nn.MultiheadAttention inside the encoder and the RCA layers

@@ -301,3 +301,81 @@ def fbank(wav: torch.Tensor, n_mels=40, n_fft=400, win=400, hop=160, sr=16000, t
     db = db - 10.0 * math.log10(max(1e-10, 1.0))  # db_multiplier with ref_value 1.0 -> 0
     mx = db.amax(dim=(-2, -1)) - top_db
     return torch.max(db, mx.view(-1, 1, 1))
+
+
+# =================================================================================================
+# Validation losses — restated from speechbrain/nnet/losses.py, pinned by
+# tests/golden/losses.pt (generated by importing the reference's own functions)
+# =================================================================================================
+def truncate(predictions: torch.Tensor, targets: torch.Tensor, allowed_len_diff: int = 3):
+    """losses.py:594-621: equalise dim 1 when the difference is within the tolerance, else ValueError."""
+    d = predictions.shape[1] - targets.shape[1]
+    if d == 0:
+        return predictions, targets
+    if abs(d) > allowed_len_diff:
+        raise ValueError("Predictions and targets should be same length, but got %s and %s respectively."
+                         % (predictions.shape[1], targets.shape[1]))
+    if d < 0:
+        return predictions, targets[:, : predictions.shape[1]]
+    return predictions[:, : targets.shape[1]], targets
+
+
+def length_mask(rel_len: Optional[torch.Tensor], batch: int, frames: int) -> torch.Tensor:
+    """dataio/dataio.py:661-706 as compute_masked_loss calls it (losses.py:655-657): fp32 `t < rel_len * frames`."""
+    if rel_len is None:
+        return torch.ones(batch, frames)
+    lim = rel_len.float() * frames
+    return (torch.arange(frames, dtype=torch.float32).expand(batch, frames) < lim.unsqueeze(1)).float()
+
+
+def _reduce(loss, mask, reg, reduction, smoothing):
+    """losses.py:664-684 (loss, reg: (B,T) already masked)."""
+    B = loss.shape[0]
+    if reduction == "mean":
+        l, r = loss.sum() / mask.sum(), reg.sum() / mask.sum()
+    elif reduction == "batchmean":
+        l, r = loss.sum() / B, reg.sum() / B
+    elif reduction == "batch":
+        l, r = loss.sum(1) / mask.sum(1), reg.sum(1) / mask.sum(1)
+    else:
+        l, r = loss, reg
+    return l if smoothing == 0 else -smoothing * r + (1 - smoothing) * l
+
+
+def bce_loss(inputs, targets, length=None, pos_weight=None, reduction="mean", allowed_len_diff=3):
+    """losses.py:458-519: BCE-with-logits x length mask, reduced as compute_masked_loss."""
+    if inputs.dim() == targets.dim() + 1:
+        inputs = inputs.squeeze(-1)
+    one_d = inputs.dim() == 1
+    if one_d:
+        inputs, targets = inputs.unsqueeze(1), targets.unsqueeze(1)
+    inputs, targets = truncate(inputs, targets, allowed_len_diff)
+    x, y = inputs.float(), targets.float()
+    sp = torch.log1p(torch.exp(-x.abs())) + torch.clamp(-x, min=0)
+    lw = 1.0 if pos_weight is None else 1 + (float(pos_weight) - 1) * y
+    mask = length_mask(length, x.shape[0], x.shape[1])
+    loss = ((1 - y) * x + lw * sp) * mask
+    out = _reduce(loss, mask, torch.zeros_like(loss), reduction, 0.0)
+    return out.squeeze(1) if (one_d and reduction == "none") else out
+
+
+def nll_loss(log_probabilities, targets, length=None, label_smoothing=0.0, allowed_len_diff=3, reduction="mean"):
+    """losses.py:402-455."""
+    two_d = log_probabilities.dim() == 2
+    if two_d:
+        log_probabilities, targets = log_probabilities.unsqueeze(1), targets.unsqueeze(1)
+    else:
+        log_probabilities, targets = truncate(log_probabilities, targets, allowed_len_diff)
+    lp, tg = log_probabilities.float(), targets.long()
+    mask = length_mask(length, lp.shape[0], lp.shape[1])
+    picked = -torch.gather(lp, 2, tg.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    picked = torch.where(tg == -100, torch.zeros_like(picked), picked)
+    loss = picked * mask
+    reg = lp.mean(dim=2) * mask
+    out = _reduce(loss, mask, reg, reduction, label_smoothing)
+    return out.squeeze(1) if (two_d and reduction == "none") else out
+
+
+def softmax(x: torch.Tensor, apply_log: bool = False) -> torch.Tensor:
+    """nnet/activations.py:14-75 over the last axis."""
+    return torch.log_softmax(x.float(), -1) if apply_log else torch.softmax(x.float(), -1)

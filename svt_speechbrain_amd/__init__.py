@@ -7,6 +7,10 @@ from .fusion import FusionRCA  # noqa: F401
 from .features import Fbank  # noqa: F401
 from .decode import decode_frames, frame2note, frames_to_info, ctc_greedy_decode, filter_ctc_output  # noqa: F401
 from .amt import AMTForward  # noqa: F401
+from . import losses  # noqa: F401
+from . import checkpoints  # noqa: F401
+from .checkpoints import Checkpointer  # noqa: F401
+from .losses import bce_loss, nll_loss, Softmax  # noqa: F401
 from .song import SongTranscriber, utterance_bounds, save_song_features, feature_path  # noqa: F401
 
 __all__ = ["EncoderConfig", "PRESETS", "config_from_source", "HuggingFaceWav2Vec2", "Linear", "FusionRCA", "Fbank",

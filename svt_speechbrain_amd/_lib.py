@@ -79,6 +79,11 @@ SYMBOLS = {
                             C.c_float, C.c_float, C.c_float, _P, _P, C.c_size_t, C.c_int, _P]),
     "svt_debug_gemm": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                  C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P]),
+    "svt_bce_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "svt_nll_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "svt_softmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "svt_debug_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),

@@ -981,6 +981,67 @@ int svt_ctc_greedy(const float* probs, int32_t B, int32_t T, int32_t V, const fl
   return launch_ctc_greedy(probs, B, T, V, rel_lens, blank, tokens, out_lens, (hipStream_t)stream);
 }
 
+// ---- validation losses ----
+static int loss_common_checks(const char* who, int64_t batch, int64_t t_pred, int64_t t_tgt, int32_t allowed, int32_t reduction,
+                              size_t ws_bytes, int64_t* T) {
+  if (batch < 1 || t_pred < 1 || t_tgt < 1) { set_error(std::string(who) + ": empty input"); return SVT_ERR_INVALID; }
+  if (reduction < 0 || reduction > 3) { set_error(std::string(who) + ": reduction must be 0 (mean), 1 (batchmean), 2 (batch) or 3 (none)"); return SVT_ERR_INVALID; }
+  const int64_t diff = t_pred - t_tgt;
+  if ((diff < 0 ? -diff : diff) > allowed) {
+    // same condition and wording as speechbrain.nnet.losses.truncate (losses.py:608-613)
+    set_error("Predictions and targets should be same length, but got " + std::to_string(t_pred) + " and " +
+              std::to_string(t_tgt) + " respectively.");
+    return SVT_ERR_INVALID;
+  }
+  *T = diff < 0 ? t_pred : t_tgt;
+  if (ws_bytes < (size_t)batch * 24 + 8) { set_error(std::string(who) + ": workspace too small (need batch*24+8 bytes)"); return SVT_ERR_INVALID; }
+  return SVT_OK;
+}
+
+int svt_bce_loss(const float* logits, int64_t batch, int64_t t_pred, const float* targets, int64_t t_tgt, const float* rel_len,
+                 const float* pos_weight, int32_t allowed_len_diff, int32_t reduction, float* out, void* workspace,
+                 size_t workspace_bytes, int device, void* stream) {
+  if (!logits || !targets || !out || !workspace) { set_error("svt_bce_loss: null argument"); return SVT_ERR_INVALID; }
+  int64_t T = 0;
+  if (int r = loss_common_checks("svt_bce_loss", batch, t_pred, t_tgt, allowed_len_diff, reduction, workspace_bytes, &T)) return r;
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  double* sums = (double*)workspace;
+  if (launch_bce_loss(logits, batch, t_pred, targets, t_tgt, T, rel_len, pos_weight, reduction == 3 ? out : nullptr, sums, s)) return SVT_ERR_HIP;
+  if (reduction != 3 && launch_loss_reduce(sums, (int)batch, reduction, 0.f, out, s)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+
+int svt_nll_loss(const float* log_probs, int64_t batch, int64_t t_pred, int32_t n_class, const int64_t* targets, int64_t t_tgt,
+                 const float* rel_len, float label_smoothing, int32_t allowed_len_diff, int32_t reduction, float* out,
+                 void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!log_probs || !targets || !out || !workspace) { set_error("svt_nll_loss: null argument"); return SVT_ERR_INVALID; }
+  if (n_class < 1) { set_error("svt_nll_loss: n_class < 1"); return SVT_ERR_INVALID; }
+  if (reduction == 3 && label_smoothing != 0.f) { set_error("svt_nll_loss: reduction none with label smoothing is not provided"); return SVT_ERR_INVALID; }
+  int64_t T = 0;
+  if (int r = loss_common_checks("svt_nll_loss", batch, t_pred, t_tgt, allowed_len_diff, reduction, workspace_bytes, &T)) return r;
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  double* sums = (double*)workspace;
+  int* bad = (int*)((char*)workspace + (size_t)batch * 24);
+  SVT_HIP(hipMemsetAsync(bad, 0, 4, s));
+  if (launch_nll_loss(log_probs, batch, t_pred, n_class, targets, t_tgt, T, rel_len, reduction == 3 ? out : nullptr, sums, bad, s)) return SVT_ERR_HIP;
+  if (reduction != 3 && launch_loss_reduce(sums, (int)batch, reduction, label_smoothing, out, s)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+
+int svt_softmax(const float* x, int64_t rows, int32_t n, int32_t apply_log, float* y, int device, void* stream) {
+  if (!x || !y) { set_error("svt_softmax: null argument"); return SVT_ERR_INVALID; }
+  if (rows < 1) return SVT_OK;
+  if (n < 1 || n > 4096) { set_error("svt_softmax: n must be in 1..4096"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  if (launch_softmax_small(x, rows, n, apply_log, y, (hipStream_t)stream)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+
 }  // extern "C"
 
 namespace {

@@ -205,6 +205,13 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
                       hipStream_t s);
 // frame head for K in {512,768,1024}, N <= 32: weight in LDS, four rows per wave (HBM-bound)
+// validation losses (masked BCE-with-logits / NLL, speechbrain/nnet/losses.py) and the narrow (log-)softmax
+int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,
+                    const float* pos_weight, float* per_frame, double* sums, hipStream_t s);
+int launch_nll_loss(const float* logp, int64_t B, int64_t t_pred, int C, const int64_t* tgt, int64_t t_tgt, int64_t T,
+                    const float* rel_len, float* per_frame, double* sums, int* bad_target, hipStream_t s);
+int launch_loss_reduce(const double* sums, int B, int reduction, float smoothing, float* out, hipStream_t s);
+int launch_softmax_small(const float* x, int64_t rows, int n, int apply_log, float* y, hipStream_t s);
 bool linear_head_eligible(int K, int N);
 int launch_linear_head(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y, hipStream_t s);
 struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };

@@ -538,6 +538,108 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Validation losses of the recipes (speechbrain/nnet/losses.py:402-519 nll_loss / bce_loss over
+// compute_masked_loss :624-684).  One workgroup per batch item: per-frame loss x length mask, block-reduced in a
+// fixed order (deterministic) into double sums {sum loss*mask, sum mask, sum mean_c(logp)*mask}; a second tiny
+// kernel applies the reduction mode.  mask[b,t] = (float)t < rel_len[b] * (float)T, the fp32 comparison
+// length_to_mask makes (speechbrain/dataio/dataio.py:661-706).
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void bce_loss_kernel(const float* x, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T,
+                                                       const float* rel_len, const float* pos_weight, float* per_frame,
+                                                       double* sums) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  const float lim = rel_len ? __fmul_rn(rel_len[b], (float)T) : 0.f;
+  const float pw = pos_weight ? pos_weight[0] : 1.f;
+  double sl = 0.0, sm = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += 256) {
+    const float xv = x[b * t_pred + t], yv = y[b * t_tgt + t];
+    const float m = rel_len ? ((float)t < lim ? 1.f : 0.f) : 1.f;
+    // torch binary_cross_entropy_with_logits: (1 - y) x + (1 + (pw - 1) y) (log1p(exp(-|x|)) + max(-x, 0))
+    const float sp = log1pf(expf(-fabsf(xv))) + fmaxf(-xv, 0.f);
+    const float lw = pos_weight ? 1.f + (pw - 1.f) * yv : 1.f;
+    const float l = ((1.f - yv) * xv + lw * sp) * m;
+    if (per_frame) per_frame[b * T + t] = l;
+    sl += (double)l;
+    sm += (double)m;
+  }
+  sl = block_sum_256(sl, sh);
+  sm = block_sum_256(sm, sh);
+  if (threadIdx.x == 0) { sums[b * 3 + 0] = sl; sums[b * 3 + 1] = sm; sums[b * 3 + 2] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void nll_loss_kernel(const float* logp, int64_t t_pred, int C, const int64_t* tgt, int64_t t_tgt,
+                                                       int64_t T, const float* rel_len, float* per_frame, double* sums,
+                                                       int* bad_target) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  const float lim = rel_len ? __fmul_rn(rel_len[b], (float)T) : 0.f;
+  double sl = 0.0, sm = 0.0, sr = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += 256) {
+    const float* row = logp + (b * t_pred + t) * C;
+    const int64_t k = tgt[b * t_tgt + t];
+    const float m = rel_len ? ((float)t < lim ? 1.f : 0.f) : 1.f;
+    float l = 0.f;
+    if (k == -100) l = 0.f;  // torch.nn.functional.nll_loss ignore_index default
+    else if (k < 0 || k >= C) { atomicExch(bad_target, 1); }
+    else l = -row[k];
+    l *= m;
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += row[c];
+    mean = mean / (float)C * m;
+    if (per_frame) per_frame[b * T + t] = l;
+    sl += (double)l;
+    sm += (double)m;
+    sr += (double)mean;
+  }
+  sl = block_sum_256(sl, sh);
+  sm = block_sum_256(sm, sh);
+  sr = block_sum_256(sr, sh);
+  if (threadIdx.x == 0) { sums[b * 3 + 0] = sl; sums[b * 3 + 1] = sm; sums[b * 3 + 2] = sr; }
+}
+
+// reduction: 0 mean, 1 batchmean, 2 batch (B outputs); label smoothing as compute_masked_loss :670-684
+__global__ void loss_reduce_kernel(const double* sums, int B, int reduction, float smoothing, float* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (reduction == 2) {
+    for (int b = 0; b < B; ++b) {
+      const float l = (float)sums[b * 3] / (float)sums[b * 3 + 1];
+      const float r = (float)sums[b * 3 + 2] / (float)sums[b * 3 + 1];
+      out[b] = smoothing == 0.f ? l : -smoothing * r + (1.f - smoothing) * l;
+    }
+    return;
+  }
+  double sl = 0.0, sm = 0.0, sr = 0.0;
+  for (int b = 0; b < B; ++b) { sl += sums[b * 3]; sm += sums[b * 3 + 1]; sr += sums[b * 3 + 2]; }
+  const float den = reduction == 0 ? (float)sm : (float)B;
+  const float l = (float)sl / den, r = (float)sr / den;
+  out[0] = smoothing == 0.f ? l : -smoothing * r + (1.f - smoothing) * l;
+}
+
+// y = log_softmax(x) / softmax(x) over the last axis (speechbrain/nnet/activations.py Softmax): one thread per row for
+// the narrow heads of this path (n <= 64), fp32
+__global__ void softmax_small_kernel(const float* x, int64_t rows, int n, int apply_log, float* y) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* xr = x + r * n;
+  float mx = xr[0];
+  for (int i = 1; i < n; ++i) mx = fmaxf(mx, xr[i]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += expf(xr[i] - mx);
+  const float ls = logf(s);
+  for (int i = 0; i < n; ++i) y[r * n + i] = apply_log ? (xr[i] - mx) - ls : expf(xr[i] - mx) / s;
+}
+
 __global__ void decode_frames_kernel(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls,
                                      FrameOut* out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -879,6 +981,30 @@ int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const
                       hipStream_t s) {
   if (N > 32) { set_error("linear_small: N > 32"); return -1; }
   hipLaunchKernelGGL(linear_small_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, K, w, b, N, y);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,
+                    const float* pos_weight, float* per_frame, double* sums, hipStream_t s) {
+  hipLaunchKernelGGL(bce_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, x, t_pred, y, t_tgt, T, rel_len, pos_weight, per_frame, sums);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_nll_loss(const float* logp, int64_t B, int64_t t_pred, int C, const int64_t* tgt, int64_t t_tgt, int64_t T,
+                    const float* rel_len, float* per_frame, double* sums, int* bad_target, hipStream_t s) {
+  hipLaunchKernelGGL(nll_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, logp, t_pred, C, tgt, t_tgt, T, rel_len, per_frame, sums,
+                     bad_target);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_loss_reduce(const double* sums, int B, int reduction, float smoothing, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, s, sums, B, reduction, smoothing, out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_softmax_small(const float* x, int64_t rows, int n, int apply_log, float* y, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_small_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, rows, n, apply_log, y);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -257,6 +257,103 @@ def make_ctc_fbank_cases():
     torch.save(fo, os.path.join(HERE, "fbank.pt"))
 
 
+def make_loss_cases():
+    """speechbrain.nnet.losses.bce_loss / nll_loss and activations.Softmax run as the recipes call them
+    (MIR_ST500/train_audio_ssl.py:66-76): (B,T) logits / (B,T,C) log-probs, relative lengths, +-3-frame truncate."""
+    from speechbrain.nnet.losses import bce_loss, nll_loss
+    from speechbrain.nnet.activations import Softmax
+    g = torch.Generator().manual_seed(77)
+    out = {"bce": [], "nll": [], "softmax": []}
+    # doctest known answers (losses.py:437-439, 498-501)
+    assert abs(float(nll_loss(torch.log(torch.tensor([[0.9, 0.1], [0.1, 0.9]])), torch.tensor([1, 1]))) - 1.2040) < 1e-4
+    assert abs(float(bce_loss(torch.tensor([10.0, -6.0]), torch.tensor([1, 0]))) - 0.0013) < 1e-4
+    shapes = [(3, 249, 249), (2, 499, 498), (4, 60, 63), (1, 250, 249), (5, 17, 17)]
+    for i, (B, tp, tt) in enumerate(shapes):
+        x = torch.randn(B, tp, generator=g) * 3
+        y = (torch.rand(B, tt, generator=g) < 0.2).float()
+        ln = torch.rand(B, generator=g) * 0.7 + 0.3
+        ln[0] = 1.0
+        for length in (None, ln):
+            for pw in (None, 15.0):
+                for red in ("mean", "batch", "batchmean", "none"):
+                    kw = dict(length=length, reduction=red)
+                    if pw is not None:
+                        kw["pos_weight"] = torch.tensor([pw])
+                    out["bce"].append(dict(x=x, y=y, length=length, pos_weight=pw, reduction=red,
+                                           expect=bce_loss(x, y, **kw)))
+        for C in (5, 13):
+            lp = Softmax(apply_log=True)(torch.randn(B, tp, C, generator=g) * 2)
+            tg = torch.randint(0, C, (B, tt), generator=g)
+            for length in (None, ln):
+                for ls in (0.0, 0.1):
+                    for red in ("mean", "batch", "batchmean") + (("none",) if ls == 0.0 else ()):
+                        out["nll"].append(dict(lp=lp, tg=tg, length=length, label_smoothing=ls, reduction=red,
+                                               expect=nll_loss(lp, tg, length=length, label_smoothing=ls, reduction=red)))
+    # 1-D / 2-D forms of the doctests and an ignored target
+    out["bce"].append(dict(x=torch.tensor([10.0, -6.0]), y=torch.tensor([1.0, 0.0]), length=None, pos_weight=None,
+                           reduction="mean", expect=bce_loss(torch.tensor([10.0, -6.0]), torch.tensor([1, 0]))))
+    lp2 = torch.log(torch.tensor([[0.9, 0.1], [0.1, 0.9]]))
+    out["nll"].append(dict(lp=lp2, tg=torch.tensor([1, 1]), length=None, label_smoothing=0.0, reduction="mean",
+                           expect=nll_loss(lp2, torch.tensor([1, 1]))))
+    lp3 = Softmax(apply_log=True)(torch.randn(2, 9, 5, generator=g))
+    tg3 = torch.randint(0, 5, (2, 9), generator=g)
+    tg3[0, 3] = -100
+    out["nll"].append(dict(lp=lp3, tg=tg3, length=torch.tensor([1.0, 0.5]), label_smoothing=0.0, reduction="batch",
+                           expect=nll_loss(lp3, tg3, length=torch.tensor([1.0, 0.5]), reduction="batch")))
+    for shape in [(3, 7, 5), (2, 13), (2, 3, 4, 6)]:
+        x = torch.randn(*shape, generator=g) * 4
+        for apply_log in (False, True):
+            out["softmax"].append(dict(x=x, apply_log=apply_log, expect=Softmax(apply_log=apply_log)(x)))
+    # error behaviour: 4 frames apart -> ValueError with this text
+    try:
+        bce_loss(torch.zeros(1, 10), torch.zeros(1, 14))
+    except ValueError as e:
+        out["truncate_error"] = str(e)
+    torch.save(out, os.path.join(HERE, "losses.pt"))
+    print("losses", len(out["bce"]), len(out["nll"]), len(out["softmax"]), out["truncate_error"])
+
+
+def make_ckpt_tree(hi):
+    """A save folder written by the reference's own Checkpointer (speechbrain/utils/checkpoints.py:505-568): three
+    CKPT+* directories with the recipes' recoverables (wav2vec2 = the reference wrapper around a tiny encoder, model =
+    speechbrain Linear) and metas carrying `loss` / `COnPOff_f1` like train_audio_ssl.py:178-186.  The expected picks are
+    the reference's own find_checkpoint answers."""
+    import json
+    import shutil
+    import time
+    from speechbrain.utils.checkpoints import Checkpointer
+    from speechbrain.nnet.linear import Linear
+    cfg = PRESETS["tiny-group"]
+    root = os.path.join(HERE, "ckpt_tree")
+    shutil.rmtree(root, ignore_errors=True)
+    expect = {"picks": {}, "digests": {}}
+    metas = [("a", dict(loss=0.52, COnPOff_f1=0.31)), ("b", dict(loss=0.47, COnPOff_f1=0.36)), ("c", dict(loss=0.49))]
+    for i, (name, meta) in enumerate(metas):
+        sd = W.seeded_encoder_state_dict(cfg, seed=300 + i)
+        enc = reference_encoder(hi, cfg, sd)
+        head = Linear(n_neurons=20, input_size=cfg.hidden_size)
+        hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=400 + i)
+        head.load_state_dict(hd)
+        ck = Checkpointer(root, {"wav2vec2": enc, "model": head})
+        ck.save_checkpoint(meta=meta, name=name)
+        wav = synth_wav(2, 4000, seed=900 + i)
+        with torch.no_grad():
+            feats = enc(wav)
+            logits = head(feats)
+        expect["digests"]["CKPT+" + name] = dict(logits_sum=float(logits.double().sum()), logits_abs=float(logits.double().abs().sum()),
+                                                 first=[float(v) for v in logits[0, 0, :4]], wav_seed=900 + i)
+        time.sleep(0.05)
+    ck = Checkpointer(root, {})
+    expect["picks"]["recent"] = ck.find_checkpoint().path.name
+    expect["picks"]["min_loss"] = ck.find_checkpoint(min_key="loss").path.name
+    expect["picks"]["max_f1"] = ck.find_checkpoint(max_key="COnPOff_f1").path.name
+    expect["picks"]["ranked_min_loss"] = [c.path.name for c in ck.find_checkpoints(min_key="loss")]
+    expect["picks"]["ranked_max_f1"] = [c.path.name for c in ck.find_checkpoints(max_key="COnPOff_f1")]
+    json.dump(expect, open(os.path.join(root, "expected.json"), "w"), indent=1)
+    sz = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(root) for f in fs)
+    print("ckpt_tree", expect["picks"], f"{sz/1e3:.0f} KB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -278,6 +375,8 @@ def main():
         "fusion": lambda: make_fusion_cases(fusion_mod),
         "frame2note": lambda: make_frame2note_cases(utils),
         "ctc_fbank": make_ctc_fbank_cases,
+        "losses": make_loss_cases,
+        "ckpt_tree": lambda: make_ckpt_tree(hi),
     }
     for k, fn in jobs.items():
         if args.only and args.only != k:

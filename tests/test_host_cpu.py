@@ -122,3 +122,50 @@ def test_utterance_bounds_match_reference_rule():
             assert 0 < (b[-1][1] - b[-1][0]) / sr <= 7.5 + 1e-9
     assert S.feature_path("/x/song1") == "/x/song1/noise_data/clean_feats.pt"
     assert S.feature_path("/x/song1", True, "babble", -5) == "/x/song1/noise_data/babble/SNR_-5dB_feats.pt"
+
+
+# ---- §8f rank 3: checkpoint directory reader ----
+CKPT_TREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_tree")
+
+
+def test_checkpoint_selection_matches_reference_checkpointer():
+    import json
+    want = json.load(open(os.path.join(CKPT_TREE, "expected.json")))["picks"]
+    ck = S.Checkpointer(CKPT_TREE)
+    assert len(ck.list_checkpoints()) == 3
+    assert ck.find_checkpoint().path.name == want["recent"]
+    assert ck.find_checkpoint(min_key="loss").path.name == want["min_loss"]
+    assert ck.find_checkpoint(max_key="COnPOff_f1").path.name == want["max_f1"]
+    assert [c.path.name for c in ck.find_checkpoints(min_key="loss")] == want["ranked_min_loss"]
+    assert [c.path.name for c in ck.find_checkpoints(max_key="COnPOff_f1")] == want["ranked_max_f1"]  # only those with the key
+    assert [c.path.name for c in ck.find_checkpoints(min_key="loss", max_num_checkpoints=1)] == want["ranked_min_loss"][:1]
+    with pytest.raises(ValueError):  # the reference's only conflict check: a key function together with a key name
+        ck.find_checkpoints(importance_key=S.checkpoints.ckpt_recency, min_key="loss")
+    assert S.Checkpointer(os.path.join(CKPT_TREE, "nowhere")).recover_if_possible() is None
+    with pytest.raises(RuntimeError):  # a recoverable with no file in the checkpoint
+        S.Checkpointer(CKPT_TREE, {"tokenizer": torch.nn.Linear(1, 1)}).recover_if_possible()
+    S.Checkpointer(CKPT_TREE, {"tokenizer": torch.nn.Linear(1, 1)}, allow_partial_load=True).recover_if_possible()
+
+
+def test_reference_checkpoint_files_load_unchanged_and_reproduce_the_reference_outputs():
+    # the .ckpt files were written by the reference's Checkpointer around the reference's own modules; the package's
+    # modules must take them as they are (HF key spelling, masked_spec_embed, w.weight / w.bias) — checked on the CPU
+    # by running the oracle on the state the modules hold after loading
+    import json
+    from oracle import svt_oracle as O
+    want = json.load(open(os.path.join(CKPT_TREE, "expected.json")))
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, seed=1)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    ck = S.Checkpointer(CKPT_TREE, {"wav2vec2": enc, "model": head})
+    chosen = ck.recover_if_possible(min_key="loss")
+    assert chosen.path.name == want["picks"]["min_loss"] and chosen.meta["loss"] == 0.47
+    d = want["digests"][chosen.path.name]
+    sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(d["wav_seed"])
+    wav = (0.1 * torch.randn(2, 4000, generator=g)).clamp_(-1, 1)
+    with torch.no_grad():
+        logits = O.head_forward(O.encoder_forward(sd, cfg, wav), head.state_dict()["w.weight"].cpu(), head.state_dict()["w.bias"].cpu())
+    assert abs(float(logits.double().sum()) - d["logits_sum"]) < 1e-3
+    assert abs(float(logits.double().abs().sum()) - d["logits_abs"]) < 1e-3
+    assert max(abs(float(a) - b) for a, b in zip(logits[0, 0, :4], d["first"])) < 2e-5

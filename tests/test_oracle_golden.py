@@ -114,3 +114,25 @@ def test_oracle_fbank(golden):
         out = O.fbank(c["wav"])
         assert out.shape == c["feats"].shape
         assert (out - c["feats"]).abs().max() < 2e-3, k  # dB scale, values O(10..80)
+
+
+# ---- §8f rank 3: validation losses ----
+def _close(a, b, tol=2e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return bool(((a - b).abs() <= tol * (1 + b.abs())).all())
+
+
+def test_oracle_losses_match_reference_golden(golden):
+    fx = golden("losses")
+    for c in fx["bce"]:
+        got = O.bce_loss(c["x"], c["y"], length=c["length"], pos_weight=c["pos_weight"], reduction=c["reduction"])
+        assert _close(got, c["expect"]), ("bce", c["reduction"], c["pos_weight"], c["x"].shape, c["y"].shape)
+    for c in fx["nll"]:
+        got = O.nll_loss(c["lp"], c["tg"], length=c["length"], label_smoothing=c["label_smoothing"], reduction=c["reduction"])
+        assert _close(got, c["expect"]), ("nll", c["reduction"], c["label_smoothing"], c["lp"].shape, c["tg"].shape)
+    for c in fx["softmax"]:
+        assert _close(O.softmax(c["x"], c["apply_log"]), c["expect"].reshape(c["x"].shape))
+    with pytest.raises(ValueError) as e:
+        O.bce_loss(torch.zeros(1, 10), torch.zeros(1, 14))
+    assert str(e.value) == fx["truncate_error"]
