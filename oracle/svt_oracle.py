@@ -379,3 +379,37 @@ def nll_loss(log_probabilities, targets, length=None, label_smoothing=0.0, allow
 def softmax(x: torch.Tensor, apply_log: bool = False) -> torch.Tensor:
     """nnet/activations.py:14-75 over the last axis."""
     return torch.log_softmax(x.float(), -1) if apply_log else torch.softmax(x.float(), -1)
+
+
+# =================================================================================================
+# AV-HuBERT lip front-end (SURVEY.md §8 a15 / §8f rank 2) — restated from N20EMv2/video_only/resnet.py,
+# pinned by tests/golden/video_front.pt (generated by importing that file itself)
+# =================================================================================================
+def _bn_eval(x, sd, p):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+
+def video_frontend_forward(sd: Dict[str, torch.Tensor], video: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """video (B,1,T,H,W) -> (B,T,embed).  resnet.py:150-158 (ResEncoder.forward), :36-72 (BasicBlock), :125-132
+    (trunk), :183-187 (SubModel: proj on the transposed features; returned here already as (B,T,E))."""
+    g = lambda k: sd[prefix + k]  # noqa: E731
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    B, _, T, _, _ = video.shape
+    x = F.conv3d(video.float(), g("resnet.frontend3D.0.weight"), None, stride=(1, 2, 2), padding=(2, 3, 3))
+    x = _bn_eval(x, sub, "resnet.frontend3D.1")
+    x = F.prelu(x, g("resnet.frontend3D.2.weight"))
+    x = F.max_pool3d(x, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+    x = x.transpose(1, 2).reshape(B * T, 64, x.shape[3], x.shape[4])
+    for li in range(1, 5):
+        for b in range(2):
+            p = f"resnet.trunk.layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            out = F.conv2d(x, sub[p + ".conv1.weight"], None, stride=stride, padding=1)
+            out = F.prelu(_bn_eval(out, sub, p + ".bn1"), sub[p + ".relu1.weight"])
+            out = _bn_eval(F.conv2d(out, sub[p + ".conv2.weight"], None, stride=1, padding=1), sub, p + ".bn2")
+            res = x
+            if (p + ".downsample.0.weight") in sub:
+                res = _bn_eval(F.conv2d(x, sub[p + ".downsample.0.weight"], None, stride=stride), sub, p + ".downsample.1")
+            x = F.prelu(out + res, sub[p + ".relu2.weight"])
+    x = x.mean(dim=(2, 3)).view(B, T, 512)
+    return F.linear(x, g("proj.weight"), g("proj.bias"))

@@ -162,3 +162,68 @@ def seeded_fusion_state_dict(d_model: int = 1024, d_ffn: int = 3072, seed: int =
 
 def count_params(sd: Dict[str, torch.Tensor]) -> int:
     return sum(int(v.numel()) for v in sd.values())
+
+
+# ---- AV-HuBERT lip front-end (ResNet-18 + projection), SURVEY.md §8 a15 ----
+def video_frontend_param_shapes(embed_dim: int = 1024) -> "OrderedDict[str, Tuple[int, ...]]":
+    """``SubModel.state_dict()`` of ``N20EMv2/video_only/resnet.py:174-187`` (= the ``feature_extractor_video.*`` keys of an
+    AV-HuBERT checkpoint): 3-D stem (:141-145), four stages of two PReLU BasicBlocks (:36-72, 84-88), 1x1 stride-2
+    downsample convs on stages 2-4 (:21-25), Linear(512 -> embed_dim)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def bn(p, c):
+        sh[f"{p}.weight"] = (c,)
+        sh[f"{p}.bias"] = (c,)
+        sh[f"{p}.running_mean"] = (c,)
+        sh[f"{p}.running_var"] = (c,)
+        sh[f"{p}.num_batches_tracked"] = ()
+
+    sh["resnet.frontend3D.0.weight"] = (64, 1, 5, 7, 7)
+    bn("resnet.frontend3D.1", 64)
+    sh["resnet.frontend3D.2.weight"] = (64,)
+    cin = 64
+    for li, c in enumerate((64, 128, 256, 512), start=1):
+        for b in range(2):
+            p = f"resnet.trunk.layer{li}.{b}"
+            sh[f"{p}.conv1.weight"] = (c, cin if b == 0 else c, 3, 3)
+            bn(f"{p}.bn1", c)
+            sh[f"{p}.relu1.weight"] = (c,)
+            sh[f"{p}.relu2.weight"] = (c,)
+            sh[f"{p}.conv2.weight"] = (c, c, 3, 3)
+            bn(f"{p}.bn2", c)
+            if b == 0 and li > 1:
+                sh[f"{p}.downsample.0.weight"] = (c, cin, 1, 1)
+                bn(f"{p}.downsample.1", c)
+        cin = c
+    sh["proj.weight"] = (embed_dim, 512)
+    sh["proj.bias"] = (embed_dim,)
+    return sh
+
+
+def seeded_video_frontend_state_dict(embed_dim: int = 1024, seed: int = 4986, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+    """Seeded values in the key order above: He-normal convs (resnet.py:94-97), batch-norm statistics away from the
+    identity (so a wrong fold shows), PReLU slopes around 0.25."""
+    g = torch.Generator().manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, shape in video_frontend_param_shapes(embed_dim).items():
+        if k.endswith("num_batches_tracked"):
+            v = torch.tensor(100, dtype=torch.long)
+        elif k.endswith("running_var"):
+            v = torch.rand(shape, generator=g) + 0.5
+        elif k.endswith("running_mean"):
+            v = torch.randn(shape, generator=g) * 0.1
+        elif ".bn2." in k and k.endswith("weight"):
+            v = torch.rand(shape, generator=g) * 0.3 + 0.3  # keeps the residual stream O(1) through eight blocks
+        elif ".bn" in k or "frontend3D.1" in k or "downsample.1" in k:
+            v = torch.rand(shape, generator=g) * 0.6 + 0.7 if k.endswith("weight") else torch.randn(shape, generator=g) * 0.1
+        elif "relu" in k or k.endswith("frontend3D.2.weight"):
+            v = torch.rand(shape, generator=g) * 0.3 + 0.1
+        elif k == "proj.bias":
+            v = torch.randn(shape, generator=g) * 0.1
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            v = torch.randn(shape, generator=g) * math.sqrt((0.25 if k == "proj.weight" else 2.0) / fan_in)
+        sd[prefix + k] = v
+    return sd

@@ -354,6 +354,28 @@ def make_ckpt_tree(hi):
     print("ckpt_tree", expect["picks"], f"{sz/1e3:.0f} KB")
 
 
+def make_video_front_cases():
+    """The reference's own lip front-end (N20EMv2/video_only/resnet.py, loaded by path: it imports only torch):
+    SubModel(input_dim=512, embed_dim, relu_type='prelu') = ResEncoder (3-D stem + ResNet-18 trunk) + proj, eval mode."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_video_resnet", REF + "/N20EMv2/video_only/resnet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for name, B, T, HW, E, seed in [("roi88", 2, 5, 88, 1024, 4986), ("roi88_t1", 1, 1, 88, 1024, 4987), ("roi32", 1, 7, 32, 256, 4988),
+                                   ("roi50", 2, 3, 50, 128, 4989)]:
+        sd = W.seeded_video_frontend_state_dict(E, seed=seed)
+        m = mod.SubModel(512, E, "prelu").eval()
+        m.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        video = torch.randn(B, 1, T, HW, HW, generator=g)
+        with torch.no_grad():
+            y = m(video).transpose(1, 2).contiguous()   # (B, T, E)
+        out[name] = dict(B=B, T=T, HW=HW, E=E, weight_seed=seed, video_seed=seed + 1, feats=y, sd_sha256=sd_digest(sd))
+        print("video_front", name, tuple(y.shape), float(y.std()))
+    torch.save(out, os.path.join(HERE, "video_front.pt"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -376,6 +398,7 @@ def main():
         "frame2note": lambda: make_frame2note_cases(utils),
         "ctc_fbank": make_ctc_fbank_cases,
         "losses": make_loss_cases,
+        "video_front": make_video_front_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),
     }
     for k, fn in jobs.items():

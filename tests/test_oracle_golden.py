@@ -136,3 +136,17 @@ def test_oracle_losses_match_reference_golden(golden):
     with pytest.raises(ValueError) as e:
         O.bce_loss(torch.zeros(1, 10), torch.zeros(1, 14))
     assert str(e.value) == fx["truncate_error"]
+
+
+# ---- §8 a15: AV-HuBERT lip front-end ----
+@pytest.mark.parametrize("name", ["roi88", "roi88_t1", "roi32", "roi50"])
+def test_oracle_video_frontend_matches_reference_golden(golden, name):
+    fx = golden("video_front")[name]
+    sd = W.seeded_video_frontend_state_dict(fx["E"], seed=fx["weight_seed"])
+    assert sd_digest(sd) == fx["sd_sha256"], "seeded video weight generator drifted from the golden fixtures"
+    g = torch.Generator().manual_seed(fx["video_seed"])
+    video = torch.randn(fx["B"], 1, fx["T"], fx["HW"], fx["HW"], generator=g)
+    with torch.no_grad():
+        y = O.video_frontend_forward(sd, video)
+    assert y.shape == fx["feats"].shape
+    assert (y - fx["feats"]).abs().max() < 2e-5 * (1 + fx["feats"].abs().max())
