@@ -160,6 +160,21 @@ int svt_debug_gemm(int32_t precision, const void* a_dev, const void* w_dev, void
 
 /* diagnostic knobs for tools/gemm_bench.py: key 0 = kernel variant (0 normal, 1 no DMA after prologue, 2 no MFMA),
  * key 1 = force the M tile (0 auto, 128/192/256).  Never set in the product path. */
+/* ---- AV-HuBERT lip front-end: replaces SubModel / ResEncoder of N20EMv2/video_only/resnet.py:134-187 (the
+ * `feature_extractor_video` of the AV-HuBERT model, hubert.py:344-346): 3-D stem + ResNet-18 trunk (PReLU) + Linear(512,
+ * embed_dim), eval mode.  Parameter keys are SubModel.state_dict() keys ("resnet.frontend3D.0.weight", "resnet.trunk.layer1.0.
+ * bn1.running_mean", ..., "proj.weight"); num_batches_tracked entries are not needed. ---- */
+typedef struct svt_video svt_video;
+int svt_video_create(int32_t embed_dim, int32_t precision, int device, svt_video** out);
+void svt_video_destroy(svt_video* v);
+int svt_video_load_param(svt_video* v, const char* key, const void* data_host, int dtype, const int64_t* shape, int ndim);
+/* folds the eval-mode batch norms into the conv weights, re-lays the weights out tap-major / as MFMA fragments, uploads */
+int svt_video_finalize(svt_video* v);
+int64_t svt_video_workspace_bytes(const svt_video* v, int32_t batch, int32_t t, int32_t h, int32_t w);
+/* video (B,1,T,H,W) f32 on the device -> out (B,T,embed_dim) f32 */
+int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- validation losses: replace speechbrain.nnet.losses.bce_loss / nll_loss (losses.py:402-519) over
  * compute_masked_loss (:624-684), truncate (:594-621) and length_to_mask (dataio/dataio.py:661-706); forward only ----
  * logits (B,t_pred) f32, targets (B,t_tgt) f32; the longer of the two is truncated when |t_pred - t_tgt| <=

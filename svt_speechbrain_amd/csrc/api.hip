@@ -981,6 +981,250 @@ int svt_ctc_greedy(const float* probs, int32_t B, int32_t T, int32_t V, const fl
   return launch_ctc_greedy(probs, B, T, V, rel_lens, blank, tokens, out_lens, (hipStream_t)stream);
 }
 
+// =================================================================================================
+// AV-HuBERT lip front-end: ResNet-18 over the mouth ROI + projection
+// =================================================================================================
+}  // extern "C"
+
+struct VConv {
+  DevBuf w, bias, slope;  // w: operand type [Cout][k*k*Cin] tap-major with the BN scale folded; bias / slope fp32
+};
+struct svt_video {
+  int E = 0, prec = 0, device = 0;
+  bool finalized = false;
+  ParamMap params;
+  DevBuf stem_w, stem_bias, stem_slope;
+  VConv conv1[4][2], conv2[4][2], down[4];
+  DevBuf slope2[4][2];
+  DevBuf proj_w, proj_b;
+};
+
+namespace {
+struct VGeom {
+  int H, W, Hp0, Wp0, H0, W0, Hs[4], Ws[4];
+};
+VGeom video_geom(int H, int W) {
+  VGeom g;
+  g.H = H; g.W = W;
+  g.Hp0 = H + 6; g.Wp0 = round_up_int(W + 8, 8);
+  g.H0 = (H - 1) / 2 + 1; g.W0 = (W - 1) / 2 + 1;
+  int h = (g.H0 - 1) / 2 + 1, w = (g.W0 - 1) / 2 + 1;   // 3x3 / 2 max-pool, pad 1
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }  // 3x3 / 2 conv, pad 1
+    g.Hs[i] = h; g.Ws[i] = w;
+  }
+  return g;
+}
+const int kVC[4] = {64, 128, 256, 512};
+
+struct VWs {
+  void *vp, *o0, *buf[4][3], *pooled;
+};
+size_t video_carve(const svt_video* v, int B, int T, const VGeom& g, void* base, VWs* out) {
+  Carver c(base);
+  const size_t es = esize(v->prec);
+  const size_t F = (size_t)B * T;
+  VWs w;
+  w.vp = c.take((size_t)B * (T + 4) * g.Hp0 * g.Wp0 * es);
+  w.o0 = c.take(F * g.H0 * g.W0 * 64 * es);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j) w.buf[i][j] = c.take(F * (g.Hs[i] + 2) * (g.Ws[i] + 2) * kVC[i] * es);
+  w.pooled = c.take(F * 512 * es);
+  if (out) *out = w;
+  return c.off;
+}
+
+// eval-mode BatchNorm -> per-channel scale / bias (eps 1e-5, torch.nn.BatchNorm2d/3d default)
+int bn_fold(const ParamMap& P, const std::string& pre, int C, std::vector<float>* scale, std::vector<float>* bias) {
+  const Param *g = nullptr, *b = nullptr, *m = nullptr, *var = nullptr;
+  if (int r = need(P, pre + ".weight", {C}, &g)) return r;
+  if (int r = need(P, pre + ".bias", {C}, &b)) return r;
+  if (int r = need(P, pre + ".running_mean", {C}, &m)) return r;
+  if (int r = need(P, pre + ".running_var", {C}, &var)) return r;
+  scale->resize(C); bias->resize(C);
+  for (int c = 0; c < C; ++c) {
+    const double sc = (double)g->v[c] / std::sqrt((double)var->v[c] + 1e-5);
+    (*scale)[c] = (float)sc;
+    (*bias)[c] = (float)((double)b->v[c] - (double)m->v[c] * sc);
+  }
+  return SVT_OK;
+}
+// conv weight (Cout, Cin, k, k) -> [Cout][(ky*k + kx)*Cin + ci] with the BN scale folded
+int fold_conv(int prec, const ParamMap& P, const std::string& wkey, const std::string& bnkey, int Cout, int Cin, int k, VConv* out) {
+  const Param* w = nullptr;
+  if (int r = need(P, wkey, {Cout, Cin, k, k}, &w)) return r;
+  std::vector<float> sc, bi;
+  if (int r = bn_fold(P, bnkey, Cout, &sc, &bi)) return r;
+  std::vector<float> t((size_t)Cout * k * k * Cin);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          t[(size_t)co * k * k * Cin + (size_t)(ky * k + kx) * Cin + ci] = w->v[(((size_t)co * Cin + ci) * k + ky) * k + kx] * sc[co];
+  if (int r = upload_operand(prec, out->w, t.data(), t.size())) return r;
+  return upload_f32(out->bias, bi.data(), bi.size());
+}
+int upload_vec(const ParamMap& P, const std::string& key, int C, DevBuf* out) {
+  const Param* p = nullptr;
+  if (int r = need(P, key, {C}, &p)) return r;
+  return upload_f32(*out, p->v.data(), p->v.size());
+}
+}  // namespace
+
+extern "C" {
+
+int svt_video_create(int32_t embed_dim, int32_t precision, int device, svt_video** out) {
+  if (!out || embed_dim < 8 || embed_dim % 8) { set_error("svt_video_create: embed_dim must be a positive multiple of 8"); return SVT_ERR_INVALID; }
+  if (precision != SVT_PREC_FP32 && precision != SVT_PREC_BF16) { set_error("svt_video_create: precision"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  svt_video* v = new svt_video();
+  v->E = embed_dim; v->prec = precision; v->device = device;
+  *out = v;
+  return SVT_OK;
+}
+void svt_video_destroy(svt_video* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  delete v;
+}
+int svt_video_load_param(svt_video* v, const char* key, const void* data_host, int dtype, const int64_t* shape, int ndim) {
+  if (!v) { set_error("null video front-end"); return SVT_ERR_INVALID; }
+  v->finalized = false;
+  return load_param_into(v->params, key, data_host, dtype, shape, ndim);
+}
+int svt_video_finalize(svt_video* v) {
+  if (!v) { set_error("null video front-end"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(v->device));
+  const ParamMap& P = v->params;
+  const Param* p = nullptr;
+  // ---- stem: (64,1,5,7,7) + BatchNorm3d + PReLU(64) ----
+  if (int r = need(P, "resnet.frontend3D.0.weight", {64, 1, 5, 7, 7}, &p)) return r;
+  std::vector<float> sc, bi;
+  if (int r = bn_fold(P, "resnet.frontend3D.1", 64, &sc, &bi)) return r;
+  auto wat = [&](int c, int dt, int dy, int dx) { return p->v[(((size_t)c * 5 + dt) * 7 + dy) * 7 + dx] * sc[c]; };
+  if (v->prec) {
+    // MFMA A-operand fragments [10 k-steps][4 channel blocks][64 lanes][8]: lane (i = lane & 15, cq = lane >> 4) holds
+    // channel (i>>2)*16 + nb*4 + (i&3), k chunk s = ks*4 + cq = (dt, dy) row, element e = x tap e-1 (e = 0: alignment pad)
+    std::vector<float> t((size_t)10 * 4 * 64 * 8, 0.f);
+    for (int ks = 0; ks < 10; ++ks)
+      for (int nb = 0; nb < 4; ++nb)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, cq = lane >> 4, c = (i >> 2) * 16 + nb * 4 + (i & 3), sidx = ks * 4 + cq;
+          if (sidx >= 35) continue;
+          for (int e = 1; e < 8; ++e) t[(((size_t)ks * 4 + nb) * 64 + lane) * 8 + e] = wat(c, sidx / 7, sidx % 7, e - 1);
+        }
+    if (int r = upload_operand(1, v->stem_w, t.data(), t.size())) return r;
+  } else {
+    std::vector<float> t((size_t)280 * 64, 0.f);  // [(dt*7+dy)*8 + j][c]
+    for (int c = 0; c < 64; ++c)
+      for (int dt = 0; dt < 5; ++dt)
+        for (int dy = 0; dy < 7; ++dy)
+          for (int j = 1; j < 8; ++j) t[(size_t)((dt * 7 + dy) * 8 + j) * 64 + c] = wat(c, dt, dy, j - 1);
+    if (int r = upload_f32(v->stem_w, t.data(), t.size())) return r;
+  }
+  if (int r = upload_f32(v->stem_bias, bi.data(), bi.size())) return r;
+  if (int r = upload_vec(P, "resnet.frontend3D.2.weight", 64, &v->stem_slope)) return r;
+  // ---- trunk ----
+  int cin = 64;
+  for (int li = 0; li < 4; ++li) {
+    const int C = kVC[li];
+    for (int b = 0; b < 2; ++b) {
+      const std::string pre = "resnet.trunk.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+      if (int r = fold_conv(v->prec, P, pre + ".conv1.weight", pre + ".bn1", C, b == 0 ? cin : C, 3, &v->conv1[li][b])) return r;
+      if (int r = upload_vec(P, pre + ".relu1.weight", C, &v->conv1[li][b].slope)) return r;
+      if (int r = fold_conv(v->prec, P, pre + ".conv2.weight", pre + ".bn2", C, C, 3, &v->conv2[li][b])) return r;
+      if (int r = upload_vec(P, pre + ".relu2.weight", C, &v->slope2[li][b])) return r;
+      if (b == 0 && li > 0)
+        if (int r = fold_conv(v->prec, P, pre + ".downsample.0.weight", pre + ".downsample.1", C, cin, 1, &v->down[li])) return r;
+    }
+    cin = C;
+  }
+  if (int r = need(P, "proj.weight", {v->E, 512}, &p)) return r;
+  if (int r = upload_operand(v->prec, v->proj_w, p->v.data(), p->v.size())) return r;
+  if (int r = upload_vec(P, "proj.bias", v->E, &v->proj_b)) return r;
+  v->finalized = true;
+  return SVT_OK;
+}
+
+int64_t svt_video_workspace_bytes(const svt_video* v, int32_t batch, int32_t t, int32_t h, int32_t w) {
+  if (!v || batch < 1 || t < 1 || h < 8 || w < 8) return -1;
+  return (int64_t)video_carve(v, batch, t, video_geom(h, w), nullptr, nullptr);
+}
+
+int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!v || !video_dev || !out_dev || !workspace_dev) { set_error("svt_video_forward: null argument"); return SVT_ERR_INVALID; }
+  if (!v->finalized) { set_error("svt_video_forward: call svt_video_finalize first"); return SVT_ERR_STATE; }
+  if (batch < 1 || t < 1 || h < 8 || w < 8) { set_error("svt_video_forward: bad geometry"); return SVT_ERR_INVALID; }
+  const VGeom g = video_geom(h, w);
+  VWs ws;
+  if (video_carve(v, batch, t, g, workspace_dev, &ws) > workspace_bytes) { set_error("svt_video_forward: workspace too small"); return SVT_ERR_WORKSPACE; }
+  if ((long)batch * t * g.Hs[0] * g.Ws[0] > 2000000000L) { set_error("svt_video_forward: too many frames for one call"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(v->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int prec = v->prec;
+  const size_t es = esize(prec);
+  const long F = (long)batch * t;
+  if (launch_video_pad(prec, video_dev, batch, t, h, w, g.Hp0, g.Wp0, ws.vp, s)) return SVT_ERR_HIP;
+  if (launch_conv3d_front(prec, ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0, g.H0,
+                          g.W0, ws.o0, s)) return SVT_ERR_HIP;
+  // zero halos: the padded stage buffers are written in their interior only
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j)
+      SVT_HIP(hipMemsetAsync(ws.buf[i][j], 0, (size_t)F * (g.Hs[i] + 2) * (g.Ws[i] + 2) * kVC[i] * es, s));
+  if (launch_maxpool_3x3s2(prec, ws.o0, F, g.H0, g.W0, 64, g.Hs[0], g.Ws[0], ws.buf[0][0], s)) return SVT_ERR_HIP;
+
+  // one k x k convolution (k = 3: pad 1; k = 1: no pad) over the zero-haloed channels-last tensor `in`
+  auto conv = [&](const void* in, int Hin, int Win, int Cin, void* out, int Ho, int Wo, int Cout, int stride, int k,
+                  const VConv& cw, const float* slope, const void* resid) -> int {
+    GemmArgs a;
+    const long Wpi = Win + 2, Hpi = Hin + 2, Wpo = Wo + 2, Hpo = Ho + 2;
+    a.gen = 1;
+    a.A = (const char*)in + (k == 1 ? (size_t)(Wpi + 1) * Cin * es : 0);
+    a.W = cw.w.p; a.C = out; a.bias = cw.bias.as<float>();
+    a.M = (int)(F * Ho * Wo); a.N = Cout; a.K = k * k * Cin;
+    a.a_rstride = (long)stride * Cin;
+    a.a_d1 = Wo; a.a_e1 = (long)stride * Wpi * Cin - (long)Wo * stride * Cin;
+    a.a_d2 = Wo * Ho; a.a_e2 = Hpi * Wpi * Cin - (long)Ho * stride * Wpi * Cin;
+    if (k == 3) { a.kseg = 3 * Cin; a.kseg_stride = Wpi * Cin; }
+    a.ldw = (long)k * k * Cin; a.ldc = Cout;
+    a.c_d1 = Wo; a.c_e1 = 2L * Cout;
+    a.c_d2 = Wo * Ho; a.c_e2 = (Hpo * Wpo - (long)Ho * Wpo) * Cout;
+    a.c_base = (Wpo + 1) * Cout;
+    a.act = slope ? ACT_PRELU : ACT_NONE; a.slope = slope;
+    a.resid = (const float*)resid; a.resid_first = 1; a.resid_op_type = 1;
+    return launch_gemm(prec, a, s);
+  };
+  const void* x = ws.buf[0][0];
+  int Hin = g.Hs[0], Win = g.Ws[0], cin = 64;
+  for (int li = 0; li < 4; ++li) {
+    const int C = kVC[li], Ho = g.Hs[li], Wo = g.Ws[li];
+    for (int b = 0; b < 2; ++b) {
+      const int stride = (b == 0 && li > 0) ? 2 : 1;
+      // the stage's three buffers minus the block input (which is also the identity residual and must survive)
+      void* fr[3]; int nf = 0;
+      for (int j = 0; j < 3; ++j) if (ws.buf[li][j] != x) fr[nf++] = ws.buf[li][j];
+      void* t1 = fr[0];
+      void* outb = fr[1];
+      const void* res = x;
+      if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
+      if (stride == 2) {  // first block of stages 2-4: the residual is the 1x1 stride-2 conv + BN of the block input
+        if (int r = conv(x, Hin, Win, cin, fr[1], Ho, Wo, C, 2, 1, v->down[li], nullptr, nullptr)) return r;
+        res = fr[1];
+        outb = fr[2];
+      }
+      if (int r = conv(t1, Ho, Wo, C, outb, Ho, Wo, C, 1, 3, v->conv2[li][b], v->slope2[li][b].as<float>(), res)) return r;
+      x = outb; Hin = Ho; Win = Wo; cin = C;
+    }
+  }
+  if (launch_avgpool_interior(prec, x, F, g.Hs[3], g.Ws[3], 512, ws.pooled, s)) return SVT_ERR_HIP;
+  GemmArgs pj;
+  pj.A = ws.pooled; pj.W = v->proj_w.p; pj.C = out_dev; pj.bias = v->proj_b.as<float>();
+  pj.M = (int)F; pj.N = v->E; pj.K = 512; pj.a_rpb = (int)F; pj.a_rstride = 512; pj.ldw = 512; pj.ldc = v->E; pj.out_f32 = 1;
+  if (launch_gemm(prec, pj, s)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+
 // ---- validation losses ----
 static int loss_common_checks(const char* who, int64_t batch, int64_t t_pred, int64_t t_tgt, int32_t allowed, int32_t reduction,
                               size_t ws_bytes, int64_t* T) {

@@ -111,7 +111,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define SVT_LAUNCH_CHECK() SVT_HIP(hipGetLastError())
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_PRELU = 3 };
 
 // C[z][m][n] = act(alpha * sum_k A[z][m][k] * W[z][n][k] + bias[n]) + resid[z][m][n]
 // A rows may overlap (implicit-GEMM view of a strided 1-D convolution over a channels-last tensor):
@@ -133,6 +133,18 @@ struct GemmArgs {
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
+  // ---- generalised addressing / epilogue (gen = 1): 2-D convolution as implicit GEMM over a zero-padded
+  // channels-last tensor (the lip front-end's ResNet), served by the register-staged kernel ----
+  int gen = 0;
+  int a_d1 = 1, a_d2 = 1;            // A row offset = m * a_rstride + (m / a_d1) * a_e1 + (m / a_d2) * a_e2
+  long a_e1 = 0, a_e2 = 0;
+  int kseg = 0;                      // K is made of kseg-element contiguous runs kseg_stride elements apart (0 = one run)
+  long kseg_stride = 0;
+  int c_d1 = 1, c_d2 = 1;            // C (and resid) row offset = c_base + m * ldc + (m / c_d1) * c_e1 + (m / c_d2) * c_e2
+  long c_e1 = 0, c_e2 = 0, c_base = 0;
+  const float* slope = nullptr;      // ACT_PRELU: per-column negative slope
+  int resid_first = 0;               // act(acc + bias + resid) instead of act(acc + bias) + resid
+  int resid_op_type = 0;             // resid is stored in the operand type (bf16 in bf16 mode), not fp32
   long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
 };
 
@@ -205,6 +217,12 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
                       hipStream_t s);
 // frame head for K in {512,768,1024}, N <= 32: weight in LDS, four rows per wave (HBM-bound)
+// lip front-end (video.hip)
+int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
+int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,
+                        int Wp, int H0, int W0, void* out, hipStream_t s);
+int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s);
+int launch_avgpool_interior(int prec, const void* in, long F, int H, int W, int C, void* out, hipStream_t s);
 // validation losses (masked BCE-with-logits / NLL, speechbrain/nnet/losses.py) and the narrow (log-)softmax
 int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,
                     const float* pos_weight, float* per_frame, double* sums, hipStream_t s);

@@ -40,7 +40,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool GEN = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int EPP = OpTraits<T>::EPP;
   constexpr int BK = OpTraits<T>::BK;
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     int r = (i * 4 + wave) * 8 + prow;  // row in tile
     int m = m0 + r;
     if (m > p.M - 1) m = p.M - 1;
-    long off = (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride;
+    long off;
+    if constexpr (GEN) off = (long)m * p.a_rstride + (long)(m / p.a_d1) * p.a_e1 + (long)(m / p.a_d2) * p.a_e2;
+    else off = (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride;
     xsrc[i] = A + off + pc * EPP;
     const int e0 = pc * EPP;
     const int ks = e0 / 32, cq = (e0 % 32) / 8, h = (e0 % 8) / EPP;
@@ -115,9 +117,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   auto stage_load = [&](int kt) {
     const int kbase = kt * BK;
     const bool ok = (kbase + pc * EPP) < p.K;
+    long ka = kbase;
+    if constexpr (GEN) {
+      if (p.kseg) ka = (long)(kbase / p.kseg) * p.kseg_stride + (kbase % p.kseg);
+    }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      xr[i] = ok ? *(const uint4*)(xsrc[i] + kbase) : uint4{0, 0, 0, 0};
+      xr[i] = ok ? *(const uint4*)(xsrc[i] + ka) : uint4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
@@ -195,6 +201,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       for (int j = 0; j < 16; ++j) if (nbase + j < p.N) bv[j] = bias[nbase + j];
     }
   }
+  if constexpr (GEN) {
+    float sv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sv[j] = (p.slope && nbase + j < p.N) ? p.slope[nbase + j] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wm * 64 + mb * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      const long idx = coff + p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + nbase;
+      float v[16], rs[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rs[j] = 0.f;
+      if (p.resid) {
+        if (full) {
+          if (p.resid_op_type && sizeof(T) == 2) {
+#pragma unroll
+            for (int j8 = 0; j8 < 2; ++j8) {
+              const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)p.resid + idx + j8 * 8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) rs[j8 * 8 + j] = (float)r8[j];
+            }
+          } else {
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+              const float4 r4 = *(const float4*)(p.resid + idx + j4 * 4);
+              rs[j4 * 4 + 0] = r4.x; rs[j4 * 4 + 1] = r4.y; rs[j4 * 4 + 2] = r4.z; rs[j4 * 4 + 3] = r4.w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (nbase + j < p.N)
+              rs[j] = (p.resid_op_type && sizeof(T) == 2) ? (float)((const bf16_t*)p.resid)[idx + j] : p.resid[idx + j];
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nb * 4 + r;
+          float x = acc[nb][mb][r] * p.alpha + bv[j];
+          if (p.resid_first) x += rs[j];
+          if (p.act == ACT_PRELU) x = x > 0.f ? x : x * sv[j];
+          else x = apply_act(x, p.act);
+          if (!p.resid_first) x += rs[j];
+          v[j] = x;
+        }
+      if (full) {
+        if (p.out_f32 || sizeof(T) == 4) {
+          float* c = (float*)p.C + idx;
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4)
+            *(float4*)(c + j4 * 4) = float4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
+        } else {
+          bf16_t* c = (bf16_t*)p.C + idx;
+#pragma unroll
+          for (int j8 = 0; j8 < 2; ++j8) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j8 * 8 + j];
+            *(bf16x8*)(c + j8 * 8) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (nbase + j >= p.N) continue;
+          if (p.out_f32 || sizeof(T) == 4) ((float*)p.C)[idx + j] = v[j];
+          else ((bf16_t*)p.C)[idx + j] = (bf16_t)v[j];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int m = m0 + wm * 64 + mb * 16 + (lane & 15);
@@ -241,14 +321,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool GEN = false>
 int launch_one(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     attr_set = true;
   }
@@ -256,7 +336,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.nz +
                        (double)a.M * a.N * a.nz * ((a.out_f32 || sizeof(T) == 4) ? 4 : 2);
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN>), grid, dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, GEN>), grid, dim3(256), lds_bytes, s, a);
   prof_end(s, flops, bytes);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -279,8 +359,17 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
   g.c_vec = mult(a.ldc, cel) && mult(a.c_z1, cel) && mult(a.c_z2, cel) && !((uintptr_t)a.C & 15) &&
             mult(a.ldc, 4) && mult(a.c_z1, 4) && mult(a.c_z2, 4) && !((uintptr_t)a.resid & 15) &&
             mult(a.bias_z2, 4) && !((uintptr_t)a.bias & 15);
-  if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   const bool narrow = a.N <= 64;
+  if (a.gen) {
+    const int kel = prec ? 64 : 32;
+    if (a.kseg && (a.kseg % kel || a.K % a.kseg)) { set_error("gemm: kseg must divide K and be a multiple of the K slab"); return -1; }
+    if (!mult(a.a_e1, epp) || !mult(a.a_e2, epp) || !mult(a.kseg_stride, epp)) { set_error("gemm: generalised A strides must be 16-byte aligned"); return -1; }
+    g.c_vec = g.c_vec && mult(a.c_e1, cel) && mult(a.c_e2, cel) && mult(a.c_base, cel) &&
+              (!a.resid || !a.resid_op_type || !((uintptr_t)a.resid & 15));
+    if (prec) return narrow ? launch_one<bf16_t, 256, 64, true>(g, s) : launch_one<bf16_t, 128, 128, true>(g, s);
+    return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);
+  }
+  if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
   return narrow ? launch_one<float, 256, 64>(g, s) : launch_one<float, 128, 128>(g, s);
 }

@@ -1,0 +1,56 @@
+"""GPU: the AV-HuBERT lip front-end through the C-ABI against the golden vectors captured from the
+reference's own resnet.py (tests/golden/video_front.pt).  fp32 mode: within 1e-3 (relative to the output scale);
+bf16 mode: bounded error, printed."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import svt_speechbrain_amd as S  # noqa: E402
+from svt_speechbrain_amd import _lib  # noqa: E402
+from svt_speechbrain_amd import weights as W  # noqa: E402
+from svt_speechbrain_amd.video import SubModel  # noqa: E402
+
+DEV = "cuda:0"
+CASES = ["roi88", "roi88_t1", "roi32", "roi50"]
+
+
+def _run(fx, precision):
+    m = SubModel(512, fx["E"], "prelu", precision=precision, seed=1)
+    m.load_state_dict(W.seeded_video_frontend_state_dict(fx["E"], seed=fx["weight_seed"]), strict=True)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(fx["video_seed"])
+    video = torch.randn(fx["B"], 1, fx["T"], fx["HW"], fx["HW"], generator=g)
+    y = m(video.to(DEV))
+    assert y.shape == (fx["B"], fx["E"], fx["T"])
+    return y.transpose(1, 2).cpu()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_video_frontend_fp32_vs_reference_golden(golden, name):
+    fx = golden("video_front")[name]
+    y = _run(fx, "fp32")
+    ref = fx["feats"]
+    err = (y - ref).abs().max().item()
+    assert err < 1e-3 * max(1.0, ref.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_video_frontend_bf16_error_bound(golden, name):
+    fx = golden("video_front")[name]
+    y = _run(fx, "bf16")
+    ref = fx["feats"]
+    d = (y - ref).abs()
+    scale = ref.abs().max().item()
+    print(f"video front-end bf16 {name}: max |d| {d.max().item():.4f}  mean |d| {d.mean().item():.5f}  (|ref| max {scale:.2f}, std {ref.std().item():.3f})")
+    assert d.max().item() < 0.06 * scale and d.mean().item() < 0.01 * scale
+
+
+def test_video_frontend_errors():
+    m = SubModel(512, 64, "prelu", precision="fp32").to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 2, 32, 32, device=DEV))
+    with pytest.raises(_lib.SvtError):
+        m(torch.zeros(1, 1, 2, 32, 32))
+    with pytest.raises(RuntimeError):  # strict load, like torch
+        m.load_state_dict({"proj.weight": torch.zeros(64, 512)})
