@@ -1171,7 +1171,7 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   // zero halos: the padded stage buffers are written in their interior only
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 3; ++j)
-      SVT_HIP(hipMemsetAsync(ws.buf[i][j], 0, (size_t)F * (g.Hs[i] + 2) * (g.Ws[i] + 2) * kVC[i] * es, s));
+      if (launch_zero_halo(prec, ws.buf[i][j], F, g.Hs[i] + 2, g.Ws[i] + 2, kVC[i], s)) return SVT_ERR_HIP;
   if (launch_maxpool_3x3s2(prec, ws.o0, F, g.H0, g.W0, 64, g.Hs[0], g.Ws[0], ws.buf[0][0], s)) return SVT_ERR_HIP;
 
   // one k x k convolution (k = 3: pad 1; k = 1: no pad) over the zero-haloed channels-last tensor `in`

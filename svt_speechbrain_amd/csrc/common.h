@@ -222,6 +222,7 @@ int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int H
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,
                         int Wp, int H0, int W0, void* out, hipStream_t s);
 int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s);
+int launch_zero_halo(int prec, void* buf, long F, int Hp, int Wp, int C, hipStream_t s);
 int launch_avgpool_interior(int prec, const void* in, long F, int H, int W, int C, void* out, hipStream_t s);
 // validation losses (masked BCE-with-logits / NLL, speechbrain/nnet/losses.py) and the narrow (log-)softmax
 int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,

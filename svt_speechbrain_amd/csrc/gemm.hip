@@ -366,6 +366,10 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
     if (!mult(a.a_e1, epp) || !mult(a.a_e2, epp) || !mult(a.kseg_stride, epp)) { set_error("gemm: generalised A strides must be 16-byte aligned"); return -1; }
     g.c_vec = g.c_vec && mult(a.c_e1, cel) && mult(a.c_e2, cel) && mult(a.c_base, cel) &&
               (!a.resid || !a.resid_op_type || !((uintptr_t)a.resid & 15));
+    // N >= 128 with bf16 output: the LDS-DMA pipeline (needs 64-element K slabs inside every run and nz == 1)
+    if (prec && gemm_dma_eligible(g) && !a.out_f32 && a.nz == 1 && (!a.resid || a.resid_op_type) && a.alpha == 1.f &&
+        (a.kseg == 0 || a.kseg % 64 == 0))
+      return launch_gemm_dma(g, s);
     if (prec) return narrow ? launch_one<bf16_t, 256, 64, true>(g, s) : launch_one<bf16_t, 128, 128, true>(g, s);
     return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);
   }

@@ -127,6 +127,79 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
   }
 }
 
+// generalised variant (GemmArgs::gen): rows land at c_base + m*ldc + (m/c_d1)*c_e1 + (m/c_d2)*c_e2 (interior of a
+// zero-haloed channels-last tensor), optional residual in the operand type added BEFORE the activation, per-column
+// PReLU slope.  bf16 output only.
+template <int MB, int BM>
+__device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, const f32x4& a0, const f32x4& a1, const f32x4& a2,
+                                                   const f32x4& a3, int mb, float* patch, int lane, int wm, int wn, int m0,
+                                                   int n0, const float* bias) {
+  constexpr int PITCH = 68;
+  const int m16 = lane & 15, q = lane >> 4;
+  const f32x4 accs[4] = {a0, a1, a2, a3};
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    f32x4 v = accs[nb];
+    v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+    *(f32x4*)(patch + m16 * PITCH + q * 16 + nb * 4) = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int mbase = m0 + wm * (BM / 2) + mb * 16;
+  const int c8 = (lane & 7) * 8;
+  const int n = n0 + wn * 64 + c8;
+  float bb[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bb[j] = 0.f; ss[j] = 0.f; }
+  if (n < p.N) {
+    if (bias) {
+      const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
+      bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
+    if (p.slope) {
+      const float4 s0 = *(const float4*)(p.slope + n), s1 = *(const float4*)(p.slope + n + 4);
+      ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 8 + (lane >> 3);
+    const int m = mbase + r;
+    const float4 v0 = *(const float4*)(patch + r * PITCH + c8), v1 = *(const float4*)(patch + r * PITCH + c8 + 4);
+    if (m < p.M && n < p.N) {
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const long idx = p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + n;
+      float rr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rr[j] = 0.f;
+      if (p.resid) {
+        const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)p.resid + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rr[j] = (float)r8[j];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = v[j] + bb[j];
+        if (p.resid_first) x += rr[j];
+        if (p.act == ACT_PRELU) x = x > 0.f ? x : x * ss[j];
+        else x = apply_act(x, p.act);
+        if (!p.resid_first) x += rr[j];
+        o[j] = (bf16_t)x;
+      }
+      *(bf16x8*)((bf16_t*)p.C + idx) = o;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int MB, int BM, int... I>
+__device__ __forceinline__ void epilogue_seq_gen(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[4][MB],
+                                                 float* patch, int lane, int wm, int wn, int m0, int n0, const float* bias) {
+  (epilogue_block_gen<MB, BM>(p, acc[0][I], acc[1][I], acc[2][I], acc[3][I], I, patch, lane, wm, wn, m0, n0, bias), ...);
+}
+
 template <int MB, int BM, bool OUT32, int... I>
 __device__ __forceinline__ void epilogue_seq(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[4][MB],
                                              float* patch, int lane, int wm, int wn, int m0, int n0, long coff,
@@ -150,7 +223,7 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmArgs& p, f32x4 (&ac
 // One tile per workgroup.  The LDS is a ring of 5 slots of 32 KiB; units alternate A-slab / W-slab of the same
 // 64-deep K step (A_0 W_0 A_1 W_1 ...), each filled by full-line LDS-DMA (8 rows x 128 B per wave-instruction).
 // While slab j is multiplied, units A_{j+1}, W_{j+1}, A_{j+2} are in flight, retired by a counted vmcnt.
-template <int BM>
+template <int BM, bool GEN = false>
 __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 32;
@@ -186,7 +259,8 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   for (int i = 0; i < GA; ++i) {
     int m = m0 + (wave + 8 * i) * 8 + r8;
     if (m > p.M - 1) m = p.M - 1;
-    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
+    if constexpr (GEN) asrc[i] = A + (long)m * p.a_rstride + (long)(m / p.a_d1) * p.a_e1 + (long)(m / p.a_d2) * p.a_e2 + ch * 8;
+    else asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8;
   }
 #pragma unroll
   for (int i = 0; i < GW; ++i) {
@@ -196,11 +270,27 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
     if (n > p.N - 1) n = p.N - 1;
     wsrc[i] = W + (long)n * p.ldw + ch * 8;
   }
+  // GEN: K is made of kseg-element runs kseg_stride apart; the element offset of the NEXT A slab to fetch is tracked
+  // incrementally (aoff), a_left = slabs left in the current run
+  long aoff = 0;
+  const int spk = GEN ? (p.kseg ? p.kseg / BK : 0x7fffffff) : 0;
+  int a_left = spk;
+  auto a_advance = [&]() {
+    if constexpr (GEN) {
+      aoff += BK;
+      if (--a_left == 0) { a_left = spk; aoff += p.kseg_stride - p.kseg; }
+    }
+  };
   // unit u: even -> A slab u/2, odd -> W slab u/2; slot u % 5
   auto issue_a = [&](int kt, int slot) {
 #pragma unroll
-    for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+    for (int i = 0; i < GA; ++i) {
+      if constexpr (GEN)
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + aoff), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
+    }
+    a_advance();
   };
   auto issue_w = [&](int kt, int slot) {
 #pragma unroll
@@ -257,8 +347,9 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
     } else {                                                                                                     \
       if (kt + 2 < nk) {                                                                                         \
         _Pragma("unroll") for (int i2 = half_ * ((GA + 1) / 2); i2 < (half_ ? GA : (GA + 1) / 2); ++i2)          \
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i2] + (kt + 2) * BK),                                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i2] + (GEN ? aoff : (long)(kt + 2) * BK)),            \
                                              (lptr_t)(lds + ((2 * kt + 4) % NSLOT) * SLOT + (wave + 8 * i2) * 64), 16, 0, 0); \
+        if (half_) a_advance();                                                                                  \
       }                                                                                                          \
     }                                                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
@@ -317,7 +408,9 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
   if (tr) t_main = wall_clock64();
   __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
-  if (p.dbg != 3)
+  if constexpr (GEN)
+    epilogue_seq_gen<MB, BM>(std::make_integer_sequence<int, MB>{}, p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, bias);
+  else if (p.dbg != 3)
     epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
   else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
   if (tr && lane == 0 && (wave & 3) == 0) {
@@ -609,21 +702,21 @@ int launch_pers(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int BM>
+template <int BM, bool GEN = false>
 int launch_pp8(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
   const size_t lds_bytes = 5 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     attr_set = true;
   }
   const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pp8_kernel<BM>), grid, dim3(512), lds_bytes, s, a);
+  hipLaunchKernelGGL((gemm_pp8_kernel<BM, GEN>), grid, dim3(512), lds_bytes, s, a);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -657,6 +750,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
   }
   if (g_gemm_force_bm) best = g_gemm_force_bm;
+  if (a.gen) {  // generalised addressing: one-tile kernel only (it also carries the residual epilogue)
+    if (best == 256) return launch_pp8<256, true>(a, s);
+    if (best == 192) return launch_pp8<192, true>(a, s);
+    return launch_pp8<128, true>(a, s);
+  }
   const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
                        a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;

@@ -157,6 +157,55 @@ __global__ void maxpool_3x3s2_kernel(const T* in, long F, int H0, int W0, int C,
   }
 }
 
+// bf16: 8 channels (16 bytes) per thread
+__global__ void maxpool_3x3s2_bf16x8_kernel(const bf16_t* in, long F, int H0, int W0, int C, int H1, int W1, bf16_t* out) {
+  const int C8 = C / 8;
+  const long n = F * H1 * W1 * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8) * 8;
+    long r = i / C8;
+    const int x1 = (int)(r % W1);
+    r /= W1;
+    const int y1 = (int)(r % H1);
+    const long f = r / H1;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -3.4e38f;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * y1 - 1 + dy;
+      if (y < 0 || y >= H0) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * x1 - 1 + dx;
+        if (x < 0 || x >= W0) continue;
+        const bf16x8 v = *(const bf16x8*)(in + ((f * H0 + y) * W0 + x) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)m[j];
+    *(bf16x8*)(out + ((f * (H1 + 2) + y1 + 1) * (W1 + 2) + x1 + 1) * C + c) = o;
+  }
+}
+
+// zero the one-pixel halo of [F][Hp][Wp][C] (16-byte stores; C * sizeof(T) is a multiple of 16)
+__global__ void zero_halo_kernel(uint4* buf, long F, int Hp, int Wp, int c16) {
+  const int nh = 2 * Wp + 2 * (Hp - 2);
+  const long n = F * nh * c16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c16);
+    long r = i / c16;
+    const int hidx = (int)(r % nh);
+    const long f = r / nh;
+    int y, x;
+    if (hidx < Wp) { y = 0; x = hidx; }
+    else if (hidx < 2 * Wp) { y = Hp - 1; x = hidx - Wp; }
+    else { const int k = hidx - 2 * Wp; y = 1 + (k >> 1); x = (k & 1) ? Wp - 1 : 0; }
+    buf[((f * Hp + y) * Wp + x) * c16 + c] = uint4{0, 0, 0, 0};
+  }
+}
+
 // mean over the H x W interior of [F][H+2][W+2][C] -> [F][C] (operand type; the projection GEMM reads it)
 template <typename T>
 __global__ void avgpool_interior_kernel(const T* in, long F, int H, int W, int C, T* out) {
@@ -211,8 +260,17 @@ int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bi
 
 int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s) {
   const long n = F * H1 * W1 * C;
-  if (prec) hipLaunchKernelGGL(maxpool_3x3s2_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, (const bf16_t*)in, F, H0, W0, C, H1, W1, (bf16_t*)out);
+  if (prec && C % 8 == 0) hipLaunchKernelGGL(maxpool_3x3s2_bf16x8_kernel, dim3(grid_of(n / 8)), dim3(256), 0, s, (const bf16_t*)in, F, H0, W0, C, H1, W1, (bf16_t*)out);
+  else if (prec) hipLaunchKernelGGL(maxpool_3x3s2_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, (const bf16_t*)in, F, H0, W0, C, H1, W1, (bf16_t*)out);
   else hipLaunchKernelGGL(maxpool_3x3s2_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, (const float*)in, F, H0, W0, C, H1, W1, (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_zero_halo(int prec, void* buf, long F, int Hp, int Wp, int C, hipStream_t s) {
+  const int c16 = C * (prec ? 2 : 4) / 16;
+  const long n = F * (2 * Wp + 2 * (Hp - 2)) * c16;
+  hipLaunchKernelGGL(zero_halo_kernel, dim3(grid_of(n)), dim3(256), 0, s, (uint4*)buf, F, Hp, Wp, c16);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,32 @@
+"""Timing of the lip front-end (BASELINE config C4 shape: B=16 clips x 500 frames of 88x88)."""
+import argparse
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svt_speechbrain_amd.video import SubModel
+from svt_speechbrain_amd import _lib
+import ctypes as C
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--frames", type=int, default=500)
+ap.add_argument("--precision", default="bf16")
+a = ap.parse_args()
+dev = "cuda:0"
+m = SubModel(512, 1024, "prelu", precision=a.precision).to(dev)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(a.batch, 1, a.frames, 88, 88, generator=g).to(dev)
+for _ in range(2):
+    y = m(x)
+torch.cuda.synchronize()
+n = 5
+t = time.perf_counter()
+for _ in range(n):
+    y = m(x)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / n
+gf = 632e6 * a.batch * a.frames
+print(f"lip front-end {a.precision}: {dt*1e3:.2f} ms per batch of {a.batch} x {a.frames} frames -> {a.batch/dt:.0f} clips/s, "
+      f"{a.batch*a.frames/dt:.0f} frames/s, {gf/dt/1e12:.0f} TFLOP/s (632 MFLOP per frame)")
