@@ -94,6 +94,13 @@ def encoder_forward(sd: Dict[str, torch.Tensor], cfg, wav: torch.Tensor, normali
     if normalize_wav:
         x = F.layer_norm(x, x.shape)  # whole-batch LN, eps 1e-5
     h = conv_feature_extractor(sd, cfg, x, prefix, taps).transpose(1, 2)  # (B, T, C)
+    return encoder_tail(sd, cfg, h, output_norm, prefix, taps)
+
+
+def encoder_tail(sd: Dict[str, torch.Tensor], cfg, h: torch.Tensor, output_norm: bool = True, prefix: str = "",
+                 taps: Optional[dict] = None) -> torch.Tensor:
+    """Everything after the conv feature extractor: feature projection, positional conv, transformer layers, the
+    wrapper's whole-batch output norm.  h: (B, T, C) features."""
     C = h.shape[-1]
     eps = cfg.layer_norm_eps
     if cfg.feat_proj_layer_norm:
@@ -413,3 +420,51 @@ def video_frontend_forward(sd: Dict[str, torch.Tensor], video: torch.Tensor, pre
             x = F.prelu(out + res, sub[p + ".relu2.weight"])
     x = x.mean(dim=(2, 3)).view(B, T, 512)
     return F.linear(x, g("proj.weight"), g("proj.bias"))
+
+
+# fairseq (AV-HuBERT / HuBERT) parameter names -> the HF names the restatement above uses.  The same table as HF's public
+# convert_hubert_original_pytorch_checkpoint_to_pytorch.py MAPPING; fairseq's TransformerEncoder
+# (pos_conv -> [layer_norm] -> layers -> [layer_norm], layer_norm_first = HF do_stable_layer_norm) is the module HF ported.
+FAIRSEQ_TO_HF = [
+    ("layer_norm.", "feature_projection.layer_norm."),
+    ("post_extract_proj.", "feature_projection.projection."),
+    ("encoder.pos_conv.0.", "encoder.pos_conv_embed.conv."),
+    ("encoder.layer_norm.", "encoder.layer_norm."),
+]
+FAIRSEQ_LAYER_TO_HF = [
+    ("self_attn.k_proj.", "attention.k_proj."), ("self_attn.v_proj.", "attention.v_proj."),
+    ("self_attn.q_proj.", "attention.q_proj."), ("self_attn.out_proj.", "attention.out_proj."),
+    ("self_attn_layer_norm.", "layer_norm."), ("fc1.", "feed_forward.intermediate_dense."),
+    ("fc2.", "feed_forward.output_dense."), ("final_layer_norm.", "final_layer_norm."),
+]
+
+
+def fairseq_to_hf_key(k: str) -> Optional[str]:
+    if k.startswith("encoder.layers."):
+        _, _, idx, rest = k.split(".", 3)
+        for a, b in FAIRSEQ_LAYER_TO_HF:
+            if rest.startswith(a):
+                return f"encoder.layers.{idx}.{b}{rest[len(a):]}"
+        return None
+    for a, b in FAIRSEQ_TO_HF:
+        if k.startswith(a):
+            return b + k[len(a):]
+    return None
+
+
+def avhubert_video_forward(sd: Dict[str, torch.Tensor], cfg, video: torch.Tensor, output_norm: bool = True,
+                           prefix: str = "") -> torch.Tensor:
+    """``FairseqAVHubertPretrain.extract_features`` for {"video": video, "audio": None}
+    (N20EMv2/video_only/fairseq_interface.py:461-476 over hubert.py:688-739): lip front-end -> cat([zeros, video], dim=C)
+    -> LayerNorm(2E) -> post_extract_proj -> TransformerEncoder -> optional whole-tensor layer norm.
+    PARITY UNPINNED for the transformer part: fairseq (and hubert.py, which imports it) is not importable in the build
+    container; the restatement relies on the fairseq encoder being the module HF ported (pinned for the audio path)."""
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    fv = video_frontend_forward(sub, video, prefix="feature_extractor_video.")  # (B, T, E)
+    feats = torch.cat([torch.zeros_like(fv), fv], dim=-1)                        # audio half first (hubert.py:706-707)
+    hf = {}
+    for k, v in sub.items():
+        nk = fairseq_to_hf_key(k)
+        if nk is not None:
+            hf[nk] = v
+    return encoder_tail(hf, cfg, feats, output_norm)

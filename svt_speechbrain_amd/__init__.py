@@ -11,6 +11,8 @@ from . import losses  # noqa: F401
 from . import checkpoints  # noqa: F401
 from .checkpoints import Checkpointer  # noqa: F401
 from .losses import bce_loss, nll_loss, Softmax  # noqa: F401
+from . import video  # noqa: F401
+from .video import FairseqAVHubertPretrain  # noqa: F401
 from .song import SongTranscriber, utterance_bounds, save_song_features, feature_path  # noqa: F401
 
 __all__ = ["EncoderConfig", "PRESETS", "config_from_source", "HuggingFaceWav2Vec2", "Linear", "FusionRCA", "Fbank",

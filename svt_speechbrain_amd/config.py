@@ -92,6 +92,20 @@ PRESETS = {
         num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
         num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, feat_extract_norm="layer",
         conv_bias=True, do_stable_layer_norm=True, feat_proj_layer_norm=False),
+    # AV-HuBERT video branch (features-in: no waveform conv stack; the transformer reads cat([audio, video]) features of
+    # width 2 * hidden_size).  LARGE: 24 layers, layer_norm_first (the public large_vox_iter5 / self_large_vox_433h cfg)
+    "avhubert-large-video": EncoderConfig(
+        name="avhubert-large-video", family="avhubert", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+        intermediate_size=4096, conv_dim=(2048,), conv_kernel=(), conv_stride=(), do_stable_layer_norm=True,
+        feat_proj_layer_norm=True),
+    "avhubert-base-video": EncoderConfig(
+        name="avhubert-base-video", family="avhubert", hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+        intermediate_size=3072, conv_dim=(1536,), conv_kernel=(), conv_stride=(), do_stable_layer_norm=True,
+        feat_proj_layer_norm=True),
+    "tiny-avhubert-video": EncoderConfig(
+        name="tiny-avhubert-video", family="avhubert", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(128,), conv_kernel=(), conv_stride=(), num_conv_pos_embeddings=16,
+        num_conv_pos_embedding_groups=4, do_stable_layer_norm=True, feat_proj_layer_norm=True),
 }
 
 

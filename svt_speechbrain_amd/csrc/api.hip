@@ -212,14 +212,19 @@ struct svt_encoder {
 
 static int validate_cfg(const svt_encoder_config& c) {
   if (c.struct_size != (int32_t)sizeof(svt_encoder_config)) { set_error("svt_encoder_config: struct_size mismatch (ABI)"); return SVT_ERR_INVALID; }
-  if (c.num_conv_layers < 1 || c.num_conv_layers > SVT_MAX_CONV_LAYERS) { set_error("num_conv_layers out of range"); return SVT_ERR_INVALID; }
-  if (c.conv_kernel[0] != 10) { set_error("conv layer 0 must have kernel 10 (wav2vec2/HuBERT geometry)"); return SVT_ERR_INVALID; }
-  if (c.conv_stride[0] > 5 || c.conv_stride[0] < 1) { set_error("conv layer 0 stride must be 1..5"); return SVT_ERR_INVALID; }
+  if (c.num_conv_layers < 0 || c.num_conv_layers > SVT_MAX_CONV_LAYERS) { set_error("num_conv_layers out of range"); return SVT_ERR_INVALID; }
+  if (c.num_conv_layers == 0) {
+    // features-in mode (AV-HuBERT video branch): the input is a (B, T, conv_dim[0]) feature tensor, the path starts at
+    // the feature projection
+    if (c.conv_dim[0] < 8 || c.conv_dim[0] % 8) { set_error("features-in mode: conv_dim[0] (the feature width) must be a multiple of 8"); return SVT_ERR_INVALID; }
+    if (c.normalize_wav) { set_error("features-in mode: normalize_wav does not apply"); return SVT_ERR_INVALID; }
+  } else if (c.conv_kernel[0] != 10) { set_error("conv layer 0 must have kernel 10 (wav2vec2/HuBERT geometry)"); return SVT_ERR_INVALID; }
+  if (c.num_conv_layers > 0 && (c.conv_stride[0] > 5 || c.conv_stride[0] < 1)) { set_error("conv layer 0 stride must be 1..5"); return SVT_ERR_INVALID; }
   for (int i = 0; i < c.num_conv_layers; ++i) {
     if (c.conv_dim[i] % 8 || c.conv_dim[i] < 8) { set_error("conv_dim must be a multiple of 8"); return SVT_ERR_INVALID; }
     if (c.conv_kernel[i] < 1 || c.conv_stride[i] < 1) { set_error("bad conv geometry"); return SVT_ERR_INVALID; }
   }
-  if (c.conv_dim[0] > 512) { set_error("conv_dim[0] > 512 unsupported"); return SVT_ERR_INVALID; }
+  if (c.num_conv_layers > 0 && c.conv_dim[0] > 512) { set_error("conv_dim[0] > 512 unsupported"); return SVT_ERR_INVALID; }
   if (c.hidden_size % c.num_heads) { set_error("hidden_size % num_heads != 0"); return SVT_ERR_INVALID; }
   const int dh = c.hidden_size / c.num_heads;
   if (dh % 8) { set_error("head_dim must be a multiple of 8"); return SVT_ERR_INVALID; }
@@ -360,7 +365,7 @@ int svt_encoder_finalize(svt_encoder* e) {
   const Param* p = nullptr;
   e->conv.clear();
   e->conv.resize(c.num_conv_layers);
-  int cin = 1;
+  int cin = c.num_conv_layers == 0 ? c.conv_dim[0] : 1;  // features-in mode: the projection reads the given features
   for (int i = 0; i < c.num_conv_layers; ++i) {
     const std::string pre = "feature_extractor.conv_layers." + std::to_string(i) + ".";
     const int co = c.conv_dim[i], k = c.conv_kernel[i];
@@ -527,6 +532,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
     if (i > 0 && n * 4 > max_f) max_f = n * 4;
   }
   const int64_t T = t;
+  if (c.num_conv_layers == 0) max_act = (size_t)B * T * c.conv_dim[0] * es;
   w.act[0] = cv.take(max_act);
   w.act[1] = cv.take(max_act);
   w.convF = c.feat_extract_norm == SVT_NORM_LAYER ? (float*)cv.take(max_f) : nullptr;
@@ -534,7 +540,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   const size_t rows = (size_t)B * T;
   const int Tp = attn_tp(c.precision, dh, (int)T);
   const bool flash = use_flash(c.precision, dh);
-  w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers - 1] * es);
+  w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers > 0 ? c.num_conv_layers - 1 : 0] * es);
   w.hF = (float*)cv.take(rows * D * 4);
   w.preF = (float*)cv.take(rows * D * 4);
   w.xb = cv.take(rows * D * es);
@@ -583,6 +589,13 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
 
   // ---- conv feature extractor (channels-last activations) ----
   int64_t tin = L;
+  int cur = 0;
+  if (c.num_conv_layers == 0) {
+    // features-in mode: `wav` is the (B, T, C) fp32 feature tensor
+    const int64_t n = (int64_t)B * L * c.conv_dim[0];
+    if (prec) { if (int r = launch_f32_to_bf16(wav, (bf16_t*)w.act[0], n, s)) return r; }
+    else SVT_HIP(hipMemcpyAsync(w.act[0], wav, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else {
   int64_t t1 = (L - c.conv_kernel[0]) / c.conv_stride[0] + 1;
   const ConvLayerW& c0 = e->conv[0];
   if (c.feat_extract_norm == SVT_NORM_GROUP) {
@@ -598,7 +611,7 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
                                    c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s)) return r;
   }
   tin = t1;
-  int cur = 0;
+  }
   for (int i = 1; i < c.num_conv_layers; ++i) {
     const int cin = c.conv_dim[i - 1], co = c.conv_dim[i], k = c.conv_kernel[i], st = c.conv_stride[i];
     const int64_t tout = (tin - k) / st + 1;
@@ -622,7 +635,7 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     cur ^= 1;
     tin = tout;
   }
-  const int C = c.conv_dim[c.num_conv_layers - 1];
+  const int C = c.conv_dim[c.num_conv_layers > 0 ? c.num_conv_layers - 1 : 0];
   const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
   const int64_t rows = (int64_t)B * T;
   const float eps = c.layer_norm_eps;

@@ -51,10 +51,11 @@ def _config_to_c(cfg: EncoderConfig, normalize_wav: bool, output_norm: bool, pre
     c.num_layers = cfg.num_hidden_layers
     c.num_heads = cfg.num_attention_heads
     c.intermediate_size = cfg.intermediate_size
-    n = len(cfg.conv_dim)
+    n = len(cfg.conv_kernel)
     if n > _lib.MAX_CONV:
         raise ValueError("too many conv layers")
-    c.num_conv_layers = n
+    c.num_conv_layers = n  # 0 = features-in mode (AV-HuBERT video branch): conv_dim[0] is the input feature width
+    c.conv_dim[0] = cfg.conv_dim[0]
     for i in range(n):
         c.conv_dim[i] = cfg.conv_dim[i]
         c.conv_kernel[i] = cfg.conv_kernel[i]

@@ -123,3 +123,159 @@ class SubModel(nn.Module):
 
 
 VideoFrontend = SubModel
+
+
+# =================================================================================================
+# AV-HuBERT video encoder = lip front-end + transformer (features-in mode of the encoder C-ABI)
+# =================================================================================================
+from .config import EncoderConfig, PRESETS  # noqa: E402
+from .huggingface_interface import _config_to_c  # noqa: E402
+from .weights import seeded_avhubert_video_state_dict, fairseq_to_hf_key  # noqa: E402
+
+_IGNORED_PREFIXES = ("mask_emb", "label_embs_concat", "final_proj.", "target_glu.", "feature_extractor_audio.")
+
+
+class FairseqAVHubertPretrain(nn.Module):
+    """Drop-in for ``N20EMv2/video_only/fairseq_interface.py:350-499`` on the video modality: ``forward({"video": x,
+    "audio": None})`` with ``x`` the ``(B, 1, T, H, W)`` lip ROI returns the ``(B, T, D)`` AV-HuBERT encoding
+    (``extract_finetune``, ``hubert.py:688-739``: front-end -> cat([zeros, video]) -> LayerNorm -> post_extract_proj ->
+    TransformerEncoder), then the wrapper's optional whole-tensor ``F.layer_norm`` (``output_norm``).
+
+    Parameters keep the fairseq names under ``model.`` (``model.feature_extractor_video.resnet...``, ``model.layer_norm.weight``,
+    ``model.post_extract_proj.weight``, ``model.encoder.pos_conv.0.weight_g``, ``model.encoder.layers.N.self_attn.q_proj.weight`` ...), so the
+    ``model`` entry of a fairseq AV-HuBERT checkpoint loads with ``load_fairseq_model_state``; pre-training-only entries
+    (``mask_emb``, ``final_proj``, ``label_embs_concat``, ``feature_extractor_audio``) are ignored.
+
+    The lip front-end is pinned to the reference; the transformer runs the same kernels as the (pinned) wav2vec2 /
+    HuBERT encoders but fairseq itself is absent from the build container, so that part is parity-unpinned."""
+
+    def __init__(self, pretrained_path=None, save_path=None, input_norm=None, output_norm=True, freeze=True, pretrain=True,
+                 dropout=None, *, config: "EncoderConfig | str" = "avhubert-large-video", precision=None, seed: int = 5986):
+        super().__init__()
+        if input_norm:
+            raise NotImplementedError("input_norm: the reference would layer-norm the modality dict itself; unused by the recipes")
+        cfg = PRESETS[config] if isinstance(config, str) else config
+        if cfg.conv_kernel:
+            raise ValueError("the AV-HuBERT video encoder needs a features-in configuration (empty conv_kernel)")
+        if cfg.conv_dim[0] != 2 * cfg.hidden_size:
+            raise ValueError("modality_fuse='concat': the transformer input width must be 2 * hidden_size")
+        self.config = cfg
+        self.output_norm = output_norm
+        self.freeze = freeze
+        self.normalize = False
+        self.precision = precision or os.environ.get("SVT_PRECISION", "bf16")
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+        self.model = ParamTree()
+        self.model.add_module("feature_extractor_video", SubModel(512, cfg.hidden_size, "prelu", precision=self.precision, seed=seed))
+        for k, v in seeded_avhubert_video_state_dict(cfg, seed=seed).items():
+            if not k.startswith("feature_extractor_video."):
+                self.model.add(k, v)
+        if pretrained_path is not None and pretrain:
+            self.load_fairseq_model_state(self._read_fairseq_checkpoint(pretrained_path))
+        if self.freeze:
+            self.eval()
+            for p in self.parameters():
+                p.requires_grad = False
+        self._handle = None
+        self._key = None
+        self._sig = None
+        self._ws = None
+
+    @staticmethod
+    def _read_fairseq_checkpoint(path):
+        try:
+            state = torch.load(path, map_location="cpu", weights_only=False)
+        except Exception as ex:  # a fairseq checkpoint pickles its cfg with omegaconf / fairseq classes
+            raise _lib.SvtError(f"cannot unpickle {path} without fairseq/omegaconf installed ({type(ex).__name__}: {ex}); "
+                                "re-save its state['model'] as a plain tensor dict and pass it to load_fairseq_model_state") from ex
+        return state["model"] if isinstance(state, dict) and "model" in state else state
+
+    def load_fairseq_model_state(self, model_state):
+        own = self.model.state_dict()
+        sd = {}
+        for k, v in model_state.items():
+            if k.startswith(_IGNORED_PREFIXES):
+                continue
+            sd[k] = v
+        missing = [k for k in own if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in own]
+        if missing or unexpected:
+            raise RuntimeError(f"AV-HuBERT state mismatch: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for k in own:
+            if k not in sd:
+                sd[k] = own[k]
+        self.model.load_state_dict(sd, strict=True)
+        self._sig = None
+
+    def _transformer_tensors(self):
+        for n, p in self.model.named_parameters():
+            if not n.startswith("feature_extractor_video."):
+                yield n, p
+
+    def _sync(self, device):
+        lib = _lib.load()
+        _lib.require_gpu()
+        idx = _lib.dev_index(device)
+        key = (idx, self.precision, bool(self.output_norm))
+        sig = tuple((p.data_ptr(), p._version) for _, p in self._transformer_tensors())
+        if self._handle is not None and key == self._key and sig == self._sig:
+            return
+        if self._handle is not None and key != self._key:
+            lib.svt_encoder_destroy(self._handle)
+            self._handle = None
+        if self._handle is None:
+            h = C.c_void_p()
+            cc = _config_to_c(self.config, False, bool(self.output_norm), self.precision)
+            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
+            self._handle, self._key = h, key
+        for name, p in self._transformer_tensors():
+            hf = fairseq_to_hf_key(name)
+            if hf is None:
+                raise _lib.SvtError(f"no encoder slot for parameter {name}")
+            t = p.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(lib.svt_encoder_load_param(self._handle, hf.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()),
+                       f"svt_encoder_load_param({hf})")
+        _lib.check(lib.svt_encoder_finalize(self._handle), "svt_encoder_finalize")
+        self._sig = sig
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._sig = None
+        return r
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().svt_encoder_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def forward(self, wav):
+        with torch.no_grad():
+            return self.extract_features(wav).detach()
+
+    def extract_features(self, wav):
+        if not isinstance(wav, dict) or "video" not in wav:
+            raise ValueError('expected {"video": (B,1,T,H,W) tensor, "audio": None}')
+        if wav.get("audio") is not None:
+            raise NotImplementedError("the recipes feed AV-HuBERT the video modality only (audio=None)")
+        video = wav["video"]
+        fv = self.model.feature_extractor_video(video)            # (B, E, T) view of a (B, T, E) buffer
+        B, E, T = fv.shape
+        feats = torch.zeros((B, T, 2 * E), dtype=torch.float32, device=fv.device)
+        feats[:, :, E:] = fv.transpose(1, 2)                       # audio half = zeros (hubert.py:700-702)
+        lib = _lib.load()
+        self._sync(feats.device)
+        need = lib.svt_encoder_workspace_bytes(self._handle, B, T)
+        if need < 0:
+            raise _lib.SvtError(_lib.last_error())
+        if self._ws is None or self._ws.numel() < need or self._ws.device != feats.device:
+            self._ws = None
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=feats.device)
+        out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=feats.device)
+        _lib.check(lib.svt_encoder_forward(self._handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(self._ws),
+                                           self._ws.numel(), _lib.stream_ptr(feats.device)), "svt_encoder_forward")
+        return out

@@ -34,6 +34,8 @@ def encoder_param_shapes(cfg: EncoderConfig, old_weight_norm_keys: bool = False)
             sh[f"{p}.layer_norm.weight"] = (c,)
             sh[f"{p}.layer_norm.bias"] = (c,)
         cin = c
+    if not cfg.conv_kernel:  # features-in configuration (AV-HuBERT video branch): the projection reads conv_dim[0] features
+        cin = cfg.conv_dim[0]
     D, F = cfg.hidden_size, cfg.intermediate_size
     if cfg.feat_proj_layer_norm:
         sh["feature_projection.layer_norm.weight"] = (cin,)
@@ -226,4 +228,58 @@ def seeded_video_frontend_state_dict(embed_dim: int = 1024, seed: int = 4986, pr
                 fan_in *= d
             v = torch.randn(shape, generator=g) * math.sqrt((0.25 if k == "proj.weight" else 2.0) / fan_in)
         sd[prefix + k] = v
+    return sd
+
+
+# ---- AV-HuBERT video encoder: fairseq parameter names (hubert.py:344-394; fairseq TransformerEncoder) ----
+HF_TO_FAIRSEQ = [
+    ("feature_projection.layer_norm.", "layer_norm."),
+    ("feature_projection.projection.", "post_extract_proj."),
+    ("encoder.pos_conv_embed.conv.", "encoder.pos_conv.0."),
+    ("encoder.layer_norm.", "encoder.layer_norm."),
+]
+HF_LAYER_TO_FAIRSEQ = [
+    ("attention.k_proj.", "self_attn.k_proj."), ("attention.v_proj.", "self_attn.v_proj."),
+    ("attention.q_proj.", "self_attn.q_proj."), ("attention.out_proj.", "self_attn.out_proj."),
+    ("layer_norm.", "self_attn_layer_norm."), ("feed_forward.intermediate_dense.", "fc1."),
+    ("feed_forward.output_dense.", "fc2."), ("final_layer_norm.", "final_layer_norm."),
+]
+
+
+def hf_to_fairseq_key(k: str) -> str:
+    if k.startswith("encoder.layers."):
+        _, _, idx, rest = k.split(".", 3)
+        for a, b in HF_LAYER_TO_FAIRSEQ:
+            if rest.startswith(a):
+                return f"encoder.layers.{idx}.{b}{rest[len(a):]}"
+        raise KeyError(k)
+    for a, b in HF_TO_FAIRSEQ:
+        if k.startswith(a):
+            return b + k[len(a):]
+    raise KeyError(k)
+
+
+def fairseq_to_hf_key(k: str):
+    if k.startswith("encoder.layers."):
+        _, _, idx, rest = k.split(".", 3)
+        for b, a in HF_LAYER_TO_FAIRSEQ:
+            if rest.startswith(a):
+                return f"encoder.layers.{idx}.{b}{rest[len(a):]}"
+        return None
+    for b, a in HF_TO_FAIRSEQ:
+        if k.startswith(a):
+            return b + k[len(a):]
+    return None
+
+
+def seeded_avhubert_video_state_dict(cfg: EncoderConfig, seed: int = 5986, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+    """``AVHubertModel.state_dict()`` entries the video-only forward reads: ``feature_extractor_video.*`` (lip front-end),
+    ``layer_norm.*`` (over cat([audio, video]) = 2E), ``post_extract_proj.*``, ``encoder.*`` (fairseq names, weight_g/weight_v
+    spelling of the positional conv's weight norm)."""
+    E = cfg.hidden_size
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in seeded_video_frontend_state_dict(E, seed=seed).items():
+        sd[prefix + "feature_extractor_video." + k] = v
+    for k, v in seeded_encoder_state_dict(cfg, seed=seed + 1, old_weight_norm_keys=True).items():
+        sd[prefix + hf_to_fairseq_key(k)] = v
     return sd

@@ -54,3 +54,32 @@ def test_video_frontend_errors():
         m(torch.zeros(1, 1, 2, 32, 32))
     with pytest.raises(RuntimeError):  # strict load, like torch
         m.load_state_dict({"proj.weight": torch.zeros(64, 512)})
+
+
+# ---- AV-HuBERT video encoder end to end (front-end pinned above; transformer checked against the oracle restatement,
+# which is parity-unpinned for fairseq: see oracle/svt_oracle.py::avhubert_video_forward) ----
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.35)])
+def test_avhubert_video_encoder_vs_oracle(prec, tol):
+    from oracle import svt_oracle as O
+    from svt_speechbrain_amd.video import FairseqAVHubertPretrain
+    cfg = S.PRESETS["tiny-avhubert-video"]
+    m = FairseqAVHubertPretrain(config=cfg, precision=prec, seed=77, output_norm=True)
+    sd = W.seeded_avhubert_video_state_dict(cfg, seed=123)
+    sd["mask_emb"] = torch.zeros(4)                         # pre-training leftovers in a real checkpoint: ignored
+    sd["final_proj.weight"] = torch.zeros(3, 3)
+    sd["feature_extractor_audio.proj.weight"] = torch.zeros(cfg.hidden_size, 104)
+    m.load_fairseq_model_state(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    video = torch.randn(2, 1, 9, 40, 40, generator=g)
+    out = m({"video": video.to(DEV), "audio": None}).cpu()
+    with torch.no_grad():
+        ref = O.avhubert_video_forward(sd, cfg, video, output_norm=True)
+    assert out.shape == ref.shape == (2, 9, cfg.hidden_size)
+    err = (out - ref).abs().max().item()
+    print(f"AV-HuBERT video encoder {prec}: max |d| {err:.5f} (ref std {ref.std().item():.3f})")
+    assert err < tol
+    with pytest.raises(NotImplementedError):
+        m({"video": video.to(DEV), "audio": torch.zeros(1)})
+    with pytest.raises(RuntimeError):
+        m.load_fairseq_model_state({"layer_norm.weight": torch.zeros(128)})

@@ -169,3 +169,34 @@ def test_reference_checkpoint_files_load_unchanged_and_reproduce_the_reference_o
     assert abs(float(logits.double().sum()) - d["logits_sum"]) < 1e-3
     assert abs(float(logits.double().abs().sum()) - d["logits_abs"]) < 1e-3
     assert max(abs(float(a) - b) for a, b in zip(logits[0, 0, :4], d["first"])) < 2e-5
+
+
+# ---- §8 a15: AV-HuBERT video encoder host side ----
+def test_avhubert_video_state_dict_uses_fairseq_names_and_maps_onto_the_encoder():
+    from svt_speechbrain_amd.video import FairseqAVHubertPretrain, SubModel
+    from oracle import svt_oracle as O
+    cfg = PRESETS["tiny-avhubert-video"]
+    m = FairseqAVHubertPretrain(config=cfg, precision="fp32")
+    keys = set(m.state_dict().keys())
+    for k in ("model.feature_extractor_video.resnet.frontend3D.0.weight", "model.feature_extractor_video.resnet.trunk.layer4.1.bn2.running_var",
+              "model.feature_extractor_video.proj.bias", "model.layer_norm.weight", "model.post_extract_proj.weight",
+              "model.encoder.pos_conv.0.weight_g", "model.encoder.pos_conv.0.weight_v", "model.encoder.layers.1.self_attn.q_proj.weight",
+              "model.encoder.layers.0.self_attn_layer_norm.bias", "model.encoder.layers.1.fc1.weight", "model.encoder.layers.1.fc2.bias",
+              "model.encoder.layers.0.final_layer_norm.weight", "model.encoder.layer_norm.weight"):
+        assert k in keys, k
+    assert m.state_dict()["model.layer_norm.weight"].shape == (2 * cfg.hidden_size,)
+    # every transformer key has an encoder slot, and the two key maps (package / oracle) agree and invert each other
+    hf_keys = set(W.encoder_param_shapes(cfg, old_weight_norm_keys=True))
+    seen = set()
+    for k in keys:
+        k = k[len("model."):]
+        if k.startswith("feature_extractor_video."):
+            continue
+        hf = W.fairseq_to_hf_key(k)
+        assert hf is not None and hf == O.fairseq_to_hf_key(k) and W.hf_to_fairseq_key(hf) == k
+        seen.add(hf)
+    assert seen == hf_keys
+    # the front-end's keys are SubModel.state_dict()'s (139 entries in the reference, num_batches_tracked included)
+    assert len(SubModel(512, 64, "prelu", precision="fp32").state_dict()) == 139
+    with pytest.raises(_lib.SvtError):  # no GPU input -> loud failure, no CPU fallback
+        m({"video": torch.zeros(1, 1, 2, 32, 32), "audio": None})
