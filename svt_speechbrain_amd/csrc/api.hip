@@ -1008,6 +1008,9 @@ struct svt_video {
   ParamMap params;
   DevBuf stem_w, stem_bias, stem_slope;
   VConv conv1[4][2], conv2[4][2], down[4];
+  // stage 1 (64 channels) with G = 2 / 4 output pixels per GEMM row (bf16 mode): index [g][block], g = 0: G = 2, 1: G = 4
+  VConv grp1[2][2], grp2[2][2];
+  DevBuf gslope1[2][2], gslope2[2][2];
   DevBuf slope2[4][2];
   DevBuf proj_w, proj_b;
 };
@@ -1076,6 +1079,36 @@ int fold_conv(int prec, const ParamMap& P, const std::string& wkey, const std::s
           t[(size_t)co * k * k * Cin + (size_t)(ky * k + kx) * Cin + ci] = w->v[(((size_t)co * Cin + ci) * k + ky) * k + kx] * sc[co];
   if (int r = upload_operand(prec, out->w, t.data(), t.size())) return r;
   return upload_f32(out->bias, bi.data(), bi.size());
+}
+// 3x3 stride-1 conv with 64 output channels re-posed for G (2 or 4) horizontally adjacent output pixels at once: the
+// A row is the 3 x (G+2) pixel window they share (K = 3 (G+2) Cin), the weight matrix has G * Cout rows, row j*Cout + co
+// holding the 3x3 kernel of pixel j shifted to taps kx' = j..j+2 (zeros elsewhere).  (G+2)/3 of the MACs, but the product
+// is G*64 wide and runs on the LDS-DMA kernel, which is LDS / fill bound on narrow tiles: multiplying the structural
+// zeros on a 256-wide tile is cheaper than a 64-wide tile without them (measured).
+int fold_conv_group(const ParamMap& P, const std::string& wkey, const std::string& bnkey, int Cout, int Cin, int G, VConv* out) {
+  const Param* w = nullptr;
+  if (int r = need(P, wkey, {Cout, Cin, 3, 3}, &w)) return r;
+  std::vector<float> sc, bi;
+  if (int r = bn_fold(P, bnkey, Cout, &sc, &bi)) return r;
+  const size_t K = (size_t)3 * (G + 2) * Cin;
+  std::vector<float> t((size_t)G * Cout * K, 0.f), b2((size_t)G * Cout);
+  for (int j = 0; j < G; ++j)
+    for (int co = 0; co < Cout; ++co) {
+      b2[(size_t)j * Cout + co] = bi[co];
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx)
+            t[((size_t)j * Cout + co) * K + (size_t)(ky * (G + 2) + kx + j) * Cin + ci] = w->v[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] * sc[co];
+    }
+  if (int r = upload_operand(1, out->w, t.data(), t.size())) return r;
+  return upload_f32(out->bias, b2.data(), b2.size());
+}
+int upload_vec_rep(const ParamMap& P, const std::string& key, int C, int G, DevBuf* out) {
+  const Param* p = nullptr;
+  if (int r = need(P, key, {C}, &p)) return r;
+  std::vector<float> t;
+  for (int j = 0; j < G; ++j) t.insert(t.end(), p->v.begin(), p->v.end());
+  return upload_f32(*out, t.data(), t.size());
 }
 int upload_vec(const ParamMap& P, const std::string& key, int C, DevBuf* out) {
   const Param* p = nullptr;
@@ -1149,6 +1182,15 @@ int svt_video_finalize(svt_video* v) {
       if (int r = upload_vec(P, pre + ".relu2.weight", C, &v->slope2[li][b])) return r;
       if (b == 0 && li > 0)
         if (int r = fold_conv(v->prec, P, pre + ".downsample.0.weight", pre + ".downsample.1", C, cin, 1, &v->down[li])) return r;
+      if (li == 0 && v->prec) {
+        for (int gi = 0; gi < 2; ++gi) {
+          const int G = gi ? 4 : 2;
+          if (int r = fold_conv_group(P, pre + ".conv1.weight", pre + ".bn1", 64, 64, G, &v->grp1[gi][b])) return r;
+          if (int r = upload_vec_rep(P, pre + ".relu1.weight", 64, G, &v->gslope1[gi][b])) return r;
+          if (int r = fold_conv_group(P, pre + ".conv2.weight", pre + ".bn2", 64, 64, G, &v->grp2[gi][b])) return r;
+          if (int r = upload_vec_rep(P, pre + ".relu2.weight", 64, G, &v->gslope2[gi][b])) return r;
+        }
+      }
     }
     cin = C;
   }
@@ -1208,6 +1250,36 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
     a.resid = (const float*)resid; a.resid_first = 1; a.resid_op_type = 1;
     return launch_gemm(prec, a, s);
   };
+  // stage 1 in bf16 mode: G output pixels per GEMM row (see fold_conv_group).  G = 4 may compute up to two pixels past the
+  // end of a row (they land on the right halo and on the next row's left halo, re-zeroed afterwards); G = 2 needs an even
+  // width; otherwise the plain 64-wide product is used.
+  int grp = 0;
+  if (prec) {
+    const int Wd = g.Ws[0];
+    if (Wd % 2 == 0) grp = 2;                        // measured on 22 x 22 x 64: G = 2 794 us, G = 4 871 us, plain 901 us per conv
+    else if ((Wd + 3) / 4 * 4 - Wd <= 2) grp = 4;
+    if (grp && F * g.Hs[0] * ((Wd + grp - 1) / grp) < 128) grp = 0;
+  }
+  auto conv_group = [&](const void* in, int Hh, int Ww, void* out, const VConv& cw, const float* slope_rep, const void* resid) -> int {
+    GemmArgs a;
+    const long Wp = Ww + 2, Hp = Hh + 2, Wq = (Ww + grp - 1) / grp;
+    a.gen = 1;
+    a.A = in; a.W = cw.w.p; a.C = out; a.bias = cw.bias.as<float>();
+    a.M = (int)(F * Hh * Wq); a.N = grp * 64; a.K = 3 * (grp + 2) * 64;
+    a.a_rstride = (long)grp * 64;
+    a.a_d1 = (int)Wq; a.a_e1 = (Wp - Wq * grp) * 64;
+    a.a_d2 = (int)(Wq * Hh); a.a_e2 = (Hp * Wp - (long)Hh * Wp) * 64;
+    a.kseg = (grp + 2) * 64; a.kseg_stride = Wp * 64;
+    a.ldw = a.K; a.ldc = (long)grp * 64;
+    a.c_d1 = (int)Wq; a.c_e1 = (Wp - Wq * grp) * 64;
+    a.c_d2 = (int)(Wq * Hh); a.c_e2 = (Hp * Wp - (long)Hh * Wp) * 64;
+    a.c_base = (Wp + 1) * 64;
+    a.act = ACT_PRELU; a.slope = slope_rep;
+    a.resid = (const float*)resid; a.resid_first = 1; a.resid_op_type = 1;
+    if (int r = launch_gemm(prec, a, s)) return r;
+    if (Wq * grp != Ww) return launch_zero_halo(prec, out, F, (int)Hp, (int)Wp, 64, s);
+    return 0;
+  };
   const void* x = ws.buf[0][0];
   int Hin = g.Hs[0], Win = g.Ws[0], cin = 64;
   for (int li = 0; li < 4; ++li) {
@@ -1220,6 +1292,13 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
       void* t1 = fr[0];
       void* outb = fr[1];
       const void* res = x;
+      if (li == 0 && grp) {
+        const int gi = grp == 4 ? 1 : 0;
+        if (int r = conv_group(x, Ho, Wo, t1, v->grp1[gi][b], v->gslope1[gi][b].as<float>(), nullptr)) return r;
+        if (int r = conv_group(t1, Ho, Wo, outb, v->grp2[gi][b], v->gslope2[gi][b].as<float>(), x)) return r;
+        x = outb;
+        continue;
+      }
       if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
       if (stride == 2) {  // first block of stages 2-4: the residual is the 1x1 stride-2 conv + BN of the block input
         if (int r = conv(x, Hin, Win, cin, fr[1], Ho, Wo, C, 2, 1, v->down[li], nullptr, nullptr)) return r;

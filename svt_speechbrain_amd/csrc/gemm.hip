@@ -367,8 +367,8 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
     g.c_vec = g.c_vec && mult(a.c_e1, cel) && mult(a.c_e2, cel) && mult(a.c_base, cel) &&
               (!a.resid || !a.resid_op_type || !((uintptr_t)a.resid & 15));
     // N >= 128 with bf16 output: the LDS-DMA pipeline (needs 64-element K slabs inside every run and nz == 1)
-    if (prec && gemm_dma_eligible(g) && !a.out_f32 && a.nz == 1 && (!a.resid || a.resid_op_type) && a.alpha == 1.f &&
-        (a.kseg == 0 || a.kseg % 64 == 0))
+    if (prec && a.K % 64 == 0 && a.N >= 128 && a.N % 8 == 0 && a.M >= 128 && g.c_vec && !a.out_f32 && a.nz == 1 &&
+        (!a.resid || a.resid_op_type) && a.alpha == 1.f && (a.kseg == 0 || a.kseg % 64 == 0))
       return launch_gemm_dma(g, s);
     if (prec) return narrow ? launch_one<bf16_t, 256, 64, true>(g, s) : launch_one<bf16_t, 128, 128, true>(g, s);
     return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);

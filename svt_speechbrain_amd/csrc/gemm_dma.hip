@@ -129,25 +129,27 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
 
 // generalised variant (GemmArgs::gen): rows land at c_base + m*ldc + (m/c_d1)*c_e1 + (m/c_d2)*c_e2 (interior of a
 // zero-haloed channels-last tensor), optional residual in the operand type added BEFORE the activation, per-column
-// PReLU slope.  bf16 output only.
-template <int MB, int BM>
-__device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, const f32x4& a0, const f32x4& a1, const f32x4& a2,
-                                                   const f32x4& a3, int mb, float* patch, int lane, int wm, int wn, int m0,
-                                                   int n0, const float* bias) {
-  constexpr int PITCH = 68;
+// PReLU slope.  bf16 output only.  NBW = 16-column MFMA blocks per wave (tile width 64 * NBW).
+template <int MB, int BM, int NBW, int I>
+__device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, f32x4 (&acc)[NBW][MB], float* patch, int lane, int wm,
+                                                   int wn, int m0, int n0, const float* bias) {
+  constexpr int WC = 16 * NBW;       // columns per wave
+  constexpr int PITCH = WC + 4;      // floats
+  constexpr int LPR = 2 * NBW;       // lanes per row on the read-back side (8 columns each)
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  constexpr int PASSES = RPP >= 16 ? 1 : 16 / RPP;
   const int m16 = lane & 15, q = lane >> 4;
-  const f32x4 accs[4] = {a0, a1, a2, a3};
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    f32x4 v = accs[nb];
+  for (int nb = 0; nb < NBW; ++nb) {
+    f32x4 v = acc[nb][I];
     v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
-    *(f32x4*)(patch + m16 * PITCH + q * 16 + nb * 4) = v;
+    *(f32x4*)(patch + m16 * PITCH + q * (4 * NBW) + nb * 4) = v;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const int mbase = m0 + wm * (BM / 2) + mb * 16;
-  const int c8 = (lane & 7) * 8;
-  const int n = n0 + wn * 64 + c8;
+  const int mbase = m0 + wm * (BM / 2) + I * 16;
+  const int c8 = (lane % LPR) * 8;
+  const int n = n0 + wn * WC + c8;
   float bb[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bb[j] = 0.f; ss[j] = 0.f; }
@@ -162,11 +164,11 @@ __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, const f32x
     }
   }
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int r = pass * 8 + (lane >> 3);
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int r = pass * RPP + lane / LPR;
     const int m = mbase + r;
-    const float4 v0 = *(const float4*)(patch + r * PITCH + c8), v1 = *(const float4*)(patch + r * PITCH + c8 + 4);
-    if (m < p.M && n < p.N) {
+    if (r < 16 && m < p.M && n < p.N) {
+      const float4 v0 = *(const float4*)(patch + r * PITCH + c8), v1 = *(const float4*)(patch + r * PITCH + c8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       const long idx = p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + n;
       float rr[8];
@@ -194,10 +196,10 @@ __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, const f32x
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int MB, int BM, int... I>
-__device__ __forceinline__ void epilogue_seq_gen(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[4][MB],
+template <int MB, int BM, int NBW, int... I>
+__device__ __forceinline__ void epilogue_seq_gen(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[NBW][MB],
                                                  float* patch, int lane, int wm, int wn, int m0, int n0, const float* bias) {
-  (epilogue_block_gen<MB, BM>(p, acc[0][I], acc[1][I], acc[2][I], acc[3][I], I, patch, lane, wm, wn, m0, n0, bias), ...);
+  (epilogue_block_gen<MB, BM, NBW, I>(p, acc, patch, lane, wm, wn, m0, n0, bias), ...);
 }
 
 template <int MB, int BM, bool OUT32, int... I>
@@ -223,9 +225,10 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmArgs& p, f32x4 (&ac
 // One tile per workgroup.  The LDS is a ring of 5 slots of 32 KiB; units alternate A-slab / W-slab of the same
 // 64-deep K step (A_0 W_0 A_1 W_1 ...), each filled by full-line LDS-DMA (8 rows x 128 B per wave-instruction).
 // While slab j is multiplied, units A_{j+1}, W_{j+1}, A_{j+2} are in flight, retired by a counted vmcnt.
-template <int BM, bool GEN = false>
+template <int BM, bool GEN = false, int NBW = 4>
 __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
-  constexpr int BN = 256, BK = 64, NSLOT = 5;
+  static_assert(GEN || NBW == 4, "narrow tiles are served by the generalised variant only");
+  constexpr int BN = 64 * NBW, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 32;
   constexpr int GA = BM / 64;       // DMA instructions per wave per A unit (BM/8 groups over 8 waves)
   constexpr int GW = BN / 64;       // per W unit
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   for (int i = 0; i < GW; ++i) {
     const int rho = (wave + 8 * i) * 8 + r8;
     const int i16 = rho & 15;
-    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+    int n = n0 + (rho / (16 * NBW)) * (16 * NBW) + (i16 >> 2) * (4 * NBW) + ((rho >> 4) % NBW) * 4 + (i16 & 3);
     if (n > p.N - 1) n = p.N - 1;
     wsrc[i] = W + (long)n * p.ldw + ch * 8;
   }
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(lds + slot * SLOT + (wave + 8 * i) * 64), 16, 0, 0);
   };
 
-  f32x4 acc[4][MB];
+  f32x4 acc[NBW][MB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NBW; ++i)
 #pragma unroll
     for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + ((cq) ^ rr8);        // ks = 0: chunk = cq
   const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);    // ks = 1: chunk = 4 + cq
   const int xoff = (wm * (MB * 2)) * 64;
-  const int woff = (wn * 8) * 64;
+  const int woff = (wn * 2 * NBW) * 64;
 
   // Staggered quarter-phase schedule ("8-phase"): the slab is multiplied in four groups of 4 x MB/2 MFMAs, each preceded
   // by a LOAD slot (its LDS fragment reads + two DMA instructions of the ring).  Slots are separated by raw barriers and
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   // LOAD slot: the matrix pipe never waits for LDS latency or DMA issue of its own wave.
   const int nk = p.K / BK;
   constexpr int HM = MB / 2;
-  bf16x8 wfr[4], xfr[HM];
+  bf16x8 wfr[NBW], xfr[HM];
   const int grp = wave >> 2;
   const bool tr = p.trace != nullptr;
   long long t_begin = 0, t_first = 0, t_main = 0;
@@ -334,13 +337,13 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   {                                                                                                              \
     constexpr int ks_ = (Q) >> 1, half_ = (Q)&1;                                                                 \
     if (half_ == 0) {                                                                                            \
-      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) wfr[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks_ ? frag1 : frag0)]); \
+      _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb) wfr[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks_ ? frag1 : frag0)]); \
     }                                                                                                            \
     _Pragma("unroll") for (int jj = 0; jj < HM; ++jj)                                                            \
         xfr[jj] = __builtin_bit_cast(bf16x8, xa[(half_ * HM + jj) * 128 + (ks_ ? frag1 : frag0)]);               \
     if (ks_ == 0) {                                                                                              \
       if (kt + 1 < nk) {                                                                                         \
-        _Pragma("unroll") for (int i2 = half_ * 2; i2 < half_ * 2 + 2; ++i2)                                     \
+        _Pragma("unroll") for (int i2 = half_ * ((GW + 1) / 2); i2 < (half_ ? GW : (GW + 1) / 2); ++i2)          \
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i2] + (kt + 1) * BK),                                 \
                                              (lptr_t)(lds + ((2 * kt + 3) % NSLOT) * SLOT + (wave + 8 * i2) * 64), 16, 0, 0); \
       }                                                                                                          \
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
     constexpr int half_ = (Q)&1;                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int jj = 0; jj < HM; ++jj)                                                            \
-      _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                           \
+      _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                         \
         acc[nb][half_ * HM + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nb], xfr[jj], acc[nb][half_ * HM + jj], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -409,10 +412,15 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   if (tr) t_main = wall_clock64();
   __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
   if constexpr (GEN)
-    epilogue_seq_gen<MB, BM>(std::make_integer_sequence<int, MB>{}, p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, bias);
-  else if (p.dbg != 3)
-    epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
-  else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
+    epilogue_seq_gen<MB, BM, NBW>(std::make_integer_sequence<int, MB>{}, p, acc, (float*)lds + wave * (16 * (16 * NBW + 4)), lane, wm, wn,
+                                  m0, n0, bias);
+  else {
+    if constexpr (NBW == 4) {
+      if (p.dbg != 3)
+        epilogue_coalesced<MB, BM>(p, acc, (float*)lds + wave * (16 * 68), lane, wm, wn, m0, n0, coff, bias);
+      else if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f;
+    }
+  }
   if (tr && lane == 0 && (wave & 3) == 0) {
     long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
     o[0] = t_begin; o[1] = t_first; o[2] = t_main - t_first; o[3] = wall_clock64() - t_main; o[4] = wall_clock64(); o[5] = 1;
@@ -702,21 +710,21 @@ int launch_pers(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int BM, bool GEN = false>
+template <int BM, bool GEN = false, int NBW = 4>
 int launch_pp8(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 64 * NBW - 1) / (64 * NBW);
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
   const size_t lds_bytes = 5 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM, GEN, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     attr_set = true;
   }
   const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pp8_kernel<BM, GEN>), grid, dim3(512), lds_bytes, s, a);
+  hipLaunchKernelGGL((gemm_pp8_kernel<BM, GEN, NBW>), grid, dim3(512), lds_bytes, s, a);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -751,6 +759,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   }
   if (g_gemm_force_bm) best = g_gemm_force_bm;
   if (a.gen) {  // generalised addressing: one-tile kernel only (it also carries the residual epilogue)
+    // 128-channel outputs (second stage of the lip front-end) get a 128-column tile: a 256-wide tile would multiply
+    // zeros for half of its MFMAs
+    // (a 64-column tile, NBW = 1, is LDS-read bound -- 18 fragment reads per 16 MFMAs -- and measured slower than the
+    // register-staged kernel: 64-channel layers stay there)
+    if (a.N <= 128) return launch_pp8<256, true, 2>(a, s);
     if (best == 256) return launch_pp8<256, true>(a, s);
     if (best == 192) return launch_pp8<192, true>(a, s);
     return launch_pp8<128, true>(a, s);

@@ -12,7 +12,7 @@ from svt_speechbrain_amd import weights as W  # noqa: E402
 from svt_speechbrain_amd.video import SubModel  # noqa: E402
 
 DEV = "cuda:0"
-CASES = ["roi88", "roi88_t1", "roi32", "roi50"]
+CASES = ["roi88", "roi88_t1", "roi32", "roi50", "roi60"]  # stage-1 widths 22 (two-pixel rows), 8, 13 (plain), 15 (four-pixel rows)
 
 
 def _run(fx, precision):

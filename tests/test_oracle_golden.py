@@ -139,7 +139,7 @@ def test_oracle_losses_match_reference_golden(golden):
 
 
 # ---- §8 a15: AV-HuBERT lip front-end ----
-@pytest.mark.parametrize("name", ["roi88", "roi88_t1", "roi32", "roi50"])
+@pytest.mark.parametrize("name", ["roi88", "roi88_t1", "roi32", "roi50", "roi60"])
 def test_oracle_video_frontend_matches_reference_golden(golden, name):
     fx = golden("video_front")[name]
     sd = W.seeded_video_frontend_state_dict(fx["E"], seed=fx["weight_seed"])
