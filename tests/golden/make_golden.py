@@ -363,7 +363,7 @@ def make_video_front_cases():
     spec.loader.exec_module(mod)
     out = {}
     for name, B, T, HW, E, seed in [("roi88", 2, 5, 88, 1024, 4986), ("roi88_t1", 1, 1, 88, 1024, 4987), ("roi32", 1, 7, 32, 256, 4988),
-                                   ("roi50", 2, 3, 50, 128, 4989), ("roi60", 1, 2, 60, 64, 4990)]:
+                                   ("roi50", 2, 3, 50, 128, 4989), ("roi60", 1, 3, 60, 64, 4990)]:
         sd = W.seeded_video_frontend_state_dict(E, seed=seed)
         m = mod.SubModel(512, E, "prelu").eval()
         m.load_state_dict(sd, strict=True)
