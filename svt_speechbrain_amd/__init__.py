@@ -12,6 +12,7 @@ from . import checkpoints  # noqa: F401
 from .checkpoints import Checkpointer  # noqa: F401
 from .losses import bce_loss, nll_loss, Softmax  # noqa: F401
 from . import video  # noqa: F401
+from . import dataio, scoring  # noqa: F401
 from .video import FairseqAVHubertPretrain  # noqa: F401
 from .song import SongTranscriber, utterance_bounds, save_song_features, feature_path  # noqa: F401
 

@@ -376,6 +376,28 @@ def make_video_front_cases():
     torch.save(out, os.path.join(HERE, "video_front.pt"))
 
 
+def make_dataio_cases():
+    """speechbrain.utils.data_utils.batch_pad_right and speechbrain.dataio.batch.PaddedBatch on ragged 1-D signals and
+    (frames, 4) annotations, as the recipes' DataLoader collates them (speechbrain/dataio/batch.py:101-137)."""
+    from speechbrain.utils.data_utils import batch_pad_right
+    from speechbrain.dataio.batch import PaddedBatch
+    g = torch.Generator().manual_seed(31)
+    out = {"pad": [], "batch": None}
+    for lens in [(80000, 61234, 99999), (5,), (7, 7), (1, 9, 4, 9)]:
+        ts = [torch.randn(n, generator=g) for n in lens]
+        data, valid = batch_pad_right(ts)
+        out["pad"].append(dict(tensors=ts if max(lens) < 100 else None, lens=lens, seed_note="randn from Generator(31) in order",
+                               valid=valid, shape=tuple(data.shape), checksum=float(data.double().sum()),
+                               tail_zero=bool((data[1, lens[1]:] == 0).all()) if len(lens) > 1 else True))
+    ex = [{"id": f"song_{i}", "sig": torch.randn(n, generator=g), "anno": torch.randint(0, 5, (n // 3, 4), generator=g).float(),
+           "cur_utter": i + 1} for i, n in enumerate((30, 18, 24))]
+    pb = PaddedBatch(ex)
+    out["batch"] = dict(examples=ex, sig=pb.sig.data, sig_lens=pb.sig.lengths, anno=pb.anno.data, anno_lens=pb.anno.lengths,
+                        ids=pb.id, cur=pb.cur_utter)
+    torch.save(out, os.path.join(HERE, "dataio.pt"))
+    print("dataio", [c["valid"].tolist() for c in out["pad"]])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -399,6 +421,7 @@ def main():
         "ctc_fbank": make_ctc_fbank_cases,
         "losses": make_loss_cases,
         "video_front": make_video_front_cases,
+        "dataio": make_dataio_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),
     }
     for k, fn in jobs.items():

@@ -275,3 +275,57 @@ def test_song_transcriber_matches_oracle_per_utterance(tmp_path):
     assert feats.shape == ref_feats.shape and (feats.cpu() - ref_feats).abs().max() < 1e-3
     path = S.save_song_features(feats, str(tmp_path / "song"))
     assert path.endswith("noise_data/clean_feats.pt") and torch.load(path).shape == ref_feats.shape
+
+
+def test_evaluation_loop_manifest_to_scores():
+    """The recipes' test stage end to end with this package only (MIR_ST500/train_audio_ssl.py:28-137): utterance plan
+    and slicing -> PaddedBatch (batch 1) -> encoder + head -> the four validation losses -> frames -> notes at the last
+    utterance -> COnPOff / COnP / COn scores.  Reference = the same loop on the oracle; fp32 mode must reproduce its notes,
+    hence score 1.0 against them, and its loss terms."""
+    from svt_speechbrain_amd import dataio as D, scoring as SC
+    cfg = PRESETS["tiny-group"]
+    sd = W.seeded_encoder_state_dict(cfg, seed=41)
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=42)
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32", seed=41).to(DEV)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict(hd)
+    amt = S.AMTForward({"wav2vec2": enc, "model": head.to(DEV)})
+    lsm = S.Softmax(apply_log=True)
+    duration = 12.3
+    song = synth_wav(1, int(duration * 16000), 7)[0]
+    g = torch.Generator().manual_seed(8)
+    n_frames = round(duration * 49.8)
+    song_anno = torch.stack([(torch.rand(n_frames, generator=g) < 0.05).float(), (torch.rand(n_frames, generator=g) < 0.05).float(),
+                             torch.randint(0, 5, (n_frames,), generator=g).float(), torch.randint(0, 13, (n_frames,), generator=g).float()], 1)
+    plan = D.plan_utterances(duration)
+    ref_info, got_losses, ref_losses, notes = [], [], [], None
+    for uid in range(1, len(plan) + 1):
+        ex = {"id": f"s_{uid}", "sig": D.slice_audio(song, uid, len(plan)), "anno": D.slice_annotation(song_anno, uid, len(plan)),
+              "cur_utter": uid, "all_utter": len(plan)}
+        batch = D.PaddedBatch([ex]).to(DEV)
+        wavs, wav_lens = batch.sig
+        on, off, octl, pcl, lens = amt.compute_forward(wavs, wav_lens)
+        anno, _ = batch.anno
+        got_losses.append(float(S.bce_loss(on, anno[:, :, 0], length=lens, pos_weight=torch.tensor([15.0], device=DEV))
+                                + S.bce_loss(off, anno[:, :, 1], length=lens)
+                                + S.nll_loss(lsm(octl), anno[:, :, 2].long(), length=lens)
+                                + S.nll_loss(lsm(pcl), anno[:, :, 3].long(), length=lens)))
+        notes = amt.decode_utterance(amt.last_logits, last_of_song=batch.cur_utter.item() == batch.all_utter.item())
+        with torch.no_grad():
+            rl = O.head_forward(O.encoder_forward(sd, cfg, ex["sig"][None]), hd["w.weight"], hd["w.bias"])
+        a = ex["anno"][None]
+        one = torch.ones(1)
+        ref_losses.append(float(O.bce_loss(rl[:, :, 0], a[:, :, 0], length=one, pos_weight=15.0) + O.bce_loss(rl[:, :, 1], a[:, :, 1], length=one)
+                                + O.nll_loss(O.softmax(rl[:, :, 2:7], True), a[:, :, 2].long(), length=one)
+                                + O.nll_loss(O.softmax(rl[:, :, 7:], True), a[:, :, 3].long(), length=one)))
+        p_on, p_off, octv, pc = O.decode_frames(rl)
+        ref_info += list(zip(p_on[0].numpy(), p_off[0].numpy(), octv[0].tolist(), pc[0].tolist()))
+    ref_notes = O.frame2note(ref_info, 0.4, 0.5)
+    assert notes == ref_notes and len(notes) > 0
+    for a_, b_ in zip(got_losses, ref_losses):
+        assert abs(a_ - b_) < 1e-4 * (1 + abs(b_))
+    scores = SC.score_song(notes, ref_notes)
+    assert scores["F-measure"] == 1.0 and scores["F-measure_no_offset"] == 1.0 and scores["Onset_F-measure"] == 1.0
+    # and a perturbed transcription scores below 1
+    worse = [[n[0] + 0.2, n[1] + 0.2, n[2]] for n in notes[: len(notes) // 2]] + notes[len(notes) // 2:]
+    assert SC.score_song(worse, ref_notes)["Onset_F-measure"] < 1.0

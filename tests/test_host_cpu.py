@@ -200,3 +200,93 @@ def test_avhubert_video_state_dict_uses_fairseq_names_and_maps_onto_the_encoder(
     assert len(SubModel(512, 64, "prelu", precision="fp32").state_dict()) == 139
     with pytest.raises(_lib.SvtError):  # no GPU input -> loud failure, no CPU fallback
         m({"video": torch.zeros(1, 1, 2, 32, 32), "audio": None})
+
+
+# ---- §8f rank 4: input pipeline and scoring (host code) ----
+def test_batch_pad_right_and_padded_batch_match_reference_golden(golden):
+    from svt_speechbrain_amd import dataio as D
+    fx = golden("dataio")
+    g = torch.Generator().manual_seed(31)
+    for c in fx["pad"]:
+        ts = [torch.randn(n, generator=g) for n in c["lens"]]
+        data, valid = D.batch_pad_right(ts)
+        assert tuple(data.shape) == c["shape"] and torch.equal(valid, c["valid"])
+        assert abs(float(data.double().sum()) - c["checksum"]) < 1e-9
+        if len(ts) > 1:
+            assert bool((data[1, c["lens"][1]:] == 0).all())
+    b = fx["batch"]
+    pb = D.PaddedBatch(b["examples"])
+    wavs, lens = pb.sig  # the unpacking compute_forward does
+    assert torch.equal(wavs, b["sig"]) and torch.equal(lens, b["sig_lens"])
+    assert torch.equal(pb.anno.data, b["anno"]) and torch.equal(pb.anno.lengths, b["anno_lens"])
+    assert pb.id == b["ids"] and torch.equal(pb.cur_utter, b["cur"]) and len(pb) == 3
+    assert pb["sig"].lengths is lens
+    with pytest.raises(IndexError):
+        D.batch_pad_right([])
+    with pytest.raises(EnvironmentError):
+        D.batch_pad_right([torch.zeros(3, 4), torch.zeros(2, 5)])
+
+
+def test_manifest_slicing_rules(tmp_path):
+    import csv
+    from svt_speechbrain_amd import dataio as D
+    # utterance plan of prepare_benchmarks.py:119-127 (round() is banker's rounding: 12.5 / 5 -> 2)
+    assert D.plan_utterances(12.3) == [5, pytest.approx(7.3)]
+    assert D.plan_utterances(7.4) == [7.4]
+    assert D.plan_utterances(7.6) == [5, pytest.approx(2.6)]
+    assert D.plan_utterances(12.5) == [5, 7.5]
+    assert D.plan_utterances(27.49) == [5, 5, 5, 5, pytest.approx(7.49)]
+    # the manifest as prepare_csv_benchmarks writes it
+    p = tmp_path / "test.csv"
+    with open(p, "w") as f:
+        wr = csv.writer(f, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
+        wr.writerow(D.CSV_COLUMNS)
+        for i, dur in enumerate(D.plan_utterances(12.3), start=1):
+            wr.writerow([f"7_{i}", str(dur), "/data/7/vocals.wav", str(i), "2", "/data/7/frame_anno.npy", "/data/7/annotation.json"])
+    rows = D.read_manifest(str(p))
+    assert [r["ID"] for r in rows] == ["7_1", "7_2"] and rows[0]["duration"] == 5.0 and rows[1]["utter_num"] == "2"
+    with open(p, "a") as f:
+        f.write("7_2,1.0,a,1,1,b,c\n")
+    with pytest.raises(ValueError):
+        D.read_manifest(str(p))
+    # slicing: the reference's expressions (train_audio_ssl.py:386-394, 412-420) evaluated literally
+    sig = torch.arange(16000 * 12 + 4800, dtype=torch.float32)
+    anno = torch.arange(612 * 4, dtype=torch.float32).view(612, 4)
+    for uid, unum in [(1, 2), (2, 2), (1, 1), (2, 3), (3, 3)]:
+        if uid == unum:
+            want_s = sig[round((uid - 1) * 16000 * 5):]
+            want_a = anno[round((uid - 1) * 49.8 * 5):]
+        else:
+            want_s = sig[round((uid - 1) * 16000 * 5):round(uid * 16000 * 5)]
+            want_a = anno[round((uid - 1) * 49.8 * 5):round(uid * 49.8 * 5)]
+        assert torch.equal(D.slice_audio(sig, str(uid), str(unum)), want_s)
+        assert torch.equal(D.slice_annotation(anno, str(uid), str(unum)), want_a)
+    assert D.slice_annotation(anno, 1, 2).shape[0] == 249 and D.slice_annotation(anno, 2, 3).shape[0] == 249  # round(249) .. round(498)
+
+
+def test_transcription_scores_hand_derived():
+    # PARITY UNPINNED (mir_eval is not installed here): known answers derived by hand from mir_eval's published rules
+    from svt_speechbrain_amd import scoring as SC
+    ref = [[0.0, 1.0, 60], [1.0, 2.0, 62], [2.0, 3.0, 64]]
+    est = [[0.02, 1.1, 60],      # onset, pitch, offset (0.1 <= max(0.2 * 1.0, 0.05)) all hit
+           [1.06, 2.0, 62],      # onset 0.06 > 0.05: no hit at all
+           [2.0, 3.5, 64.4],     # 40 cents ok, offset 0.5 > 0.2: counts only without the offset rule
+           [5.0, 6.0, 70]]       # spurious
+    m = SC.score_song(est, ref)
+    assert m["Precision"] == pytest.approx(1 / 4) and m["Recall"] == pytest.approx(1 / 3) and m["F-measure"] == pytest.approx(2 / 7)
+    assert m["Precision_no_offset"] == pytest.approx(2 / 4) and m["Recall_no_offset"] == pytest.approx(2 / 3)
+    assert m["F-measure_no_offset"] == pytest.approx(4 / 7)
+    assert m["Onset_Precision"] == pytest.approx(2 / 4) and m["Onset_Recall"] == pytest.approx(2 / 3)
+    # pitch tolerance is in cents: 0.6 semitone off = 60 cents -> miss
+    assert SC.score_song([[0.0, 1.0, 60.6]], [[0.0, 1.0, 60]])["F-measure_no_offset"] == 0.0
+    # the boundary is inclusive after rounding to 4 decimals (0.05000001 -> hit)
+    assert SC.score_song([[0.05000001, 1.0, 60]], [[0.0, 1.0, 60]])["Onset_F-measure"] == 1.0
+    # maximum matching, not greedy: est X fits refs A and B, est Y fits A only -> both can be matched
+    refs = [[1.00, 2.0, 60], [1.04, 2.0, 60]]
+    ests = [[1.02, 2.0, 60], [0.96, 2.0, 60]]
+    assert SC.score_song(ests, refs)["Onset_F-measure"] == 1.0 and SC.score_song(ests, refs)["F-measure"] == 1.0
+    # empty sides score zero; malformed intervals raise
+    assert SC.score_song([], refs)["F-measure"] == 0.0 and SC.score_song(ests, [])["Onset_Recall"] == 0.0
+    with pytest.raises(ValueError):
+        SC.score_song([[1.0, 1.0, 60]], refs)
+    assert SC.midi_to_hz(69) == pytest.approx(440.0) and SC.midi_to_hz(57) == pytest.approx(220.0)
