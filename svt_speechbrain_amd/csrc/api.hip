@@ -507,6 +507,7 @@ struct EncWs {
   float* preF;
   void* xb;
   float* xF;
+  void* xlo;
   void* posg;
   void* qkv;
   AttnBufs ab;
@@ -545,6 +546,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.preF = (float*)cv.take(rows * D * 4);
   w.xb = cv.take(rows * D * es);
   w.xF = c.precision ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
+  w.xlo = c.precision ? cv.take(rows * D * 2) : nullptr;  // low half of the (hi, lo) bf16 residual stream (post-LN, bf16 mode)
   w.posg = cv.take((size_t)B * (T + c.pos_conv_kernel) * D * es);
   w.qkv = cv.take(rows * 3 * D * es);
   w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * H * T * Tp * 4);
@@ -692,7 +694,28 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   // the GEMM epilogue and half the read of the LayerNorm) and widened when added to the fp32 residual stream
   const bool vecD = (D == 512 || D == 768 || D == 1024);
   const int tmp_f32 = (prec && vecD) ? 0 : 1;
-  if (!c.stable_layer_norm) {
+  if (!c.stable_layer_norm && prec && layernorm_hilo_ok(D) && c.num_layers > 0) {
+    // throughput mode: the residual stream lives as a bf16 (hi, lo) pair -- hi IS the operand copy the next GEMM
+    // reads -- so a LayerNorm moves 10 bytes per element instead of 12 (see kernels.hip, layernorm_hilo_kernel)
+    bf16_t* xh = (bf16_t*)w.xb;
+    bf16_t* xl = (bf16_t*)w.xlo;
+    if (int r = launch_layernorm_hilo(nullptr, nullptr, nullptr, w.preF, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps,
+                                      xh, xl, nullptr, s)) return r;
+    for (int l = 0; l < c.num_layers; ++l) {
+      const EncLayerW& Lw = e->layers[l];
+      const bool last = l + 1 == c.num_layers;
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = attention()) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 0, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps,
+                                        xh, xl, nullptr, s)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 0, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps,
+                                        xh, xl, last ? w.xF : nullptr, s)) return r;
+    }
+    final_x = w.xF;
+  } else if (!c.stable_layer_norm) {
     if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.xb,
                                  prec ? w.xF : nullptr, s)) return r;
     for (int l = 0; l < c.num_layers; ++l) {

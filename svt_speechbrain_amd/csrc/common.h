@@ -217,6 +217,10 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,
                       hipStream_t s);
 // frame head for K in {512,768,1024}, N <= 32: weight in LDS, four rows per wave (HBM-bound)
+// post-LN residual stream as a bf16 (hi, lo) pair (throughput mode, D in {512, 768, 1024})
+bool layernorm_hilo_ok(int D);
+int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
+                          const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s);
 // lip front-end (video.hip)
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,

@@ -163,6 +163,87 @@ __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const TI* x, con
   }
 }
 
+// Post-LN residual stream kept as a bf16 pair (hi = the operand copy the next GEMM reads anyway, lo = bf16(x - hi):
+// 16 mantissa bits, 2^-17 relative) instead of an extra fp32 copy: y = LN(branch + hi + lo) -> (hi', lo').  Per
+// element 6 bytes read + 4 written instead of 6 + 6 (the kernel is at the HBM roofline, so -17 % bytes = -17 % time).
+// yF (optional) also receives the full fp32 result (last layer: the whole-batch output norm reads it).
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_hilo_kernel(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl,
+                                                             int64_t rows, const float* gamma, const float* beta, float eps,
+                                                             bf16_t* yh, bf16_t* yl, float* yF) {
+  constexpr int D = 64 * VPT, NV = VPT / 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const long o = row * D + (lane + 64 * j) * 4;
+    const bf16x4 h = *(const bf16x4*)(rh + o), l = *(const bf16x4*)(rl + o);
+    float4 t = float4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+    if (branch) {
+      const bf16x4 a = *(const bf16x4*)(branch + o);
+      t.x += (float)a[0]; t.y += (float)a[1]; t.z += (float)a[2]; t.w += (float)a[3];
+    }
+    v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    const float o[4] = {fmaf(v[4 * j] * rstd, g.x, b.x), fmaf(v[4 * j + 1] * rstd, g.y, b.y),
+                        fmaf(v[4 * j + 2] * rstd, g.z, b.z), fmaf(v[4 * j + 3] * rstd, g.w, b.w)};
+    bf16x4 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { oh[i] = (bf16_t)o[i]; ol[i] = (bf16_t)(o[i] - (float)oh[i]); }
+    *(bf16x4*)(yh + row * D + c) = oh;
+    *(bf16x4*)(yl + row * D + c) = ol;
+    if (yF) *(float4*)(yF + row * D + c) = float4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+// fp32 -> (hi, lo) bf16 pair with a LayerNorm in front (first LN of the post-LN encoder): x fp32 in
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_f32_to_hilo_kernel(const float* x, int64_t rows, const float* gamma,
+                                                                    const float* beta, float eps, bf16_t* yh, bf16_t* yl) {
+  constexpr int D = 64 * VPT, NV = VPT / 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float4 t = ((const float4*)(x + row * D))[lane + 64 * j];
+    v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    const float o[4] = {fmaf(v[4 * j] * rstd, g.x, b.x), fmaf(v[4 * j + 1] * rstd, g.y, b.y),
+                        fmaf(v[4 * j + 2] * rstd, g.z, b.z), fmaf(v[4 * j + 3] * rstd, g.w, b.w)};
+    bf16x4 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { oh[i] = (bf16_t)o[i]; ol[i] = (bf16_t)(o[i] - (float)oh[i]); }
+    *(bf16x4*)(yh + row * D + c) = oh;
+    *(bf16x4*)(yl + row * D + c) = ol;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv layer 0, "group" mode.  GroupNorm(C groups) needs per-(clip,channel) mean/var over ALL frames
 // before the GELU.  Because Cin = 1, y[c,t] = w_c . window_t, so the statistics of all C channels
@@ -842,6 +923,24 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
   } else {
     hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, add, sumF, rows, D,
                        gamma, beta, eps, gelu, (bf16_t*)yT, yF);
+  }
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+bool layernorm_hilo_ok(int D) { return D == 512 || D == 768 || D == 1024; }
+// branch == nullptr && x32 != nullptr: y = LN(x32);  otherwise y = LN(branch + rh + rl)
+int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
+                          const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (x32) {
+    if (D == 512) hipLaunchKernelGGL((layernorm_f32_to_hilo_kernel<8>), grid, block, 0, s, x32, rows, gamma, beta, eps, yh, yl);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_f32_to_hilo_kernel<12>), grid, block, 0, s, x32, rows, gamma, beta, eps, yh, yl);
+    else hipLaunchKernelGGL((layernorm_f32_to_hilo_kernel<16>), grid, block, 0, s, x32, rows, gamma, beta, eps, yh, yl);
+  } else {
+    if (D == 512) hipLaunchKernelGGL((layernorm_hilo_kernel<8>), grid, block, 0, s, branch, rh, rl, rows, gamma, beta, eps, yh, yl, yF);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_hilo_kernel<12>), grid, block, 0, s, branch, rh, rl, rows, gamma, beta, eps, yh, yl, yF);
+    else hipLaunchKernelGGL((layernorm_hilo_kernel<16>), grid, block, 0, s, branch, rh, rl, rows, gamma, beta, eps, yh, yl, yF);
   }
   SVT_LAUNCH_CHECK();
   return 0;
