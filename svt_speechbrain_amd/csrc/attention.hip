@@ -5,10 +5,10 @@
 //
 // Mapping (wave64, v_mfma_f32_32x32x16_bf16):
 //   * block = 4 waves = 128 queries of one (clip, head); each wave owns 32 queries for the whole sweep.
-//   * K and V tiles of 64 keys are staged global -> registers -> LDS row-major with an XOR swizzle of the
-//     16-byte chunks (8 consecutive lanes fetch one 128-byte row: one request per line); next tile's global
-//     loads are issued before the current tile's MFMAs and written after them (one LDS buffer, two barriers
-//     per tile; several blocks per CU cover the rest of the latency).
+//   * K and V tiles of 64 keys are moved global -> LDS by LDS-DMA (no staging registers, no ds_write) into a row-major
+//     image with an XOR swizzle of the 16-byte chunks, applied on the SOURCE address (8 consecutive lanes fetch one
+//     128-byte row: one request per line); two stages, the next tile is in flight during the current tile's MFMAs,
+//     one barrier per tile.
 //   * S^T = K Q^T is computed with keys on the MFMA rows, so a lane holds 16 keys x 1 query per 32-key
 //     block: the row max / row sum are in-register reductions plus ONE cross-lane exchange
 //     (lane ^ 32).  The S accumulator, converted pairwise to bf16, is directly the B operand of
@@ -37,10 +37,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
   constexpr int KSD = DH / 16;   // k-steps over head_dim for S
   constexpr int DB = DH / 32;    // 32-row blocks of O^T
   constexpr int CPR = DH / 8;    // 16-byte chunks per K row
-  constexpr int KP = CPR / 4;    // K pieces per thread per tile (64 keys)
   constexpr int RB = 2 * DH;     // bytes per K / V row in LDS
-  __shared__ __attribute__((aligned(16))) uint4 Kf[2 * KSD * 64];
-  __shared__ __attribute__((aligned(16))) uint4 Vs[64 * CPR];  // V tile, row-major [key][slot], slot = chunk ^ sw(key)
+  // two stages of { K tile, V tile }, each tile row-major [key][slot] with slot = chunk ^ swizzle(key); filled by LDS-DMA
+  constexpr int TILE16 = 64 * CPR;  // uint4 per tile
+  __shared__ __attribute__((aligned(16))) uint4 KV[2][2 * TILE16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -59,57 +59,38 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
-  // staging maps.  Global side: 8 (DH=64) / 16 (DH=128) consecutive lanes fetch the consecutive 16-byte chunks of ONE
-  // row, so the texture addresser issues one request per 128-byte line (a lane-per-row mapping costs one request
-  // per lane).  K tile in LDS: row-major [key][slot], slot = chunk ^ g(key) (g = (key>>1)&7 for 128-byte rows,
-  // key&15 for 256-byte rows) -> the 32x32x16 A-operand read (32 keys x one chunk) is a conflict-free ds_read_b128.
-  int koff[KP], kdst[KP], kkey[KP];
+  // LDS-DMA staging: a wave instruction moves 64 x 16 B = 1 KB = ROWS_PER_DMA whole rows; lane (row r = lane / CPR,
+  // slot = lane % CPR) fetches chunk slot ^ g(key) of its row, so the linear LDS image holds chunk c of a key at slot
+  // c ^ g(key) -- the same swizzled row-major layout the MFMA operand reads below expect (K: g = (key>>1)&7 for
+  // 128-byte rows, key&15 for 256-byte rows; V: (key>>1 & 1) << 2, resp. (key & 3) << 2).  No staging registers, no
+  // ds_write; the next tile is in flight while the current one is multiplied (two stages, one barrier per tile).
+  constexpr int ROWS_PER_DMA = 64 / CPR;                 // 8 (dh 64) / 4 (dh 128)
+  constexpr int DMA_PER_WAVE = 64 / ROWS_PER_DMA / 4;    // 2 / 4 instructions per wave per tile and operand
+  int dkey[DMA_PER_WAVE], kch[DMA_PER_WAVE], vch[DMA_PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < KP; ++i) {
-    const int f = i * 256 + tid;
-    const int cc = f % CPR, kk = f / CPR;  // chunk, key in tile
-    koff[i] = cc * 8;                      // + key * ldk at load time (clamped)
-    kkey[i] = kk;
+  for (int i = 0; i < DMA_PER_WAVE; ++i) {
+    const int kk = (wave * DMA_PER_WAVE + i) * ROWS_PER_DMA + lane / CPR;  // key within the tile
+    const int slot = lane % CPR;
     const int g = (DH == 64) ? ((kk >> 1) & 7) : (kk & 15);
-    kdst[i] = kk * CPR + (cc ^ g);
-  }
-  int vdst[KP];
-#pragma unroll
-  for (int i = 0; i < KP; ++i) {
-    const int f = i * 256 + tid;
-    const int cc = f % CPR, kk = f / CPR;
     const int sw = (DH == 64) ? (((kk >> 1) & 1) << 2) : ((kk & 3) << 2);
-    vdst[i] = kk * CPR + (cc ^ sw);
+    dkey[i] = kk;
+    kch[i] = (slot ^ g) * 8;
+    vch[i] = (slot ^ sw) * 8;
   }
-
-  u32x4 kr[KP], vr[KP];
-  const bf16_t* kptr[KP];
-  const long vdelta = Vb - Kb;  // V rows sit at a fixed distance from the K rows (same packed buffer / same strides)
-#pragma unroll
-  for (int i = 0; i < KP; ++i) kptr[i] = Kb + koff[i] + (long)kkey[i] * ldk;
-  // (written as macros, not lambdas: arrays captured by reference in a lambda called from two sites were left in
-  // scratch memory by the compiler)
-#define SVT_STAGE_LOAD(TILE)                                                          \
-  {                                                                                   \
-    const int key0_ = (TILE) * 64;                                                    \
-    if (key0_ + 64 <= T) {                                                            \
-      _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                \
-        kr[i] = *(const u32x4*)(kptr[i]);                                             \
-        vr[i] = *(const u32x4*)(kptr[i] + vdelta);                                    \
-        kptr[i] += 64 * ldk;                                                          \
-      }                                                                               \
-    } else {                                                                          \
-      _Pragma("unroll") for (int i = 0; i < KP; ++i) {                                \
-        int key_ = key0_ + kkey[i];                                                   \
-        if (key_ > T - 1) key_ = T - 1;                                               \
-        kr[i] = *(const u32x4*)(Kb + koff[i] + (long)key_ * ldk);                     \
-        vr[i] = *(const u32x4*)(Vb + koff[i] + (long)key_ * ldk);                     \
-      }                                                                               \
-    }                                                                                 \
-  }
-#define SVT_STAGE_WRITE()                                                             \
-  {                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < KP; ++i) { ((u32x4*)Kf)[kdst[i]] = kr[i]; ((u32x4*)Vs)[vdst[i]] = vr[i]; } \
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+#define SVT_STAGE_DMA(TILE, STAGE)                                                                                  \
+  {                                                                                                                  \
+    const int key0_ = (TILE) * 64;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < DMA_PER_WAVE; ++i) {                                                       \
+      int key_ = key0_ + dkey[i];                                                                                    \
+      if (key_ > T - 1) key_ = T - 1;                                                                                \
+      const bf16_t* kp_ = Kb + (long)key_ * ldk;                                                                     \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kp_ + kch[i]),                                                       \
+                                       (lptr_t)(&KV[STAGE][(wave * DMA_PER_WAVE + i) * 64]), 16, 0, 0);              \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kp_ + (Vb - Kb) + vch[i]),                                           \
+                                       (lptr_t)(&KV[STAGE][TILE16 + (wave * DMA_PER_WAVE + i) * 64]), 16, 0, 0);     \
+    }                                                                                                                \
   }
 
   f32x16 o[DB];
@@ -131,16 +112,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
       const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
-      vbase[db] = (const char*)Vs + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
+      vbase[db] = (const char*)&KV[0][TILE16] + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
     }
   }
 
-  SVT_STAGE_LOAD(0)
+  constexpr long STAGE_BYTES = (long)2 * TILE16 * 16;
+  SVT_STAGE_DMA(0, 0)
   for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();  // previous tile fully consumed
-    SVT_STAGE_WRITE()
+    const int st = tile & 1;
+    // own fills of this tile have landed (vmcnt(0), emitted with the barrier), everyone's have after the barrier, and
+    // every wave is done reading the other stage (tile - 1), which the next fill overwrites
     __syncthreads();
-    if (tile + 1 < ntiles) SVT_STAGE_LOAD(tile + 1)
+    if (tile + 1 < ntiles) {
+      if (st) SVT_STAGE_DMA(tile + 1, 0) else SVT_STAGE_DMA(tile + 1, 1)
+    }
+    const uint4* Kf = KV[st];
 
     f32x16 s[2];
 #pragma unroll
@@ -214,7 +200,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
           // A operand of O^T += V^T P^T straight from the row-major V tile: two ds_read_b64_tr_b16 (4 keys x 16 d
           // blocks, delivered column-major) give this lane V[key][d] for its d and the permuted k-slots
           // {16s+4h+0..3, 16s+8+4h+0..3}
-          const char* vp = vbase[db] + (kb * 32 + ss * 16) * RB;
+          const char* vp = vbase[db] + st * STAGE_BYTES + (kb * 32 + ss * 16) * RB;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
           const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -238,8 +224,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     }
 }
 
-#undef SVT_STAGE_LOAD
-#undef SVT_STAGE_WRITE
+#undef SVT_STAGE_DMA
 }  // namespace
 
 // V row-major (same layout and strides as K): no transposed copy of V is needed
