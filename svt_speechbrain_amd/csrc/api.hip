@@ -207,6 +207,8 @@ struct svt_encoder {
   ParamMap params;
   std::vector<ConvLayerW> conv;
   DevBuf fp_g, fp_b, proj_w, proj_b, pos_w, pos_b, enc_g, enc_b;
+  DevBuf pos_wP, pos_bP;   // multi-frame form of the positional conv (bf16 mode): P frames per GEMM row
+  int pos_P = 0;
   std::vector<EncLayerW> layers;
 };
 
@@ -435,6 +437,28 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = upload_operand(prec, e->pos_w, wt.data(), wt.size())) return r;
     if (int r = need(P, pc + "bias", {D}, &p)) return r;
     if (int r = upload_f32(e->pos_b, p->v.data(), p->v.size())) return r;
+    // Multi-frame form (throughput mode).  The grouped conv has only cg = D/G (48 / 64) output channels per group: a
+    // 64-wide product.  With Pf consecutive output frames per GEMM row the product is Pf*cg (240 / 256) wide and K grows
+    // only from kp*cg to (kp+Pf-1)*cg (+3 %, the kernel is 128 taps long): row j*cg+co of a group holds the same filter
+    // shifted by j taps.  That runs on the LDS-DMA kernel instead of the 64-wide register-staged one.
+    e->pos_P = 0;
+    const int Pf = cg > 0 ? 256 / cg : 0;
+    if (prec && Pf >= 2 && cg % 8 == 0 && ((kp + Pf - 1) * cg) % 64 == 0) {
+      const size_t Np = (size_t)Pf * cg, Kp = (size_t)(kp + Pf - 1) * cg;
+      std::vector<float> wp((size_t)G * Np * Kp, 0.f), bp((size_t)G * Np);
+      for (int g = 0; g < G; ++g)
+        for (int j = 0; j < Pf; ++j)
+          for (int co = 0; co < cg; ++co) {
+            const int o = g * cg + co;
+            bp[(size_t)g * Np + (size_t)j * cg + co] = p->v[o];
+            float* row = wp.data() + ((size_t)g * Np + (size_t)j * cg + co) * Kp;
+            for (int k = 0; k < kp; ++k)
+              for (int ci = 0; ci < cg; ++ci) row[(size_t)(k + j) * cg + ci] = w[((size_t)o * cg + ci) * kp + k];
+          }
+      if (int r = upload_operand(1, e->pos_wP, wp.data(), wp.size())) return r;
+      if (int r = upload_f32(e->pos_bP, bp.data(), bp.size())) return r;
+      e->pos_P = Pf;
+    }
   }
   if (int r = need(P, "encoder.layer_norm.weight", {D}, &p)) return r;
   if (int r = upload_f32(e->enc_g, p->v.data(), p->v.size())) return r;
@@ -509,6 +533,7 @@ struct EncWs {
   float* xF;
   void* xlo;
   void* posg;
+  void* posy;
   void* qkv;
   AttnBufs ab;
   void* attn_o;
@@ -547,7 +572,13 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.xb = cv.take(rows * D * es);
   w.xF = c.precision ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
   w.xlo = c.precision ? cv.take(rows * D * 2) : nullptr;  // low half of the (hi, lo) bf16 residual stream (post-LN, bf16 mode)
-  w.posg = cv.take((size_t)B * (T + c.pos_conv_kernel) * D * es);
+  {
+    const int Pf = e->pos_P;
+    const size_t Tq = Pf ? (T + Pf - 1) / Pf : 0;
+    const size_t Tp = Pf ? Tq * Pf + c.pos_conv_kernel : (size_t)(T + c.pos_conv_kernel);
+    w.posg = cv.take((size_t)B * Tp * D * es);
+    w.posy = Pf ? cv.take((size_t)B * Tq * Pf * D * 2) : nullptr;
+  }
   w.qkv = cv.take(rows * 3 * D * es);
   w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * H * T * Tp * 4);
   w.ab.P = flash ? nullptr : cv.take((size_t)B * H * T * Tp * es);
@@ -658,7 +689,22 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   // ---- positional conv embedding: pre = h + gelu(grouped_conv(h) + b) ----
   {
     const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
-    if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, w.posg, s)) return r;
+    const int Pf = e->pos_P;
+    if (Pf && (int64_t)B * ((T + Pf - 1) / Pf) >= 128) {
+      const int Tq = (int)((T + Pf - 1) / Pf), Tp = Tq * Pf + kp;
+      if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, Tp, w.posg, s)) return r;
+      GemmArgs g;
+      g.A = w.posg; g.W = e->pos_wP.p; g.C = w.posy; g.bias = e->pos_bP.as<float>();
+      g.M = B * Tq; g.N = Pf * cg; g.K = (kp + Pf - 1) * cg;
+      g.a_rpb = Tq; g.a_bstride = (long)G * Tp * cg; g.a_rstride = (long)Pf * cg;
+      g.ldw = g.K; g.ldc = g.N;
+      g.nz = G; g.nz2 = G;
+      g.a_z2 = (long)Tp * cg; g.w_z2 = (long)g.N * g.K; g.c_z2 = (long)B * Tq * g.N; g.bias_z2 = g.N;
+      g.act = ACT_GELU; g.out_f32 = 0;
+      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_posconv_scatter_add(w.hF, w.posy, B, (int)T, D, G, Pf, Tq, w.preF, s)) return r;
+    } else {
+    if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, (int)T + kp, w.posg, s)) return r;
     GemmArgs g;
     g.A = w.posg; g.W = e->pos_w.p; g.C = w.preF; g.bias = e->pos_b.as<float>(); g.resid = w.hF;
     g.M = (int)T; g.N = cg; g.K = kp * cg;
@@ -670,6 +716,7 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     g.c_z1 = (long)T * D; g.c_z2 = cg; g.bias_z2 = cg;
     g.act = ACT_GELU; g.out_f32 = 1;
     if (int r = launch_gemm(prec, g, s)) return r;
+    }
   }
   const float scale = 1.0f / std::sqrt((float)dh);
   auto attention = [&](void) -> int {

@@ -461,9 +461,8 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int6
 
 // ------------------------------------------------------------------------------------------------
 template <typename TO>
-__global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G, int kp, TO* out) {
+__global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, TO* out) {
   const int cg = D / G;
-  const int Tp = T + kp;
   const int64_t n = (int64_t)B * G * Tp * cg;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -996,14 +995,40 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
   return 0;
 }
 
-int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, void* out, hipStream_t s) {
-  const int64_t n = (int64_t)B * (T + kp) * D;
+int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s) {
+  const int64_t n = (int64_t)B * Tp * D;
   if (prec)
-    hipLaunchKernelGGL((posconv_gather_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp,
+    hipLaunchKernelGGL((posconv_gather_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp, Tp,
                        (bf16_t*)out);
   else
-    hipLaunchKernelGGL((posconv_gather_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp,
+    hipLaunchKernelGGL((posconv_gather_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp, Tp,
                        (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+// multi-frame positional conv: y[g][b*Tq + q][j*cg + c] (bf16, GELU applied) holds frame t = q*P + j of group g;
+// pre[b][t][g*cg + c] = h[b][t][g*cg + c] + y[...]  (8 channels per thread)
+__global__ void posconv_scatter_add_kernel(const float* h, const bf16_t* y, int B, int T, int D, int G, int P, int Tq, float* pre) {
+  const int cg = D / G, c8n = D / 8;
+  const int64_t n = (int64_t)B * T * c8n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c8n) * 8;
+    const int64_t r = i / c8n;
+    const int t = (int)(r % T), b = (int)(r / T);
+    const int g = ch / cg, c = ch - g * cg;
+    const int q = t / P, j = t - q * P;
+    const bf16x8 v = *(const bf16x8*)(y + (((int64_t)g * B + b) * Tq + q) * (P * cg) + j * cg + c);
+    const float* hp = h + r * D + ch;
+    const float4 h0 = *(const float4*)hp, h1 = *(const float4*)(hp + 4);
+    float* op = pre + r * D + ch;
+    *(float4*)op = float4{h0.x + (float)v[0], h0.y + (float)v[1], h0.z + (float)v[2], h0.w + (float)v[3]};
+    *(float4*)(op + 4) = float4{h1.x + (float)v[4], h1.y + (float)v[5], h1.z + (float)v[6], h1.w + (float)v[7]};
+  }
+}
+int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s) {
+  const int64_t n = (int64_t)B * T * (D / 8);
+  hipLaunchKernelGGL(posconv_scatter_add_kernel, dim3(grid_for(n)), dim3(256), 0, s, h, (const bf16_t*)y, B, T, D, G, P, Tq, pre);
   SVT_LAUNCH_CHECK();
   return 0;
 }
