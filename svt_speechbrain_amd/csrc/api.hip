@@ -780,24 +780,30 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     final_x = w.xF;
   } else {
     float* h = w.preF;
-    const float* pending = nullptr;  // branch output not yet added to h
+    const void* pending = nullptr;  // branch output not yet added to h
+    // branch outputs in the operand type in throughput mode (bf16: half the GEMM store burst and 2 of the 14 bytes per
+    // element the LayerNorm moves); the fp32 residual stream h is updated in place by the LayerNorm kernel (sumF)
+    auto ln_add = [&](const float* g_, const float* b_, const void* branch, void* y_op, float* y_f32) -> int {
+      if (!branch) return launch_layernorm(prec, h, 1, rows, D, g_, b_, eps, 0, y_op, y_f32, s, nullptr, nullptr);
+      if (!tmp_f32)  // x = bf16 branch, add = fp32 residual, sumF = residual updated in place
+        return launch_layernorm(prec, branch, 0, rows, D, g_, b_, eps, 0, y_op, y_f32, s, h, y_op ? h : nullptr);
+      return launch_layernorm(y_op ? prec : 0, h, 1, rows, D, g_, b_, eps, 0, y_op ? y_op : (void*)y_f32, nullptr, s,
+                              (const float*)branch, y_op ? h : nullptr);
+    };
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
-      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb, nullptr, s,
-                                   pending, pending ? h : nullptr)) return r;
+      if (int r = ln_add(Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), pending, w.xb, nullptr)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
       if (int r = attention()) return r;
-      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, h, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, w.xb, nullptr, s,
-                                   tmp, h)) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
+      if (int r = ln_add(Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), tmp, w.xb, nullptr)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
-      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
       pending = tmp;
     }
     // final LN(h + last FFN branch) -> fp32 (xF is unused in this family when prec == 0 it aliases xb: use qkv space)
     float* fin = (float*)w.qkv;
-    if (int r = launch_layernorm(0, h, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, fin, nullptr, s,
-                                 pending, nullptr)) return r;
+    if (int r = ln_add(e->enc_g.as<float>(), e->enc_b.as<float>(), pending, nullptr, fin)) return r;
     final_x = fin;
   }
   // ---- wrapper's whole-batch output LayerNorm ----
