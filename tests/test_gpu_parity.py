@@ -83,7 +83,7 @@ def test_full_size_fp32_vs_reference_golden(golden, name):
     check_decode(logits, fx, exact=True)
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "large_c1"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1"])  # base_b2: 2 x 10 s -> multi-frame positional conv
 def test_bf16_mode_error_bound(golden, name):
     """bf16 MFMA operands, fp32 accumulate/residual/norms: bounded error, decode mostly identical."""
     fx = golden(name)
