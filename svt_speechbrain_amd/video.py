@@ -172,7 +172,13 @@ class FairseqAVHubertPretrain(nn.Module):
             if not k.startswith("feature_extractor_video."):
                 self.model.add(k, v)
         if pretrained_path is not None and pretrain:
-            self.load_fairseq_model_state(self._read_fairseq_checkpoint(pretrained_path))
+            # the reference downloads `pretrained_path` (a URL in the recipes' yaml) to `save_path` and loads that file
+            # (fairseq_interface.py:392-412); there is no network here, so the file has to be in place already
+            path = save_path if (save_path and os.path.exists(save_path)) else pretrained_path
+            if str(path).startswith(("http://", "https://")):
+                raise _lib.SvtError(f"no network in this build: put the AV-HuBERT checkpoint at save_path ({save_path!r}) "
+                                    f"instead of downloading {pretrained_path}")
+            self.load_fairseq_model_state(self._read_fairseq_checkpoint(path))
         if self.freeze:
             self.eval()
             for p in self.parameters():
