@@ -478,6 +478,31 @@ __global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G
   }
 }
 
+// bf16 output, 8 channels (16 bytes out, 32 bytes in) per thread
+__global__ void posconv_gather_bf16x8_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, bf16_t* out) {
+  const int cg = D / G, c8 = cg / 8;
+  const int64_t n = (int64_t)B * G * Tp * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % c8) * 8;
+    int64_t r = i / c8;
+    const int tp = (int)(r % Tp); r /= Tp;
+    const int g = (int)(r % G);
+    const int b = (int)(r / G);
+    const int t = tp - kp / 2;
+    bf16x8 o;
+    if (t >= 0 && t < T) {
+      const float* src = h + ((int64_t)b * T + t) * D + g * cg + ci;
+      const float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+      o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+      o[4] = (bf16_t)c.x; o[5] = (bf16_t)c.y; o[6] = (bf16_t)c.z; o[7] = (bf16_t)c.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    }
+    *(bf16x8*)(out + (((int64_t)b * G + g) * Tp + tp) * cg + ci) = o;
+  }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int64_t rows, int T, int Tp, TO* P) {
   const int lane = threadIdx.x & 63;
@@ -997,7 +1022,9 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
 
 int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s) {
   const int64_t n = (int64_t)B * Tp * D;
-  if (prec)
+  if (prec && (D / G) % 8 == 0 && !((uintptr_t)h & 15) && !((uintptr_t)out & 15))
+    hipLaunchKernelGGL(posconv_gather_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, h, B, T, D, G, kp, Tp, (bf16_t*)out);
+  else if (prec)
     hipLaunchKernelGGL((posconv_gather_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp, Tp,
                        (bf16_t*)out);
   else
