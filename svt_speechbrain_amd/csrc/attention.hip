@@ -120,8 +120,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
   SVT_STAGE_DMA(0, 0)
   for (int tile = 0; tile < ntiles; ++tile) {
     const int st = tile & 1;
-    // own fills of this tile have landed (vmcnt(0), emitted with the barrier), everyone's have after the barrier, and
-    // every wave is done reading the other stage (tile - 1), which the next fill overwrites
+    // own fills of this tile have landed (explicit vmcnt(0): hipcc's own placement of that wait is an alias-analysis
+    // artefact, not a contract), everyone's have after the barrier, and every wave is done reading the other stage
+    // (tile - 1), which the next fill overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tile + 1 < ntiles) {
       if (st) SVT_STAGE_DMA(tile + 1, 0) else SVT_STAGE_DMA(tile + 1, 1)
