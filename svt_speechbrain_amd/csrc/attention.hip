@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     }
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);  // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     if (!__all(mx - m <= 8.0f)) {
       const float mnew = fmaxf(m, mx);
@@ -169,19 +169,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
-    float sum0 = 0.f, sum1 = 0.f;
+    // exponent arguments and row sums on pairs (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot)
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    f32x2v sum2 = {0.f, 0.f};
+    const f32x2v c2 = {c, c}, nm2 = {-m, -m};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], c, -m));
-        s[kb][r] = p0;
-        s[kb][r + 1] = p1;
-        sum0 += p0;
-        sum1 += p1;
+        const f32x2v e = f32x2v{s[kb][r], s[kb][r + 1]} * c2 + nm2;
+        const f32x2v pp = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+        s[kb][r] = pp.x;
+        s[kb][r + 1] = pp.y;
+        sum2 += pp;
       }
-    float sum = sum0 + sum1;
+    float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 32, 64);
     l += sum;
     // P (bf16) fragments straight from the S accumulators: k-step ss of key block kb = regs 8ss..8ss+7
