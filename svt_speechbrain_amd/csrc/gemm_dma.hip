@@ -629,7 +629,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
           for (int nb = 0; nb < 4; ++nb) {
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[nb][mb][r] * p.alpha + bv[nb * 4 + r], p.act);
+            for (int r = 0; r < 4; ++r) v[r] = acc[nb][mb][r] * p.alpha + bv[nb * 4 + r];
+            // activation selected once per block of four (wave-uniform), not per element
+            if (p.act == ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), crsrc, off + nb * 16, 0, 0);
           }
         }
@@ -654,11 +662,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
                 o[2 * j] = (bf16_t)g[j].x;
                 o[2 * j + 1] = (bf16_t)g[j].y;
               }
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int nbr = h * 8 + j;
+                const float x = acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr];
+                o[j] = (bf16_t)(x > 0.f ? x : 0.f);
+              }
             } else {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 const int nbr = h * 8 + j;
-                o[j] = (bf16_t)apply_act(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr], p.act);
+                o[j] = (bf16_t)(acc[nbr >> 2][mb][nbr & 3] * p.alpha + bv[nbr]);
               }
             }
             if (p.dbg != 10) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), crsrc, off + h * 16, 0, 0);
