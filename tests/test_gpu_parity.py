@@ -329,3 +329,25 @@ def test_evaluation_loop_manifest_to_scores():
     # and a perturbed transcription scores below 1
     worse = [[n[0] + 0.2, n[1] + 0.2, n[2]] for n in notes[: len(notes) // 2]] + notes[len(notes) // 2:]
     assert SC.score_song(worse, ref_notes)["Onset_F-measure"] < 1.0
+
+
+def test_two_streams_bitwise_identical_to_one():
+    """bench.py issues successive steps on two HIP streams (two encoder objects).  Kernels that share the chip run with
+    different timing (the LDS-DMA pipelines order their reads by counted waits, not by luck): every overlapped result must
+    be bit-identical to the single-stream result."""
+    cfg = PRESETS["wav2vec2-base"]
+    encs = [S.HuggingFaceWav2Vec2("wav2vec2-base", None, config=cfg, precision="bf16", seed=3).to(DEV) for _ in range(2)]
+    head = S.Linear(20, input_size=cfg.hidden_size).to(DEV)
+    wavs = [synth_wav(4, 160000, 50 + i).to(DEV) for i in range(2)]
+    ref = [head(encs[0](w)).clone() for w in wavs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    streams[1].wait_stream(streams[0])
+    outs = []
+    for it in range(12):
+        i = it % 2
+        with torch.cuda.stream(streams[i]):
+            outs.append((i, head(encs[i](wavs[i]))))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        assert torch.equal(o, ref[i]), "overlapped step differs from the single-stream result"
