@@ -14,6 +14,10 @@
 //   * two kernels share this pipeline: gemm_pp8_kernel (one tile per workgroup, LDS-transposed coalesced epilogue)
 //     and gemm_pers_kernel (one workgroup per CU walks a tile list; the next tile's fills and the epilogue stores
 //     overlap the MFMAs).  launch_gemm_dma picks BM in {128,192,256} and the kernel per problem.
+//   * gemm_pp8_kernel<BM, GEN = true, NBW> is the same pipeline with generalised addressing (GemmArgs::gen): A rows at
+//     m*stride + floor(m/d1)*e1 + floor(m/d2)*e2, K made of equal runs a fixed distance apart, C rows likewise -- the
+//     3x3 / 1x1 convolutions of the lip front-end's ResNet over zero-haloed channels-last tensors -- with bias +
+//     residual (operand type) + per-column PReLU in the epilogue; NBW = 2 gives a 128-column tile for 128-channel layers.
 #include "common.h"
 #include <utility>
 
