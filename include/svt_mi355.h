@@ -200,6 +200,11 @@ int svt_softmax(const float* x_dev, int64_t rows, int32_t n, int32_t apply_log, 
 int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
                         int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
                         void* stream);
+/* Fused attention-output projection + residual + LayerNorm (hidden size 768, bf16): y = LN(a w^T + bias + rh + rl) as a
+ * bf16 (hi, lo) pair [+ fp32 copy].  Replaces Wav2Vec2Attention.out_proj followed by `hidden_states = attn_residual +
+ * hidden_states; hidden_states = self.layer_norm(hidden_states)` (HF modeling_wav2vec2.py:575-590); test hook. */
+int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const void* rh, const void* rl, int32_t m, int32_t k,
+                         const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yf, int device, void* stream);
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

@@ -222,6 +222,10 @@ int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const
 bool layernorm_hilo_ok(int D);
 int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
                           const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s);
+// attention output projection + residual + LayerNorm in one kernel (gemm_ln.hip; hidden size 768, bf16 mode)
+bool outproj_ln_eligible(int D, int K);
+int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias, const void* rh, const void* rl, int M, int K,
+                      const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yF, hipStream_t s);
 // lip front-end (video.hip)
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,
