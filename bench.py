@@ -210,7 +210,7 @@ def main():
         if os.path.exists(pmc_file) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
             try:
                 pm = json.load(open(pmc_file))
-                fam = [v for k, v in pm.items() if k.startswith("gemm_pers_kernel") or k.startswith("gemm_pp8_kernel")]
+                fam = [v for k, v in pm.items() if k.startswith(("gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel"))]
                 tot_n = sum(v["launches"] for v in fam)
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
             except Exception:
@@ -237,7 +237,7 @@ def main():
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # dominant kernel = svt::gemm_pp8_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
             # launches / HIP-event time of those launches on their stream, over the timed region
-            "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, persistent or one tile per workgroup)",
+            "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline: persistent, one tile per workgroup, or row-complete with fused LayerNorm)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": "GB of HBM traffic per launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
