@@ -255,7 +255,7 @@ int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias,
   }
   prof_begin(s);
   hipLaunchKernelGGL(outproj_ln_kernel, dim3((M + kBM - 1) / kBM), dim3(512), lds_bytes, s, a);
-  prof_end(s, 2.0 * M * (double)kD * K, 0.0, 0);
+  prof_end(s, 2.0 * M * (double)kD * K, ((double)M * K + (double)kD * K + 4.0 * M * kD) * 2 + (yF ? 4.0 * M * kD : 0.0), 0);
   SVT_LAUNCH_CHECK();
   return 0;
 }
