@@ -423,19 +423,28 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int6
     be[i] = beta[c];
   }
   const int nfr = (int)((T1 - t0 < FPW) ? (T1 - t0) : FPW);
+  // the wave's normalised samples staged once in a wave-private LDS strip (was: ten broadcast global loads per frame)
+  __shared__ float xs[4][FPW * 5 + 16];  // stride <= 5
+  {
+    const int ns = (nfr - 1) * stride + K0;
+    for (int i = lane; i < ns; i += 64) xs[wave][i] = (x[t0 * stride + i] - mu) * r;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
   for (int f = 0; f < nfr; ++f) {
     float xv[K0];
 #pragma unroll
-    for (int j = 0; j < K0; ++j) xv[j] = (x[(t0 + f) * stride + j] - mu) * r;
+    for (int j = 0; j < K0; ++j) xv[j] = xs[wave][f * stride + j];
     float y[8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float a = bb[i];
+    for (int i = 0; i < 8; i += 2) {  // channel pairs on packed fp32 math
+      f32x2_t a = {bb[i], bb[i + 1]};
 #pragma unroll
-      for (int j = 0; j < K0; ++j) a = fmaf(w[i][j], xv[j], a);
-      y[i] = a;
-      if (active) s += a;
+      for (int j = 0; j < K0; ++j) a = f32x2_t{w[i][j], w[i + 1][j]} * xv[j] + a;
+      y[i] = a.x;
+      y[i + 1] = a.y;
+      if (active) s += a.x + a.y;
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
@@ -444,8 +453,19 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int6
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     if (!active) continue;
     float o[8];
+    if constexpr (sizeof(TO) == 2) {
+      // bf16 result: polynomial GELU, four pair-chains interleaved (common.h)
+      f32x2_t a4[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = gelu_erf((y[i] - mean) * rstd * g[i] + be[i]);
+      for (int i = 0; i < 4; ++i)
+        a4[i] = f32x2_t{(y[2 * i] - mean) * rstd * g[2 * i] + be[2 * i], (y[2 * i + 1] - mean) * rstd * g[2 * i + 1] + be[2 * i + 1]};
+      gelu_bf16x2_x4(a4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { o[2 * i] = a4[i].x; o[2 * i + 1] = a4[i].y; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = gelu_erf((y[i] - mean) * rstd * g[i] + be[i]);
+    }
     TO* dst = out + ((int64_t)b * T1 + t0 + f) * C + c0;
     if constexpr (sizeof(TO) == 2) {
       bf16x8 v;
