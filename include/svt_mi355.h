@@ -175,6 +175,14 @@ int64_t svt_video_workspace_bytes(const svt_video* v, int32_t batch, int32_t t, 
 int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- Fbank add-ons: replace speechbrain.processing.features.Deltas (features.py:788-850; replicate padding, kernel
+ * -n..n, denominator n(n+1)(2n+1)/3) and ContextWindow (:853-940; out[..., c*ctx + j], zero padding).  x rows have pitch ldx
+ * (so a delta can be written next to its source inside a wider feature tensor). ---- */
+int svt_deltas(const float* x_dev, int64_t ldx, int32_t batch, int32_t t, int32_t c, int32_t window_length, float* out_dev,
+               int64_t ldo, int device, void* stream);
+int svt_context_window(const float* x_dev, int32_t batch, int32_t t, int32_t c, int32_t left_frames, int32_t right_frames,
+                       float* out_dev, int device, void* stream);
+
 /* ---- validation losses: replace speechbrain.nnet.losses.bce_loss / nll_loss (losses.py:402-519) over
  * compute_masked_loss (:624-684), truncate (:594-621) and length_to_mask (dataio/dataio.py:661-706); forward only ----
  * logits (B,t_pred) f32, targets (B,t_tgt) f32; the longer of the two is truncated when |t_pred - t_tgt| <=

@@ -468,3 +468,27 @@ def avhubert_video_forward(sd: Dict[str, torch.Tensor], cfg, video: torch.Tensor
         if nk is not None:
             hf[nk] = v
     return encoder_tail(hf, cfg, feats, output_norm)
+
+
+# ---- Fbank add-ons (speechbrain/processing/features.py:788-850, 853-940), pinned by tests/golden/fbank_ext.pt ----
+def deltas(x: torch.Tensor, window_length: int = 5) -> torch.Tensor:
+    """(B,T,C) -> time derivative with replicate padding: sum_k k x[t+k] / (n(n+1)(2n+1)/3)."""
+    n = (window_length - 1) // 2
+    denom = n * (n + 1) * (2 * n + 1) / 3
+    xt = F.pad(x.float().transpose(1, 2), (n, n), mode="replicate")
+    k = torch.arange(-n, n + 1, dtype=torch.float32).repeat(x.shape[-1], 1, 1)
+    return (F.conv1d(xt, k, groups=x.shape[-1]) / denom).transpose(1, 2)
+
+
+def context_window(x: torch.Tensor, left_frames: int = 5, right_frames: int = 5) -> torch.Tensor:
+    """(B,T,C) -> (B,T,C*(left+right+1)), column c*ctx + j = x[t + j + lag - pad, c], zeros outside."""
+    B, T, C = x.shape
+    ctx, pad = left_frames + right_frames + 1, max(left_frames, right_frames)
+    lag = max(right_frames - left_frames, 0)
+    out = torch.zeros(B, T, C, ctx)
+    for j in range(ctx):
+        off = j + lag - pad
+        lo, hi = max(0, -off), min(T, T - off)
+        if hi > lo:
+            out[:, lo:hi, :, j] = x[:, lo + off:hi + off, :]
+    return out.reshape(B, T, C * ctx)

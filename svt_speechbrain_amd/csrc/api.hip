@@ -1412,6 +1412,30 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   return SVT_OK;
 }
 
+// ---- Fbank add-ons ----
+int svt_deltas(const float* x, int64_t ldx, int32_t batch, int32_t t, int32_t c, int32_t window_length, float* out, int64_t ldo,
+               int device, void* stream) {
+  if (!x || !out) { set_error("svt_deltas: null argument"); return SVT_ERR_INVALID; }
+  if (batch < 1 || t < 1 || c < 1 || window_length < 3 || ldx < c || ldo < c) { set_error("svt_deltas: bad geometry"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  const int n = (window_length - 1) / 2;
+  const float denom = (float)(n * (n + 1) * (2 * n + 1)) / 3.0f;
+  if (launch_deltas(x, ldx, batch, t, c, n, 1.0f / denom, out, ldo, (hipStream_t)stream)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+int svt_context_window(const float* x, int32_t batch, int32_t t, int32_t c, int32_t left_frames, int32_t right_frames, float* out,
+                       int device, void* stream) {
+  if (!x || !out) { set_error("svt_context_window: null argument"); return SVT_ERR_INVALID; }
+  if (batch < 1 || t < 1 || c < 1 || left_frames < 0 || right_frames < 0) { set_error("svt_context_window: bad geometry"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  const int ctx = left_frames + right_frames + 1, pad = left_frames > right_frames ? left_frames : right_frames;
+  const int lag = right_frames > left_frames ? right_frames - left_frames : 0;
+  if (launch_context_window(x, batch, t, c, ctx, lag, pad, out, (hipStream_t)stream)) return SVT_ERR_HIP;
+  return SVT_OK;
+}
+
 // ---- validation losses ----
 static int loss_common_checks(const char* who, int64_t batch, int64_t t_pred, int64_t t_tgt, int32_t allowed, int32_t reduction,
                               size_t ws_bytes, int64_t* T) {

@@ -226,6 +226,9 @@ int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* 
 bool outproj_ln_eligible(int D, int K);
 int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias, const void* rh, const void* rl, int M, int K,
                       const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yF, hipStream_t s);
+// Fbank add-ons: time derivatives and context window
+int launch_deltas(const float* x, long ldx, int B, int T, int C, int n, float inv_denom, float* out, long ldo, hipStream_t s);
+int launch_context_window(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out, hipStream_t s);
 // lip front-end (video.hip)
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,

@@ -774,6 +774,40 @@ __global__ void softmax_small_kernel(const float* x, int64_t rows, int n, int ap
   for (int i = 0; i < n; ++i) y[r * n + i] = apply_log ? (xr[i] - mx) - ls : expf(xr[i] - mx) / s;
 }
 
+// Fbank add-ons (speechbrain/processing/features.py: Deltas :788-850, ContextWindow :853-940).
+// delta[b,t,c] = sum_{k=-n..n} k * x[b, clamp(t+k), c] / denom   (replicate padding), x and out (B,T,ld) with column offsets
+__global__ void deltas_kernel(const float* x, long ldx, int B, int T, int C, int n, float inv_denom, float* out, long ldo) {
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    float acc = 0.f;
+    for (int k = -n; k <= n; ++k) {
+      int tt = t + k;
+      tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+      acc = fmaf((float)k, x[(b * T + tt) * ldx + c], acc);
+    }
+    out[(b * T + t) * ldo + c] = acc * inv_denom;
+  }
+}
+// out[b,t,c*ctx + j] = x[b, t + j - left', c] with zero padding, where the kernel is eye(ctx, klen) rolled by
+// max(right - left, 0): tap j reads offset j + lag - pad, pad = max(left, right)
+__global__ void context_window_kernel(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out) {
+  const long total = (long)B * T * C * ctx;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % ctx);
+    long r = i / ctx;
+    const int c = (int)(r % C);
+    r /= C;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    const int tt = t + j + lag - pad;
+    out[i] = (tt >= 0 && tt < T) ? x[(b * T + tt) * C + c] : 0.f;
+  }
+}
+
 __global__ void decode_frames_kernel(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls,
                                      FrameOut* out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1185,6 +1219,17 @@ int launch_loss_reduce(const double* sums, int B, int reduction, float smoothing
 }
 int launch_softmax_small(const float* x, int64_t rows, int n, int apply_log, float* y, hipStream_t s) {
   hipLaunchKernelGGL(softmax_small_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, rows, n, apply_log, y);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_deltas(const float* x, long ldx, int B, int T, int C, int n, float inv_denom, float* out, long ldo, hipStream_t s) {
+  hipLaunchKernelGGL(deltas_kernel, dim3(grid_for((int64_t)B * T * C)), dim3(256), 0, s, x, ldx, B, T, C, n, inv_denom, out, ldo);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_context_window(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(context_window_kernel, dim3(grid_for((int64_t)B * T * C * ctx)), dim3(256), 0, s, x, B, T, C, ctx, lag, pad, out);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -2,7 +2,8 @@
 ``speechbrain/lobes/features.py:18-143``: STFT -> power -> 40 triangular mel filters -> dB -> top_db clip).
 Named by the north star although no AMT recipe calls it.  On MI355X the STFT is a
 dense fp32 contraction with a (2*208, 400) DFT basis (``v_mfma_f32_16x16x4_f32``), the mel projection a
-second one; deltas / context windows are not built (``deltas=False, context=False`` is the default)."""
+second one; ``deltas=True`` appends first and second time derivatives (``Deltas``, features.py:788-850) and
+``context=True`` gathers ``left_frames`` / ``right_frames`` neighbours per frame (``ContextWindow``, :853-940)."""
 from __future__ import annotations
 
 import torch
@@ -16,8 +17,8 @@ class Fbank(nn.Module):
                  n_fft=400, n_mels=40, filter_shape="triangular", param_change_factor=1.0, param_rand_factor=0.0,
                  left_frames=5, right_frames=5, win_length=25, hop_length=10):
         super().__init__()
-        if deltas or context:
-            raise NotImplementedError("Fbank(deltas/context) is out of scope (SURVEY.md §2.2)")
+        self.deltas, self.context = bool(deltas), bool(context)
+        self.left_frames, self.right_frames = int(left_frames), int(right_frames)
         if filter_shape != "triangular" or requires_grad:
             raise NotImplementedError("only frozen triangular filters are built")
         self.sample_rate = sample_rate
@@ -43,4 +44,19 @@ class Fbank(nn.Module):
         _lib.check(lib.svt_fbank(_lib.ptr(x), B, L, self.sample_rate, self.n_fft, self.win, self.hop, self.n_mels,
                                  self.f_min, self.f_max, self.top_db, _lib.ptr(out), _lib.ptr(self._ws),
                                  self._ws.numel(), _lib.dev_index(x.device), _lib.stream_ptr(x.device)), "svt_fbank")
+        if self.deltas:   # [fbank, delta, delta-delta] side by side (lobes/features.py:137-140)
+            C0 = self.n_mels
+            cat = torch.empty((B, nf, 3 * C0), dtype=torch.float32, device=x.device)
+            cat[:, :, :C0] = out
+            for k in (1, 2):
+                _lib.check(lib.svt_deltas(_lib.ptr(cat) + 4 * (k - 1) * C0, 3 * C0, B, nf, C0, 5, _lib.ptr(cat) + 4 * k * C0, 3 * C0,
+                                          _lib.dev_index(x.device), _lib.stream_ptr(x.device)), "svt_deltas")
+            out = cat
+        if self.context:
+            C1 = out.shape[-1]
+            ctx = self.left_frames + self.right_frames + 1
+            cw = torch.empty((B, nf, C1 * ctx), dtype=torch.float32, device=x.device)
+            _lib.check(lib.svt_context_window(_lib.ptr(out), B, nf, C1, self.left_frames, self.right_frames, _lib.ptr(cw),
+                                              _lib.dev_index(x.device), _lib.stream_ptr(x.device)), "svt_context_window")
+            out = cw
         return out

@@ -398,6 +398,27 @@ def make_dataio_cases():
     print("dataio", [c["valid"].tolist() for c in out["pad"]])
 
 
+def make_fbank_ext_cases():
+    """speechbrain.processing.features.Deltas / ContextWindow forward methods.  Deltas.__init__ moves its kernel to CUDA
+    (features.py:812-816), so the object is built without __init__ and given the same attributes on the CPU."""
+    from speechbrain.processing.features import Deltas, ContextWindow
+    g = torch.Generator().manual_seed(61)
+    out = {"deltas": [], "context": []}
+    for B, T, C in [(2, 101, 40), (1, 3, 5), (3, 17, 120)]:
+        x = torch.randn(B, T, C, generator=g)
+        d = Deltas.__new__(Deltas)
+        torch.nn.Module.__init__(d)
+        d.n = 2
+        d.denom = d.n * (d.n + 1) * (2 * d.n + 1) / 3
+        d.register_buffer("kernel", torch.arange(-d.n, d.n + 1, dtype=torch.float32).repeat(C, 1, 1))
+        out["deltas"].append(dict(x=x, expect=d(x)))
+    for (B, T, C), (l, r) in [((2, 50, 8), (5, 5)), ((1, 9, 3), (2, 4)), ((2, 20, 6), (3, 0)), ((1, 4, 2), (5, 5))]:
+        x = torch.randn(B, T, C, generator=g)
+        out["context"].append(dict(x=x, left=l, right=r, expect=ContextWindow(left_frames=l, right_frames=r)(x)))
+    torch.save(out, os.path.join(HERE, "fbank_ext.pt"))
+    print("fbank_ext", [tuple(c["expect"].shape) for c in out["context"]])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -422,6 +443,7 @@ def main():
         "losses": make_loss_cases,
         "video_front": make_video_front_cases,
         "dataio": make_dataio_cases,
+        "fbank_ext": make_fbank_ext_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),
     }
     for k, fn in jobs.items():

@@ -351,3 +351,32 @@ def test_two_streams_bitwise_identical_to_one():
     torch.cuda.synchronize()
     for i, o in outs:
         assert torch.equal(o, ref[i]), "overlapped step differs from the single-stream result"
+
+
+def test_fbank_deltas_and_context_vs_reference_golden(golden):
+    """Fbank(deltas=True, context=True) pieces: svt_deltas / svt_context_window against the reference's Deltas / ContextWindow
+    forward outputs, and the assembled lobe against the oracle chain."""
+    from svt_speechbrain_amd import _lib
+    lib = _lib.load()
+    fx = golden("fbank_ext")
+    st = torch.cuda.current_stream().cuda_stream
+    for c in fx["deltas"]:
+        x = c["x"].to(DEV).contiguous()
+        B, T, Cc = x.shape
+        out = torch.empty_like(x)
+        _lib.check(lib.svt_deltas(x.data_ptr(), Cc, B, T, Cc, 5, out.data_ptr(), Cc, 0, st), "svt_deltas")
+        assert (out.cpu() - c["expect"]).abs().max() < 1e-6
+    for c in fx["context"]:
+        x = c["x"].to(DEV).contiguous()
+        B, T, Cc = x.shape
+        ctx = c["left"] + c["right"] + 1
+        out = torch.empty(B, T, Cc * ctx, device=DEV)
+        _lib.check(lib.svt_context_window(x.data_ptr(), B, T, Cc, c["left"], c["right"], out.data_ptr(), 0, st), "svt_context_window")
+        assert torch.equal(out.cpu(), c["expect"])
+    wav = synth_wav(2, 16000, 77)
+    fb = S.Fbank(deltas=True, context=True, left_frames=3, right_frames=2).to(DEV)(wav.to(DEV)).cpu()
+    base = O.fbank(wav)
+    d1 = O.deltas(base)
+    want = O.context_window(torch.cat([base, d1, O.deltas(d1)], dim=2), 3, 2)
+    assert fb.shape == want.shape == (2, 101, 120 * 6)
+    assert (fb - want).abs().max() < 5e-3   # dB scale, same bound as the plain Fbank test

@@ -150,3 +150,12 @@ def test_oracle_video_frontend_matches_reference_golden(golden, name):
         y = O.video_frontend_forward(sd, video)
     assert y.shape == fx["feats"].shape
     assert (y - fx["feats"]).abs().max() < 2e-5 * (1 + fx["feats"].abs().max())
+
+
+def test_oracle_fbank_deltas_and_context_match_reference_golden(golden):
+    fx = golden("fbank_ext")
+    for c in fx["deltas"]:
+        assert (O.deltas(c["x"]) - c["expect"]).abs().max() < 1e-6
+    for c in fx["context"]:
+        got = O.context_window(c["x"], c["left"], c["right"])
+        assert got.shape == c["expect"].shape and torch.equal(got, c["expect"])
