@@ -116,8 +116,8 @@ def main():
         wav = synth_wav(B, L).to(dev)
 
     ns = max(1, args.streams)
-    encs = [S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, seed=1986).to(dev) for _ in range(ns)]
-    enc = encs[0]
+    enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, seed=1986).to(dev)
+    encs = [enc] + [enc.replica() for _ in range(ns - 1)]  # same parameters, own device handle + workspace per stream
     head = S.Linear(20, input_size=cfg.hidden_size)
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=2986)
     head.load_state_dict(hd)

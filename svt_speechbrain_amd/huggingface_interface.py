@@ -254,6 +254,17 @@ class HuggingFaceWav2Vec2(nn.Module):
         except Exception:
             pass
 
+    def replica(self):
+        """A second encoder object over the SAME parameter tensors with its own device handle and workspace: what a caller
+        needs to keep two forwards in flight on two HIP streams (bench.py, SongTranscriber)."""
+        import copy
+        c = copy.copy(self)
+        c._handle = None
+        c._handle_dev = None
+        c._sig = None
+        c._ws = None
+        return c
+
     def num_frames(self, n_samples: int) -> int:
         return self.config.frames(n_samples)
 

@@ -38,26 +38,48 @@ class SongTranscriber:
 
     def __init__(self, encoder, head, pitch_octave_num: int = 4, pitch_class_num: int = 12, onset_threshold: float = 0.4,
                  offset_threshold: float = 0.5, frame_rate: float = 49.8, sample_rate: int = 16000,
-                 dur_threshold: float = 5.0):
+                 dur_threshold: float = 5.0, streams: int = 2):
         self.encoder, self.head = encoder, head
         self.pitch_octave_num, self.pitch_class_num = pitch_octave_num, pitch_class_num
         self.onset_threshold, self.offset_threshold = onset_threshold, offset_threshold
         self.frame_rate, self.sample_rate, self.dur_threshold = frame_rate, sample_rate, dur_threshold
+        # Utterances are forwarded one at a time (batch 1, as the reference's eval asserts: the whole-batch norms would
+        # couple the clips of a larger batch), but they are independent of each other: successive utterances go round-robin
+        # to `streams` HIP streams, each with its own copy of the encoder object (device handle + workspace), and the frames
+        # of the whole song are decoded by ONE kernel + ONE device-to-host copy at the end.
+        self.streams = max(1, int(streams))
+        self._encoders = None
+        self._side = None
+
+    def _lanes(self, device):
+        if self._encoders is None:
+            if self.streams > 1 and not hasattr(self.encoder, "replica"):
+                self.streams = 1  # a foreign encoder module: no second device object to run concurrently
+            self._encoders = [self.encoder] + [self.encoder.replica() for _ in range(self.streams - 1)]
+            self._side = [torch.cuda.Stream(device=device) for _ in range(self.streams - 1)]
+        return self._encoders, [torch.cuda.current_stream(device)] + self._side
 
     @torch.no_grad()
     def transcribe(self, song: torch.Tensor, return_feats: bool = False):
         """song: 1-D waveform on the GPU.  Returns notes [[on_s, off_s, midi], ...] (and the (T_song, D) features)."""
         if song.dim() != 1:
             raise ValueError("expected a mono 1-D waveform")
-        pred: list = []
-        feats_all = []
-        for lo, hi in utterance_bounds(song.shape[0], self.sample_rate, self.dur_threshold):
-            feats = self.encoder(song[lo:hi].unsqueeze(0))  # batch of one utterance, as in the reference eval
-            logits = self.head(feats)
-            pred.extend(frames_to_info(decode_frames(logits[0], self.pitch_octave_num, self.pitch_class_num)))
-            if return_feats:
-                feats_all.append(feats[0])
-        notes = frame2note(pred, self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
+        encs, lanes = self._lanes(song.device)
+        main = lanes[0]
+        for st in lanes[1:]:
+            st.wait_stream(main)
+        logits_all, feats_all = [], []
+        for i, (lo, hi) in enumerate(utterance_bounds(song.shape[0], self.sample_rate, self.dur_threshold)):
+            k = i % len(lanes)
+            with torch.cuda.stream(lanes[k]):
+                feats = encs[k](song[lo:hi].unsqueeze(0))  # batch of one utterance, as in the reference eval
+                logits_all.append(self.head(feats)[0])
+                if return_feats:
+                    feats_all.append(feats[0])
+        for st in lanes[1:]:
+            main.wait_stream(st)
+        frames = decode_frames(torch.cat(logits_all, dim=0), self.pitch_octave_num, self.pitch_class_num)
+        notes = frame2note(frames_to_info(frames), self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
         if return_feats:
             return notes, torch.cat(feats_all, dim=0)
         return notes
