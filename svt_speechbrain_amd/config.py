@@ -77,6 +77,19 @@ PRESETS = {
         name="hubert-large-ll60k", family="hubert", hidden_size=1024, num_hidden_layers=24,
         num_attention_heads=16, intermediate_size=4096, feat_extract_norm="layer", conv_bias=True,
         do_stable_layer_norm=True, feat_proj_layer_norm=True),
+    # Other public checkpoints the reference's `source` argument commonly names.  Their geometry is restated from the public
+    # HF config.json files, which cannot be fetched offline: a local checkpoint directory's own config.json always wins
+    # (huggingface_interface._config_from_dir).
+    "hubert-base-ls960": EncoderConfig(
+        name="hubert-base-ls960", family="hubert", hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+        intermediate_size=3072, feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False,
+        feat_proj_layer_norm=False),
+    "hubert-xlarge-ll60k": EncoderConfig(
+        name="hubert-xlarge-ll60k", family="hubert", hidden_size=1280, num_hidden_layers=48, num_attention_heads=16,
+        intermediate_size=5120, feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True, feat_proj_layer_norm=True),
+    "wav2vec2-large": EncoderConfig(
+        name="wav2vec2-large", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+        feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False),
     # Small configurations for golden fixtures / fast parity tests (SURVEY.md §8c "tiny config").
     "tiny-group": EncoderConfig(
         name="tiny-group", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
@@ -116,11 +129,21 @@ def config_from_source(source: str) -> EncoderConfig:
     if key in PRESETS:
         return PRESETS[key]
     low = source.lower()
+    if "avhubert" in low or "av_hubert" in low:
+        return PRESETS["avhubert-base-video" if "base" in low else "avhubert-large-video"]
     if "hubert" in low:
-        return PRESETS["hubert-large-ll60k"]
+        if "xlarge" in low:
+            return PRESETS["hubert-xlarge-ll60k"]
+        return PRESETS["hubert-base-ls960"] if "base" in low else PRESETS["hubert-large-ll60k"]
     if "data2vec" in low or "wavlm" in low:
         raise NotImplementedError(
             f"{source}: data2vec/WavLM encoders are out of scope for the MI355X path (SURVEY.md §8 note iii)")
     if "wav2vec2" in low:
-        return PRESETS["wav2vec2-large-lv60"] if "large" in low else PRESETS["wav2vec2-base"]
+        if "large" not in low and "xls" not in low:
+            return PRESETS["wav2vec2-base"]
+        # the LibriLight / multilingual large models (lv60, xlsr, xls-r, robust) use the layer-norm conv stack and the pre-LN
+        # encoder; the LibriSpeech-only "wav2vec2-large" / "-large-960h" keep the base layout at large width
+        if any(t in low for t in ("lv60", "xls", "robust", "voxpopuli")):
+            return PRESETS["wav2vec2-large-lv60"]
+        return PRESETS["wav2vec2-large"]
     raise ValueError(f"cannot infer an encoder family from source={source!r}")

@@ -380,3 +380,20 @@ def test_fbank_deltas_and_context_vs_reference_golden(golden):
     want = O.context_window(torch.cat([base, d1, O.deltas(d1)], dim=2), 3, 2)
     assert fb.shape == want.shape == (2, 101, 120 * 6)
     assert (fb - want).abs().max() < 5e-3   # dB scale, same bound as the plain Fbank test
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.6)])
+def test_hubert_base_layout_vs_oracle(prec, tol):
+    """HuBERT-base geometry class (GroupNorm conv stack, post-LN encoder, NO feature-projection LayerNorm — the
+    `hubert-base-ls960` preset) at tiny width, against the oracle (no reference golden for this combination)."""
+    import dataclasses
+    cfg = dataclasses.replace(PRESETS["tiny-group"], name="tiny-hubert-base", family="hubert", feat_proj_layer_norm=False)
+    sd = W.seeded_encoder_state_dict(cfg, seed=77)
+    assert "feature_projection.layer_norm.weight" not in sd
+    enc = S.HuggingFaceWav2Vec2("tiny-hubert-base", None, config=cfg, precision=prec, seed=77).to(DEV)
+    wav = synth_wav(2, 6000, 78)
+    out = enc(wav.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = O.encoder_forward(sd, cfg, wav)
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max() < tol

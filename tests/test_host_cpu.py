@@ -290,3 +290,21 @@ def test_transcription_scores_hand_derived():
     with pytest.raises(ValueError):
         SC.score_song([[1.0, 1.0, 60]], refs)
     assert SC.midi_to_hz(69) == pytest.approx(440.0) and SC.midi_to_hz(57) == pytest.approx(220.0)
+
+
+def test_config_from_source_family_heuristics():
+    c = config_from_source
+    assert c("facebook/wav2vec2-base").name == "wav2vec2-base" and c("facebook/wav2vec2-base-960h").hidden_size == 768
+    assert c("facebook/wav2vec2-large-lv60").do_stable_layer_norm and c("facebook/wav2vec2-large-xlsr-53").feat_extract_norm == "layer"
+    assert c("facebook/wav2vec2-large-960h").feat_extract_norm == "group" and not c("facebook/wav2vec2-large").do_stable_layer_norm
+    assert c("facebook/hubert-large-ll60k").num_hidden_layers == 24 and c("facebook/hubert-base-ls960").num_hidden_layers == 12
+    assert c("facebook/hubert-xlarge-ll60k").hidden_size == 1280
+    assert c("ssl_model/AVHuBERT/large_vox_iter5.pt".replace("AVHuBERT", "avhubert")).family == "avhubert"
+    with pytest.raises(NotImplementedError):
+        c("microsoft/wavlm-large")
+    with pytest.raises(ValueError):
+        c("my-model")
+    # every preset's parameter schema is self-consistent (head_dim, group sizes)
+    for name, cfg in PRESETS.items():
+        assert cfg.hidden_size % cfg.num_attention_heads == 0 and cfg.hidden_size % cfg.num_conv_pos_embedding_groups == 0, name
+        assert len(W.encoder_param_shapes(cfg)) > 0
