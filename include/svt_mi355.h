@@ -71,6 +71,8 @@ typedef struct svt_encoder_config {
   int32_t normalize_wav;        /* wrapper: F.layer_norm(wav, wav.shape) */
   int32_t output_norm;          /* wrapper: F.layer_norm(out, out.shape) */
   int32_t precision;            /* svt_precision: operand type of the MFMA contractions */
+  int32_t pos_conv_depth;       /* 1: one weight-normed positional conv + GELU (wav2vec2 / HuBERT); n > 1: data2vec-audio's stack of
+                                 * n plain grouped convs, each followed by LayerNorm(no affine) + GELU */
 } svt_encoder_config;
 
 typedef struct svt_encoder svt_encoder;

@@ -113,11 +113,23 @@ def encoder_tail(sd: Dict[str, torch.Tensor], cfg, h: torch.Tensor, output_norm:
     # positional conv embedding (HF:326-379)
     D = cfg.hidden_size
     kp, g = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
-    w = _posconv_weight(sd, prefix)
-    pos = F.conv1d(h.transpose(1, 2), w, sd[prefix + "encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=g)
-    if kp % 2 == 0:
-        pos = pos[:, :, :-1]
-    pos = F.gelu(pos).transpose(1, 2)
+    if getattr(cfg, "pos_conv_depth", 1) > 1:
+        # data2vec-audio (HF modeling_data2vec_audio.py, Data2VecAudioPositionalConvEmbedding): a stack of plain grouped convs,
+        # each followed by LayerNorm over channels without affine parameters (eps 1e-5) and GELU
+        pos = h.transpose(1, 2)
+        for i in range(cfg.pos_conv_depth):
+            pl = prefix + f"encoder.pos_conv_embed.layers.{i}.conv."
+            pos = F.conv1d(pos, sd[pl + "weight"], sd[pl + "bias"], padding=kp // 2, groups=g)
+            if kp % 2 == 0:
+                pos = pos[:, :, :-1]
+            pos = F.gelu(F.layer_norm(pos.transpose(1, 2), (D,), None, None, 1e-5)).transpose(1, 2)
+        pos = pos.transpose(1, 2)
+    else:
+        w = _posconv_weight(sd, prefix)
+        pos = F.conv1d(h.transpose(1, 2), w, sd[prefix + "encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=g)
+        if kp % 2 == 0:
+            pos = pos[:, :, :-1]
+        pos = F.gelu(pos).transpose(1, 2)
     h = h + pos
     if taps is not None:
         taps["pos"] = h.clone()

@@ -40,6 +40,7 @@ class EncoderConfigC(C.Structure):
         ("normalize_wav", C.c_int32),
         ("output_norm", C.c_int32),
         ("precision", C.c_int32),
+        ("pos_conv_depth", C.c_int32),
     ]
 
 

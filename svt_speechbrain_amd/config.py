@@ -15,7 +15,7 @@ from typing import Tuple
 @dataclasses.dataclass(frozen=True)
 class EncoderConfig:
     name: str = "wav2vec2-base"
-    family: str = "wav2vec2"  # "wav2vec2" | "hubert" (selects the HF key layout only)
+    family: str = "wav2vec2"  # "wav2vec2" | "hubert" | "data2vec" | "avhubert" (selects the key layout only)
     hidden_size: int = 768
     num_hidden_layers: int = 12
     num_attention_heads: int = 12
@@ -30,6 +30,9 @@ class EncoderConfig:
     num_conv_pos_embeddings: int = 128
     num_conv_pos_embedding_groups: int = 16
     layer_norm_eps: float = 1e-5
+    # data2vec-audio: a STACK of `pos_conv_depth` positional conv layers (kernel num_conv_pos_embeddings, no weight norm), each
+    # followed by LayerNorm(no affine) + GELU (HF modeling_data2vec_audio.py Data2VecAudioPositionalConvLayer); 1 = wav2vec2 / HuBERT
+    pos_conv_depth: int = 1
 
     @property
     def head_dim(self) -> int:
@@ -61,7 +64,7 @@ class EncoderConfig:
         T = ts[-1]
         D, F = self.hidden_size, self.intermediate_size
         fl += 2.0 * T * cin * D  # feature projection
-        fl += 2.0 * T * D * (D // self.num_conv_pos_embedding_groups) * self.num_conv_pos_embeddings
+        fl += 2.0 * T * D * (D // self.num_conv_pos_embedding_groups) * self.num_conv_pos_embeddings * self.pos_conv_depth
         per_layer = 4 * 2.0 * T * D * D + 2 * 2.0 * T * T * D + 2 * 2.0 * T * D * F
         fl += self.num_hidden_layers * per_layer
         fl += 2.0 * T * D * head_out
@@ -90,6 +93,18 @@ PRESETS = {
     "wav2vec2-large": EncoderConfig(
         name="wav2vec2-large", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
         feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False),
+    "data2vec-audio-base": EncoderConfig(
+        name="data2vec-audio-base", family="data2vec", hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+        intermediate_size=3072, feat_extract_norm="layer", conv_bias=False, do_stable_layer_norm=False,
+        num_conv_pos_embeddings=19, pos_conv_depth=5),
+    "data2vec-audio-large": EncoderConfig(
+        name="data2vec-audio-large", family="data2vec", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+        intermediate_size=4096, feat_extract_norm="layer", conv_bias=False, do_stable_layer_norm=False,
+        num_conv_pos_embeddings=19, pos_conv_depth=5),
+    "tiny-data2vec": EncoderConfig(
+        name="tiny-data2vec", family="data2vec", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, feat_extract_norm="layer", conv_bias=False, num_conv_pos_embeddings=5,
+        num_conv_pos_embedding_groups=4, pos_conv_depth=3),
     # Small configurations for golden fixtures / fast parity tests (SURVEY.md §8c "tiny config").
     "tiny-group": EncoderConfig(
         name="tiny-group", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
@@ -135,9 +150,11 @@ def config_from_source(source: str) -> EncoderConfig:
         if "xlarge" in low:
             return PRESETS["hubert-xlarge-ll60k"]
         return PRESETS["hubert-base-ls960"] if "base" in low else PRESETS["hubert-large-ll60k"]
-    if "data2vec" in low or "wavlm" in low:
+    if "data2vec" in low:
+        return PRESETS["data2vec-audio-large" if "large" in low else "data2vec-audio-base"]
+    if "wavlm" in low:
         raise NotImplementedError(
-            f"{source}: data2vec/WavLM encoders are out of scope for the MI355X path (SURVEY.md §8 note iii)")
+            f"{source}: WavLM (gated relative position bias in the attention) is out of scope for the MI355X path (SURVEY.md §8 note iii)")
     if "wav2vec2" in low:
         if "large" not in low and "xls" not in low:
             return PRESETS["wav2vec2-base"]

@@ -211,6 +211,8 @@ struct svt_encoder {
   DevBuf fp_g, fp_b, proj_w, proj_b, pos_w, pos_b, enc_g, enc_b;
   DevBuf pos_wP, pos_bP;   // multi-frame form of the positional conv (bf16 mode): P frames per GEMM row
   int pos_P = 0;
+  std::vector<DevBuf> pos_ws, pos_bs;   // data2vec-audio: one plain grouped conv per stacked positional layer
+  DevBuf ones, zeros;                   // LayerNorm without affine parameters
   std::vector<EncLayerW> layers;
 };
 
@@ -236,6 +238,7 @@ static int validate_cfg(const svt_encoder_config& c) {
   if (c.intermediate_size % 8 || c.hidden_size % 8) { set_error("sizes must be multiples of 8"); return SVT_ERR_INVALID; }
   if (c.feat_extract_norm != SVT_NORM_GROUP && c.feat_extract_norm != SVT_NORM_LAYER) { set_error("feat_extract_norm"); return SVT_ERR_INVALID; }
   if (c.precision != SVT_PREC_FP32 && c.precision != SVT_PREC_BF16) { set_error("precision"); return SVT_ERR_INVALID; }
+  if (c.pos_conv_depth < 1 || c.pos_conv_depth > 16) { set_error("pos_conv_depth must be 1..16"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
 
@@ -422,6 +425,28 @@ int svt_encoder_finalize(svt_encoder* e) {
   if (int r = need(P, "feature_projection.projection.bias", {D}, &p)) return r;
   if (int r = upload_f32(e->proj_b, p->v.data(), p->v.size())) return r;
 
+  if (c.pos_conv_depth > 1) {
+    // data2vec-audio: plain grouped convs "encoder.pos_conv_embed.layers.<i>.conv.{weight,bias}", (D, cg, kp) -> per group
+    // (cg_out, kp*cg_in) tap-major like the single-layer form
+    const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
+    e->pos_ws.clear(); e->pos_bs.clear();
+    e->pos_ws.resize(c.pos_conv_depth); e->pos_bs.resize(c.pos_conv_depth);
+    for (int i = 0; i < c.pos_conv_depth; ++i) {
+      const std::string pl = "encoder.pos_conv_embed.layers." + std::to_string(i) + ".conv.";
+      if (int r = need(P, pl + "weight", {D, cg, kp}, &p)) return r;
+      std::vector<float> wt(p->v.size());
+      for (int o = 0; o < D; ++o)
+        for (int ci = 0; ci < cg; ++ci)
+          for (int j = 0; j < kp; ++j) wt[((size_t)o * kp + j) * cg + ci] = p->v[((size_t)o * cg + ci) * kp + j];
+      if (int r = upload_operand(prec, e->pos_ws[i], wt.data(), wt.size())) return r;
+      if (int r = need(P, pl + "bias", {D}, &p)) return r;
+      if (int r = upload_f32(e->pos_bs[i], p->v.data(), p->v.size())) return r;
+    }
+    std::vector<float> one((size_t)D, 1.f), zero((size_t)D, 0.f);
+    if (int r = upload_f32(e->ones, one.data(), one.size())) return r;
+    if (int r = upload_f32(e->zeros, zero.data(), zero.size())) return r;
+    e->pos_P = 0;
+  } else
   // positional conv: fold weight-norm (dim=2): W[:,:,j] = g[j] v[:,:,j] / ||v[:,:,j]||_F ; accept both spellings
   {
     const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
@@ -703,7 +728,29 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   {
     const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
     const int Pf = e->pos_P;
-    if (Pf && (int64_t)B * ((T + Pf - 1) / Pf) >= 128) {
+    if (c.pos_conv_depth > 1) {
+      // data2vec-audio: pos = stack of [grouped conv -> LayerNorm(no affine, eps 1e-5) -> GELU]; pre = h + pos
+      const float* cur = w.hF;
+      float* lnout = w.xF;  // fp32 scratch (rows x D): free until the encoder's first LayerNorm
+      for (int i = 0; i < c.pos_conv_depth; ++i) {
+        if (int r = launch_posconv_gather(prec, cur, B, (int)T, D, G, kp, (int)T + kp, w.posg, s)) return r;
+        GemmArgs g;
+        g.A = w.posg; g.W = e->pos_ws[i].p; g.C = w.preF; g.bias = e->pos_bs[i].as<float>();
+        g.M = (int)T; g.N = cg; g.K = kp * cg;
+        g.a_rpb = (int)T; g.a_rstride = cg;
+        g.ldw = g.K; g.ldc = D;
+        g.nz = B * G; g.nz2 = G;
+        g.a_z1 = (long)G * (T + kp) * cg; g.a_z2 = (long)(T + kp) * cg;
+        g.w_z1 = 0; g.w_z2 = (long)cg * g.K;
+        g.c_z1 = (long)T * D; g.c_z2 = cg; g.bias_z2 = cg;
+        g.act = ACT_NONE; g.out_f32 = 1;
+        if (int r = launch_gemm(prec, g, s)) return r;
+        if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->ones.as<float>(), e->zeros.as<float>(), 1e-5f, 1, nullptr,
+                                     lnout, s)) return r;
+        cur = lnout;
+      }
+      if (int r = launch_add_f32(w.hF, cur, w.preF, rows * (int64_t)D, s)) return r;
+    } else if (Pf && (int64_t)B * ((T + Pf - 1) / Pf) >= 128) {
       const int Tq = (int)((T + Pf - 1) / Pf), Tp = Tq * Pf + kp;
       if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, Tp, w.posg, s)) return r;
       GemmArgs g;

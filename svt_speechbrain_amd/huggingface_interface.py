@@ -70,6 +70,7 @@ def _config_to_c(cfg: EncoderConfig, normalize_wav: bool, output_norm: bool, pre
     c.normalize_wav = int(normalize_wav)
     c.output_norm = int(output_norm)
     c.precision = PRECISIONS[precision]
+    c.pos_conv_depth = cfg.pos_conv_depth
     return c
 
 

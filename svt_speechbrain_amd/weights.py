@@ -43,12 +43,19 @@ def encoder_param_shapes(cfg: EncoderConfig, old_weight_norm_keys: bool = False)
     sh["feature_projection.projection.weight"] = (D, cin)
     sh["feature_projection.projection.bias"] = (D,)
     kp, g = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    if cfg.pos_conv_depth > 1:  # data2vec-audio: plain (no weight norm) grouped convs, one per stacked layer
+        for i in range(cfg.pos_conv_depth):
+            sh[f"encoder.pos_conv_embed.layers.{i}.conv.weight"] = (D, D // g, kp)
+            sh[f"encoder.pos_conv_embed.layers.{i}.conv.bias"] = (D,)
     pc = "encoder.pos_conv_embed.conv"
-    sh[f"{pc}.bias"] = (D,)
-    if old_weight_norm_keys:
+    if cfg.pos_conv_depth > 1:
+        pass
+    elif old_weight_norm_keys:
+        sh[f"{pc}.bias"] = (D,)
         sh[f"{pc}.weight_g"] = (1, 1, kp)
         sh[f"{pc}.weight_v"] = (D, D // g, kp)
     else:
+        sh[f"{pc}.bias"] = (D,)
         sh[f"{pc}.parametrizations.weight.original0"] = (1, 1, kp)
         sh[f"{pc}.parametrizations.weight.original1"] = (D, D // g, kp)
     sh["encoder.layer_norm.weight"] = (D,)

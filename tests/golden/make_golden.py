@@ -71,7 +71,12 @@ def hf_model(cfg):
               layer_norm_eps=cfg.layer_norm_eps, hidden_dropout=0.0, attention_dropout=0.0,
               activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, apply_spec_augment=False,
               attn_implementation="eager")
-    if cfg.family == "hubert":
+    if cfg.family == "data2vec":
+        from transformers import Data2VecAudioModel, Data2VecAudioConfig
+        kw.pop("do_stable_layer_norm"); kw.pop("feat_extract_norm"); kw.pop("num_conv_pos_embeddings")
+        m = Data2VecAudioModel(Data2VecAudioConfig(conv_pos_kernel_size=cfg.num_conv_pos_embeddings,
+                                                   num_conv_pos_embeddings=cfg.pos_conv_depth, **kw))
+    elif cfg.family == "hubert":
         hc = HubertConfig(feat_proj_layer_norm=cfg.feat_proj_layer_norm, **kw)
         m = HubertModel(hc)
     else:
@@ -437,6 +442,8 @@ def main():
         "large_c1": lambda: make_encoder_case(hi, utils, "large_c1", "wav2vec2-large-lv60", 1, 80000, 23, full=False),
         "hubert_large_c1": lambda: make_encoder_case(hi, utils, "hubert_large_c1", "hubert-large-ll60k", 1, 48000, 24,
                                                       full=False),
+        "tiny_data2vec": lambda: make_encoder_case(hi, utils, "tiny_data2vec", "tiny-data2vec", 2, 4000, 15),
+        "data2vec_base_c1": lambda: make_encoder_case(hi, utils, "data2vec_base_c1", "data2vec-audio-base", 1, 48000, 25, full=False),
         "fusion": lambda: make_fusion_cases(fusion_mod),
         "frame2note": lambda: make_frame2note_cases(utils),
         "ctc_fbank": make_ctc_fbank_cases,

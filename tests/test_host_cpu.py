@@ -63,7 +63,7 @@ def test_config_frames_and_flops():
 
 
 def test_state_dict_schema_matches_hf_keys():
-    for name in ["tiny-group", "tiny-layer", "tiny-hubert"]:
+    for name in ["tiny-group", "tiny-layer", "tiny-hubert", "tiny-data2vec"]:
         cfg = PRESETS[name]
         enc = S.HuggingFaceWav2Vec2(name, None, config=cfg)
         keys = list(enc.state_dict().keys())
@@ -300,6 +300,7 @@ def test_config_from_source_family_heuristics():
     assert c("facebook/hubert-large-ll60k").num_hidden_layers == 24 and c("facebook/hubert-base-ls960").num_hidden_layers == 12
     assert c("facebook/hubert-xlarge-ll60k").hidden_size == 1280
     assert c("ssl_model/AVHuBERT/large_vox_iter5.pt".replace("AVHuBERT", "avhubert")).family == "avhubert"
+    assert c("facebook/data2vec-audio-base-960h").pos_conv_depth == 5 and c("facebook/data2vec-audio-large").hidden_size == 1024
     with pytest.raises(NotImplementedError):
         c("microsoft/wavlm-large")
     with pytest.raises(ValueError):
