@@ -73,6 +73,8 @@ typedef struct svt_encoder_config {
   int32_t precision;            /* svt_precision: operand type of the MFMA contractions */
   int32_t pos_conv_depth;       /* 1: one weight-normed positional conv + GELU (wav2vec2 / HuBERT); n > 1: data2vec-audio's stack of
                                  * n plain grouped convs, each followed by LayerNorm(no affine) + GELU */
+  int32_t rel_pos_buckets;      /* 0: none; > 0: WavLM's gated relative position bias with this many buckets */
+  int32_t rel_pos_max_distance; /* WavLM max_bucket_distance */
 } svt_encoder_config;
 
 typedef struct svt_encoder svt_encoder;

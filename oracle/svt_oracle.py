@@ -75,14 +75,39 @@ def conv_feature_extractor(sd, cfg, x: torch.Tensor, prefix: str = "", taps: Opt
     return h
 
 
-def attention(sd, p: str, u: torch.Tensor, nheads: int) -> torch.Tensor:
-    """HF:466-548 eager path; no mask."""
+def wavlm_position_bias(table: torch.Tensor, T: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """HF modeling_wavlm.py WavLMAttention.compute_bias / _relative_positions_bucket: (H, T, T) bias from the (buckets, H)
+    embedding of the bucketed key - query distance (half of the buckets per sign, exact below max_exact, log-spaced above)."""
+    ctx = torch.arange(T, dtype=torch.long)[:, None]
+    mem = torch.arange(T, dtype=torch.long)[None, :]
+    rel = mem - ctx
+    nb = num_buckets // 2
+    bucket = (rel > 0).to(torch.long) * nb
+    rel = rel.abs()
+    max_exact = nb // 2
+    large = torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)
+    large = torch.min((max_exact + large).to(torch.long), torch.full_like(rel, nb - 1))
+    bucket = bucket + torch.where(rel < max_exact, rel, large)
+    return table[bucket].permute(2, 0, 1)
+
+
+def attention(sd, p: str, u: torch.Tensor, nheads: int, pos_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HF:466-548 eager path; no mask.  pos_bias (H,T,T): WavLM's relative position bias, gated per
+    (clip, head, query) by a projection of the attention input (modeling_wavlm.py WavLMAttention.forward)."""
     B, T, D = u.shape
     dh = D // nheads
     q = F.linear(u, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
     k = F.linear(u, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
     v = F.linear(u, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"]).view(B, T, nheads, dh).transpose(1, 2)
-    a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5), dim=-1)
+    scores = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
+    if pos_bias is not None:
+        gh = u.view(B, T, nheads, dh).permute(0, 2, 1, 3)
+        proj = F.linear(gh, sd[p + "gru_rel_pos_linear.weight"], sd[p + "gru_rel_pos_linear.bias"])
+        proj = proj.view(B, nheads, T, 2, 4).sum(-1)
+        gate_a, gate_b = torch.sigmoid(proj).chunk(2, dim=-1)
+        gate = gate_a * (gate_b * sd[p + "gru_rel_pos_const"] - 1.0) + 2.0          # (B, H, T, 1)
+        scores = scores + gate * pos_bias.unsqueeze(0)
+    a = torch.softmax(scores, dim=-1)
     o = torch.matmul(a, v).transpose(1, 2).reshape(B, T, D)
     return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
@@ -142,18 +167,22 @@ def encoder_tail(sd: Dict[str, torch.Tensor], cfg, h: torch.Tensor, output_norm:
         t = F.gelu(F.linear(t, sd[p + "intermediate_dense.weight"], sd[p + "intermediate_dense.bias"]))
         return F.linear(t, sd[p + "output_dense.weight"], sd[p + "output_dense.bias"])
 
+    pb = None
+    if getattr(cfg, "rel_pos_buckets", 0):
+        pb = wavlm_position_bias(sd[prefix + "encoder.layers.0.attention.rel_attn_embed.weight"], h.shape[1], cfg.rel_pos_buckets,
+                                 cfg.rel_pos_max_distance)
     if not cfg.do_stable_layer_norm:
         h = ln(h, "encoder.layer_norm")
         for l in range(cfg.num_hidden_layers):
             p = f"encoder.layers.{l}"
-            h = ln(h + attention(sd, prefix + p + ".attention.", h, nh), p + ".layer_norm")
+            h = ln(h + attention(sd, prefix + p + ".attention.", h, nh, pb), p + ".layer_norm")
             h = ln(h + ffn(h, prefix + p + ".feed_forward."), p + ".final_layer_norm")
             if taps is not None:
                 taps[f"layer{l}"] = h.clone()
     else:
         for l in range(cfg.num_hidden_layers):
             p = f"encoder.layers.{l}"
-            h = h + attention(sd, prefix + p + ".attention.", ln(h, p + ".layer_norm"), nh)
+            h = h + attention(sd, prefix + p + ".attention.", ln(h, p + ".layer_norm"), nh, pb)
             h = h + ffn(ln(h, p + ".final_layer_norm"), prefix + p + ".feed_forward.")
             if taps is not None:
                 taps[f"layer{l}"] = h.clone()

@@ -41,6 +41,8 @@ class EncoderConfigC(C.Structure):
         ("output_norm", C.c_int32),
         ("precision", C.c_int32),
         ("pos_conv_depth", C.c_int32),
+        ("rel_pos_buckets", C.c_int32),
+        ("rel_pos_max_distance", C.c_int32),
     ]
 
 

@@ -33,6 +33,9 @@ class EncoderConfig:
     # data2vec-audio: a STACK of `pos_conv_depth` positional conv layers (kernel num_conv_pos_embeddings, no weight norm), each
     # followed by LayerNorm(no affine) + GELU (HF modeling_data2vec_audio.py Data2VecAudioPositionalConvLayer); 1 = wav2vec2 / HuBERT
     pos_conv_depth: int = 1
+    # WavLM: gated relative position bias in every self-attention (HF modeling_wavlm.py WavLMAttention); 0 = none
+    rel_pos_buckets: int = 0
+    rel_pos_max_distance: int = 800
 
     @property
     def head_dim(self) -> int:
@@ -93,6 +96,20 @@ PRESETS = {
     "wav2vec2-large": EncoderConfig(
         name="wav2vec2-large", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
         feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False),
+    "wavlm-base": EncoderConfig(
+        name="wavlm-base", family="wavlm", hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+        intermediate_size=3072, feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False, rel_pos_buckets=320),
+    "wavlm-large": EncoderConfig(
+        name="wavlm-large", family="wavlm", hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+        intermediate_size=4096, feat_extract_norm="layer", conv_bias=False, do_stable_layer_norm=True, rel_pos_buckets=320),
+    "tiny-wavlm": EncoderConfig(
+        name="tiny-wavlm", family="wavlm", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+        rel_pos_buckets=32, rel_pos_max_distance=40),
+    "tiny-wavlm-stable": EncoderConfig(
+        name="tiny-wavlm-stable", family="wavlm", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+        feat_extract_norm="layer", do_stable_layer_norm=True, rel_pos_buckets=32, rel_pos_max_distance=40),
     "data2vec-audio-base": EncoderConfig(
         name="data2vec-audio-base", family="data2vec", hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
         intermediate_size=3072, feat_extract_norm="layer", conv_bias=False, do_stable_layer_norm=False,
@@ -153,8 +170,7 @@ def config_from_source(source: str) -> EncoderConfig:
     if "data2vec" in low:
         return PRESETS["data2vec-audio-large" if "large" in low else "data2vec-audio-base"]
     if "wavlm" in low:
-        raise NotImplementedError(
-            f"{source}: WavLM (gated relative position bias in the attention) is out of scope for the MI355X path (SURVEY.md §8 note iii)")
+        return PRESETS["wavlm-large" if "large" in low else "wavlm-base"]
     if "wav2vec2" in low:
         if "large" not in low and "xls" not in low:
             return PRESETS["wav2vec2-base"]

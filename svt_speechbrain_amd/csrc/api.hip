@@ -151,11 +151,11 @@ static int attn_tp(int prec, int dh, int T) { return use_flash(prec, dh) ? round
 
 static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
-                                 long ldo, hipStream_t s) {
-  if (use_flash(prec, dh)) {
+                                 long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr) {
+  if (use_flash(prec, dh)) {  // (with a gate: head_dim 64 and 2T-1 <= 8192, else the launcher reports an error)
     (void)vt_ready;
     return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
-                                  scale, s);
+                                  scale, s, gate, gate ? relpb : nullptr);
   }
   const int Tp = round_up_int(T, 8);
   GemmArgs g;
@@ -169,6 +169,8 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
   g.c_z1 = (long)H * T * Tp; g.c_z2 = (long)T * Tp;
   g.alpha = scale; g.out_f32 = 1;
   if (int r = launch_gemm(prec, g, s)) return r;
+  if (gate)
+    if (int r = launch_scores_add_relbias(ab.S, (int64_t)B * H, H, T, Tp, gate, relpb, s)) return r;
   if (int r = launch_softmax_rows(prec, ab.S, (int64_t)B * H * T, T, Tp, ab.P, s)) return r;
   if (!vt_ready)
     if (int r = launch_transpose_v(prec, V, B, T, H, dh, ldkv, 0, Tp, ab.Vt, s)) return r;
@@ -200,6 +202,7 @@ struct ConvLayerW {
 };
 struct EncLayerW {
   DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
+  DevBuf g_wab, g_bab, g_const;   // WavLM gate: folded gru_rel_pos_linear (2 x dh, 2) and gru_rel_pos_const (H)
 };
 
 struct svt_encoder {
@@ -212,6 +215,7 @@ struct svt_encoder {
   DevBuf pos_wP, pos_bP;   // multi-frame form of the positional conv (bf16 mode): P frames per GEMM row
   int pos_P = 0;
   std::vector<DevBuf> pos_ws, pos_bs;   // data2vec-audio: one plain grouped conv per stacked positional layer
+  DevBuf rel_embed;                     // WavLM: (buckets, H) relative position embedding of layer 0
   DevBuf ones, zeros;                   // LayerNorm without affine parameters
   std::vector<EncLayerW> layers;
 };
@@ -239,6 +243,8 @@ static int validate_cfg(const svt_encoder_config& c) {
   if (c.feat_extract_norm != SVT_NORM_GROUP && c.feat_extract_norm != SVT_NORM_LAYER) { set_error("feat_extract_norm"); return SVT_ERR_INVALID; }
   if (c.precision != SVT_PREC_FP32 && c.precision != SVT_PREC_BF16) { set_error("precision"); return SVT_ERR_INVALID; }
   if (c.pos_conv_depth < 1 || c.pos_conv_depth > 16) { set_error("pos_conv_depth must be 1..16"); return SVT_ERR_INVALID; }
+  if (c.rel_pos_buckets < 0 || c.rel_pos_buckets % 4 || (c.rel_pos_buckets > 0 && c.rel_pos_max_distance <= c.rel_pos_buckets / 4)) {
+    set_error("rel_pos_buckets must be a multiple of 4 and rel_pos_max_distance > rel_pos_buckets / 4"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
 
@@ -538,6 +544,26 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = upload_f32(L.ln2g, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "final_layer_norm.bias", {D}, &p)) return r;
     if (int r = upload_f32(L.ln2b, p->v.data(), p->v.size())) return r;
+    if (c.rel_pos_buckets) {
+      // gate = a (b const - 1) + 2, a / b = sigmoid of the sums of rows 0-3 / 4-7 of gru_rel_pos_linear(x_head): fold the row sums
+      const int Hh = c.num_heads, dhh = D / Hh;
+      const Param *gw = nullptr, *gb = nullptr, *gc = nullptr;
+      if (int r = need(P, pre + "attention.gru_rel_pos_linear.weight", {8, dhh}, &gw)) return r;
+      if (int r = need(P, pre + "attention.gru_rel_pos_linear.bias", {8}, &gb)) return r;
+      if (int r = need(P, pre + "attention.gru_rel_pos_const", {1, Hh, 1, 1}, &gc)) return r;
+      std::vector<float> wab((size_t)2 * dhh, 0.f), bab(2, 0.f);
+      for (int j = 0; j < 8; ++j) {
+        for (int d = 0; d < dhh; ++d) wab[(size_t)(j / 4) * dhh + d] += gw->v[(size_t)j * dhh + d];
+        bab[j / 4] += gb->v[j];
+      }
+      if (int r = upload_f32(L.g_wab, wab.data(), wab.size())) return r;
+      if (int r = upload_f32(L.g_bab, bab.data(), bab.size())) return r;
+      if (int r = upload_f32(L.g_const, gc->v.data(), gc->v.size())) return r;
+      if (l == 0) {
+        if (int r = need(P, pre + "attention.rel_attn_embed.weight", {c.rel_pos_buckets, Hh}, &p)) return r;
+        if (int r = upload_f32(e->rel_embed, p->v.data(), p->v.size())) return r;
+      }
+    }
   }
   SVT_HIP(hipDeviceSynchronize());
   e->finalized = true;
@@ -572,6 +598,8 @@ struct EncWs {
   void* xlo;
   void* posg;
   void* posy;
+  float* gate;
+  float* relpb;
   void* qkv;
   AttnBufs ab;
   void* attn_o;
@@ -623,6 +651,8 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.ab.Vt = cv.take((size_t)B * H * dh * Tp * es);
   w.attn_o = cv.take(rows * D * es);
   w.ffn = cv.take(rows * F * es);
+  w.gate = c.rel_pos_buckets ? (float*)cv.take((size_t)B * H * T * 4) : nullptr;
+  w.relpb = c.rel_pos_buckets ? (float*)cv.take((size_t)H * (2 * T - 1) * 4) : nullptr;
   w.total = cv.off;
   return w;
 }
@@ -779,10 +809,22 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     }
   }
   const float scale = 1.0f / std::sqrt((float)dh);
+  if (c.rel_pos_buckets)
+    if (int r = launch_relpos_table(e->rel_embed.as<float>(), H, (int)T, c.rel_pos_buckets, c.rel_pos_max_distance, w.relpb, s)) return r;
+  int cur_layer = 0;
   auto attention = [&](void) -> int {
+    const float* gate = nullptr;
+    if (c.rel_pos_buckets) {
+      // WavLM: the gate of the relative position bias is a function of the attention INPUT (w.xb, operand type)
+      const EncLayerW& Lg = e->layers[cur_layer];
+      if (int r = launch_relpos_gate(prec, w.xb, rows, (int)T, H, dh, Lg.g_wab.as<float>(), Lg.g_bab.as<float>(),
+                                     Lg.g_const.as<float>(), w.gate, s)) return r;
+      gate = w.gate;
+    }
+    ++cur_layer;
     return attention_scores_path(prec, w.qkv, 3L * D, (const char*)w.qkv + (size_t)D * esize(prec),
                                  (const char*)w.qkv + (size_t)2 * D * esize(prec), 3L * D, B, (int)T, H, dh, scale, w.ab,
-                                 false, w.attn_o, D, s);
+                                 false, w.attn_o, D, s, gate, w.relpb);
   };
   auto gemm_rows = [&](const void* A, int K, const DevBuf& W, const DevBuf& bias, int N, void* Cout, int out_f32, int act,
                        const float* resid) -> int {

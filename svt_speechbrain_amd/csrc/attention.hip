@@ -29,11 +29,14 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-template <int DH>
+// BIAS: WavLM's gated relative position bias, scores += gate[b,h,q] * pb[h][key - q + T - 1] (pb row of 2T-1 floats kept
+// in LDS; added in the scaled log2 domain before the row max).
+template <int DH, bool BIAS = false>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
                                                          const bf16_t* __restrict__ K, long ldk, long k_bstride,
                                                          const bf16_t* __restrict__ V, int /*unused*/, bf16_t* __restrict__ O,
-                                                         long ldo, long o_bstride, int T, int H, float c) {
+                                                         long ldo, long o_bstride, int T, int H, float c,
+                                                         const float* __restrict__ gate, const float* __restrict__ pbias) {
   constexpr int KSD = DH / 16;   // k-steps over head_dim for S
   constexpr int DB = DH / 32;    // 32-row blocks of O^T
   constexpr int CPR = DH / 8;    // 16-byte chunks per K row
@@ -41,6 +44,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
   // two stages of { K tile, V tile }, each tile row-major [key][slot] with slot = chunk ^ swizzle(key); filled by LDS-DMA
   constexpr int TILE16 = 64 * CPR;  // uint4 per tile
   __shared__ __attribute__((aligned(16))) uint4 KV[2][2 * TILE16];
+  extern __shared__ float pbl[];  // BIAS: this head's 2T-1 bias values
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -59,6 +63,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
+  float gq = 0.f;   // gate of this lane's query, pre-multiplied by log2(e)
+  int qrel = 0;     // T - 1 - query
+  if constexpr (BIAS) {
+    for (int i = tid; i < 2 * T - 1; i += 256) pbl[i] = pbias[(long)h * (2 * T - 1) + i];
+    int q = q0 + (lane & 31);
+    if (q > T - 1) q = T - 1;
+    gq = gate[((long)b * H + h) * T + q] * 1.44269504088896340736f;
+    qrel = T - 1 - q;
+  }
   // LDS-DMA staging: a wave instruction moves 64 x 16 B = 1 KB = ROWS_PER_DMA whole rows; lane (row r = lane / CPR,
   // slot = lane % CPR) fetches chunk slot ^ g(key) of its row, so the linear LDS image holds chunk c of a key at slot
   // c ^ g(key) -- the same swizzled row-major layout the MFMA operand reads below expect (K: g = (key>>1)&7 for
@@ -144,6 +157,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     // taken on the raw scores, and the running max is only raised (O and l rescaled) when some row of the wave grew
     // by more than 2^8 (deferred rescale: P stays <= 256, exact in fp32 and safe in bf16); keys >= T are masked in
     // the last tile only.
+    if constexpr (BIAS) {
+      // x = s*c + gate*log2e * pb[key - q + T - 1]; from here on the scores ARE in the log2 domain (cs = 1 below)
+      const int kb0 = tile * 64 + 4 * hh + qrel;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int idx = kb0 + kb * 32 + (r & 3) + 8 * (r >> 2);
+          if (idx > 2 * T - 2) idx = 2 * T - 2;   // keys >= T of the last tile (masked below)
+          s[kb][r] = fmaf(s[kb][r], c, gq * pbl[idx]);
+        }
+    }
+    const float cs = BIAS ? 1.0f : c;
     if (__builtin_expect(tile * 64 + 64 > T, 0)) {  // wave-uniform, last tile only
       const int kbase = tile * 64 + 4 * hh;
 #pragma unroll
@@ -158,7 +184,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);  // v_max3_f32
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * cs;
     if (!__all(mx - m <= 8.0f)) {
       const float mnew = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);
@@ -172,7 +198,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
     // exponent arguments and row sums on pairs (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot)
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     f32x2v sum2 = {0.f, 0.f};
-    const f32x2v c2 = {c, c}, nm2 = {-m, -m};
+    const f32x2v c2 = {cs, cs}, nm2 = {-m, -m};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -233,18 +259,30 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
 
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
-                           void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s) {
+                           void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
+                           const float* gate, const float* pb) {
   if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8) { set_error("flash_attention: strides must be multiples of 8"); return -1; }
   const float c = scale * 1.44269504088896340736f;
   dim3 grid((T + 127) / 128, H, B);
   const double flops = 4.0 * B * H * (double)T * T * dh;
+  if (gate && pb) {
+    if (dh != 64) { set_error("flash_attention: the relative-position-bias variant is built for head_dim 64"); return -1; }
+    const size_t dyn = (size_t)(2 * T - 1) * 4;
+    if (dyn > 32768) { set_error("flash_attention: sequence too long for the LDS-resident position-bias row"); return -1; }
+    prof_begin(s);
+    hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), dyn, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, gate, pb);
+    prof_end(s, flops, 0.0, 2);
+    SVT_LAUNCH_CHECK();
+    return 0;
+  }
   prof_begin(s);
   if (dh == 64)
     hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
-                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else if (dh == 128)
     hipLaunchKernelGGL((flash_attn_kernel<128>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
-                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c);
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else { set_error("flash_attention: head_dim must be 64 or 128"); return -1; }
   prof_end(s, flops, 0.0, 2);
   SVT_LAUNCH_CHECK();

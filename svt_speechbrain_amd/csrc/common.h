@@ -204,8 +204,10 @@ int launch_transpose_v(int prec, const void* qkv, int B, int T, int H, int dh, l
 
 // fused attention (bf16, head_dim 64/128): Q/K row-major with row strides ldq/ldk and per-clip strides, V^T padded
 // Q/K/V row-major (K and V share row / clip strides); V is transposed on the fly by ds_read_b64_tr_b16
+// gate (B,H,T) / pb (H, 2T-1): WavLM's gated relative position bias, or nullptr
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
-                           void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s);
+                           void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
+                           const float* gate = nullptr, const float* pb = nullptr);
 
 // out = a*x + b*y (fp32 or operand type)
 int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s);
@@ -229,6 +231,11 @@ int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias,
 // Fbank add-ons: time derivatives and context window
 int launch_deltas(const float* x, long ldx, int B, int T, int C, int n, float inv_denom, float* out, long ldo, hipStream_t s);
 int launch_context_window(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out, hipStream_t s);
+// WavLM gated relative position bias
+int launch_relpos_table(const float* embed, int H, int T, int num_buckets, int max_distance, float* pb, hipStream_t s);
+int launch_relpos_gate(int prec, const void* u, int64_t rows, int T, int H, int dh, const float* wab, const float* bab,
+                       const float* cst, float* gate, hipStream_t s);
+int launch_scores_add_relbias(float* S, int64_t BH, int H, int T, int Tp, const float* gate, const float* pb, hipStream_t s);
 // lip front-end (video.hip)
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,

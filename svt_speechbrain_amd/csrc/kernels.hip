@@ -808,6 +808,63 @@ __global__ void context_window_kernel(const float* x, int B, int T, int C, int c
   }
 }
 
+// ---- WavLM gated relative position bias (HF modeling_wavlm.py WavLMAttention) ----
+// pb[h][d + T - 1] = embed[bucket(d)][h], d = key - query in (-T, T): half of the buckets per sign, exact below max_exact,
+// log-spaced above, with torch's fp32 arithmetic (log(|d| / max_exact) / log(max_distance / max_exact) * (nb - max_exact),
+// truncated)
+__global__ void relpos_table_kernel(const float* embed, int H, int T, int num_buckets, int max_distance, float* pb) {
+  const int n = 2 * T - 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * H) return;
+  const int h = i / n, di = i - h * n;
+  const int d = di - (T - 1);
+  const int nb = num_buckets / 2, max_exact = nb / 2;
+  int bucket = d > 0 ? nb : 0;
+  const int a = d < 0 ? -d : d;
+  if (a < max_exact) bucket += a;
+  else {
+    float v = logf((float)a / (float)max_exact);
+    v = v / (float)log((double)max_distance / (double)max_exact);
+    v = v * (float)(nb - max_exact);
+    long lb = (long)((float)max_exact + v);
+    if (lb > nb - 1) lb = nb - 1;
+    bucket += (int)lb;
+  }
+  pb[i] = embed[bucket * H + h];
+}
+// gate[b][h][t] = ga * (gb * const[h] - 1) + 2,  ga / gb = sigmoid(u_h . wa + ba), sigmoid(u_h . wb + bb); u = the attention
+// input (operand type), wa / wb = the sums of rows 0-3 / 4-7 of gru_rel_pos_linear (folded at finalize)
+template <typename T>
+__global__ void relpos_gate_kernel(const T* u, int64_t rows, int Tt, int H, int dh, const float* wab, const float* bab,
+                                   const float* cst, float* gate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * H) return;
+  const int h = (int)(i % H);
+  const int64_t row = i / H;
+  const T* x = u + row * (int64_t)H * dh + (int64_t)h * dh;
+  float sa = bab[0], sb = bab[1];
+  for (int d = 0; d < dh; ++d) {
+    const float xv = (float)x[d];
+    sa = fmaf(xv, wab[d], sa);
+    sb = fmaf(xv, wab[dh + d], sb);
+  }
+  const float ga = 1.f / (1.f + expf(-sa)), gb = 1.f / (1.f + expf(-sb));
+  const int64_t b = row / Tt, t = row % Tt;
+  gate[(b * H + h) * Tt + t] = ga * (gb * cst[h] - 1.f) + 2.f;
+}
+// materialised-score path: S[b,h,q,k] += gate[b,h,q] * pb[h][k - q + T - 1]
+__global__ void scores_add_relbias_kernel(float* S, int64_t BH, int H, int T, int Tp, const float* gate, const float* pb) {
+  const int64_t n = BH * T * (int64_t)T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % T);
+    int64_t r = i / T;
+    const int q = (int)(r % T);
+    const int64_t bh = r / T;
+    const int h = (int)(bh % H);
+    S[(bh * T + q) * Tp + k] += gate[bh * T + q] * pb[(int64_t)h * (2 * T - 1) + (k - q + T - 1)];
+  }
+}
+
 __global__ void decode_frames_kernel(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls,
                                      FrameOut* out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1230,6 +1287,26 @@ int launch_deltas(const float* x, long ldx, int B, int T, int C, int n, float in
 }
 int launch_context_window(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out, hipStream_t s) {
   hipLaunchKernelGGL(context_window_kernel, dim3(grid_for((int64_t)B * T * C * ctx)), dim3(256), 0, s, x, B, T, C, ctx, lag, pad, out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_relpos_table(const float* embed, int H, int T, int num_buckets, int max_distance, float* pb, hipStream_t s) {
+  const int n = (2 * T - 1) * H;
+  hipLaunchKernelGGL(relpos_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, embed, H, T, num_buckets, max_distance, pb);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_relpos_gate(int prec, const void* u, int64_t rows, int T, int H, int dh, const float* wab, const float* bab,
+                       const float* cst, float* gate, hipStream_t s) {
+  const int64_t n = rows * H;
+  if (prec) hipLaunchKernelGGL(relpos_gate_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)u, rows, T, H, dh, wab, bab, cst, gate);
+  else hipLaunchKernelGGL(relpos_gate_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)u, rows, T, H, dh, wab, bab, cst, gate);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_scores_add_relbias(float* S, int64_t BH, int H, int T, int Tp, const float* gate, const float* pb, hipStream_t s) {
+  hipLaunchKernelGGL(scores_add_relbias_kernel, dim3(grid_for(BH * T * (int64_t)T)), dim3(256), 0, s, S, BH, H, T, Tp, gate, pb);
   SVT_LAUNCH_CHECK();
   return 0;
 }

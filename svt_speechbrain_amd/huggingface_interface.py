@@ -71,6 +71,8 @@ def _config_to_c(cfg: EncoderConfig, normalize_wav: bool, output_norm: bool, pre
     c.output_norm = int(output_norm)
     c.precision = PRECISIONS[precision]
     c.pos_conv_depth = cfg.pos_conv_depth
+    c.rel_pos_buckets = cfg.rel_pos_buckets
+    c.rel_pos_max_distance = cfg.rel_pos_max_distance
     return c
 
 

@@ -62,9 +62,17 @@ def encoder_param_shapes(cfg: EncoderConfig, old_weight_norm_keys: bool = False)
     sh["encoder.layer_norm.bias"] = (D,)
     for l in range(cfg.num_hidden_layers):
         p = f"encoder.layers.{l}"
+        if cfg.rel_pos_buckets:  # WavLM (HF modeling_wavlm.py WavLMAttention.__init__): gate parameters in every layer, the
+            # bucket embedding in layer 0 only; the bare Parameter precedes the sub-modules in state_dict order
+            sh[f"{p}.attention.gru_rel_pos_const"] = (1, cfg.num_attention_heads, 1, 1)
         for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
             sh[f"{p}.attention.{n}.weight"] = (D, D)
             sh[f"{p}.attention.{n}.bias"] = (D,)
+        if cfg.rel_pos_buckets:
+            sh[f"{p}.attention.gru_rel_pos_linear.weight"] = (8, D // cfg.num_attention_heads)
+            sh[f"{p}.attention.gru_rel_pos_linear.bias"] = (8,)
+            if l == 0:
+                sh[f"{p}.attention.rel_attn_embed.weight"] = (cfg.rel_pos_buckets, cfg.num_attention_heads)
         sh[f"{p}.layer_norm.weight"] = (D,)
         sh[f"{p}.layer_norm.bias"] = (D,)
         sh[f"{p}.feed_forward.intermediate_dense.weight"] = (F, D)
@@ -83,6 +91,12 @@ def _draw(name: str, shape, gen: torch.Generator) -> torch.Tensor:
         return 1.0 + 0.1 * x if leaf == "weight" else 0.1 * x
     if leaf == "bias":
         return 0.05 * x
+    if leaf == "gru_rel_pos_const":
+        return 1.0 + 0.3 * x
+    if "rel_attn_embed" in name:
+        return 1.5 * x          # bias values O(1): a wrong bucket or gate shows in the logits
+    if "gru_rel_pos_linear" in name and leaf == "weight":
+        return x * (1.0 / math.sqrt(shape[1]))
     if leaf in ("original0", "weight_g"):
         return 0.6 + 0.1 * x.abs()  # per-tap gain g[j]; norm of v per tap is O(sqrt(D*D/g)) -> W ~ small
     if leaf in ("original1", "weight_v"):

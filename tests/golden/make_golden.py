@@ -71,7 +71,10 @@ def hf_model(cfg):
               layer_norm_eps=cfg.layer_norm_eps, hidden_dropout=0.0, attention_dropout=0.0,
               activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, apply_spec_augment=False,
               attn_implementation="eager")
-    if cfg.family == "data2vec":
+    if cfg.family == "wavlm":
+        from transformers import WavLMModel, WavLMConfig
+        m = WavLMModel(WavLMConfig(num_buckets=cfg.rel_pos_buckets, max_bucket_distance=cfg.rel_pos_max_distance, **kw))
+    elif cfg.family == "data2vec":
         from transformers import Data2VecAudioModel, Data2VecAudioConfig
         kw.pop("do_stable_layer_norm"); kw.pop("feat_extract_norm"); kw.pop("num_conv_pos_embeddings")
         m = Data2VecAudioModel(Data2VecAudioConfig(conv_pos_kernel_size=cfg.num_conv_pos_embeddings,
@@ -442,6 +445,9 @@ def main():
         "large_c1": lambda: make_encoder_case(hi, utils, "large_c1", "wav2vec2-large-lv60", 1, 80000, 23, full=False),
         "hubert_large_c1": lambda: make_encoder_case(hi, utils, "hubert_large_c1", "hubert-large-ll60k", 1, 48000, 24,
                                                       full=False),
+        "tiny_wavlm": lambda: make_encoder_case(hi, utils, "tiny_wavlm", "tiny-wavlm", 2, 4000, 16),
+        "tiny_wavlm_stable": lambda: make_encoder_case(hi, utils, "tiny_wavlm_stable", "tiny-wavlm-stable", 2, 4000, 17),
+        "wavlm_base_c1": lambda: make_encoder_case(hi, utils, "wavlm_base_c1", "wavlm-base", 1, 48000, 26, full=False),
         "tiny_data2vec": lambda: make_encoder_case(hi, utils, "tiny_data2vec", "tiny-data2vec", 2, 4000, 15),
         "data2vec_base_c1": lambda: make_encoder_case(hi, utils, "data2vec_base_c1", "data2vec-audio-base", 1, 48000, 25, full=False),
         "fusion": lambda: make_fusion_cases(fusion_mod),

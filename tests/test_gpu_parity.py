@@ -55,7 +55,7 @@ def check_decode(logits_gpu, fx, exact=True):
     return mism
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable"])
 def test_tiny_fp32_vs_reference_golden(golden, name):
     fx = golden(name)
     cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp32")
@@ -68,7 +68,7 @@ def test_tiny_fp32_vs_reference_golden(golden, name):
     check_decode(logits, fx, exact=True)
 
 
-@pytest.mark.parametrize("name", ["base_c1", "base_b2", "large_c1", "hubert_large_c1", "data2vec_base_c1"])
+@pytest.mark.parametrize("name", ["base_c1", "base_b2", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1"])
 def test_full_size_fp32_vs_reference_golden(golden, name):
     fx = golden(name)
     cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp32")
@@ -83,7 +83,7 @@ def test_full_size_fp32_vs_reference_golden(golden, name):
     check_decode(logits, fx, exact=True)
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1"])  # base_b2: 2 x 10 s -> multi-frame positional conv
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1"])  # base_b2: 2 x 10 s -> multi-frame positional conv
 def test_bf16_mode_error_bound(golden, name):
     """bf16 MFMA operands, fp32 accumulate/residual/norms: bounded error, decode mostly identical."""
     fx = golden(name)

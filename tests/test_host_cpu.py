@@ -58,12 +58,11 @@ def test_config_frames_and_flops():
     assert config_from_source("facebook/wav2vec2-base").hidden_size == 768
     assert config_from_source("facebook/wav2vec2-large-lv60").do_stable_layer_norm
     assert config_from_source("facebook/hubert-large-ll60k").family == "hubert"
-    with pytest.raises(NotImplementedError):
-        config_from_source("microsoft/wavlm-large")
+    assert config_from_source("microsoft/wavlm-large").rel_pos_buckets == 320
 
 
 def test_state_dict_schema_matches_hf_keys():
-    for name in ["tiny-group", "tiny-layer", "tiny-hubert", "tiny-data2vec"]:
+    for name in ["tiny-group", "tiny-layer", "tiny-hubert", "tiny-data2vec", "tiny-wavlm"]:
         cfg = PRESETS[name]
         enc = S.HuggingFaceWav2Vec2(name, None, config=cfg)
         keys = list(enc.state_dict().keys())
@@ -301,8 +300,7 @@ def test_config_from_source_family_heuristics():
     assert c("facebook/hubert-xlarge-ll60k").hidden_size == 1280
     assert c("ssl_model/AVHuBERT/large_vox_iter5.pt".replace("AVHuBERT", "avhubert")).family == "avhubert"
     assert c("facebook/data2vec-audio-base-960h").pos_conv_depth == 5 and c("facebook/data2vec-audio-large").hidden_size == 1024
-    with pytest.raises(NotImplementedError):
-        c("microsoft/wavlm-large")
+    assert c("microsoft/wavlm-large").rel_pos_buckets == 320 and c("microsoft/wavlm-base-plus").num_hidden_layers == 12
     with pytest.raises(ValueError):
         c("my-model")
     # every preset's parameter schema is self-consistent (head_dim, group sizes)

@@ -40,7 +40,7 @@ def _run_case(fx):
     return cfg, feats, logits
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable"])
 def test_oracle_tiny(golden, name):
     fx = golden(name)
     cfg, feats, logits = _run_case(fx)
@@ -55,7 +55,7 @@ def test_oracle_tiny(golden, name):
         assert notes == d["notes"]
 
 
-@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1", "data2vec_base_c1"])
+@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1"])
 def test_oracle_full_size(golden, name):
     fx = golden(name)
     torch.set_num_threads(8)
