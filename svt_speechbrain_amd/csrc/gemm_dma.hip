@@ -328,14 +328,14 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   bf16x8 wfr[NBW], xfr[HM];
   const int grp = wave >> 2;
   const bool tr = p.trace != nullptr;
-  long long t_begin = 0, t_first = 0, t_main = 0;
+  long long t_begin = 0, t_first = 0, t_main = 0, c_first = 0, c_main = 0;  // t_*: s_memrealtime (100 MHz), c_*: s_memtime (core clock)
   if (tr) t_begin = wall_clock64();
   issue_a(0, 0);
   issue_w(0, 1);
   if (nk > 1) issue_a(1, 2);
   if (nk > 1) wait_vm<GA>(); else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
-  if (tr) t_first = wall_clock64();
+  if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
   int sa = 0, sw = 1;
 #define SVT_LOAD(Q)                                                                                              \
   {                                                                                                              \
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   // ---- epilogue ----
   const long coff = z1 * p.c_z1 + z2 * p.c_z2;
   const float* bias = p.bias ? p.bias + z2 * p.bias_z2 : nullptr;
-  if (tr) t_main = wall_clock64();
+  if (tr) { t_main = wall_clock64(); c_main = __builtin_amdgcn_s_memtime(); }
   __syncthreads();  // every wave is done with the ring before it is reused as transpose patches
   if constexpr (GEN)
     epilogue_seq_gen<MB, BM, NBW>(std::make_integer_sequence<int, MB>{}, p, acc, (float*)lds + wave * (16 * (16 * NBW + 4)), lane, wm, wn,
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
   if (tr && lane == 0 && (wave & 3) == 0) {
     long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
     o[0] = t_begin; o[1] = t_first; o[2] = t_main - t_first; o[3] = wall_clock64() - t_main; o[4] = wall_clock64(); o[5] = 1;
+    o[6] = c_main - c_first; o[7] = BM;
   }
 }
 

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
     ap.add_argument("--nobias", action="store_true")
+    ap.add_argument("--load-seconds", type=float, default=0.0,
+                    help="run the kernel back to back for this long before the stamped launch (the clock the chip holds under "
+                         "load: MI355X_MICROARCH.md 'DVFS give-back' item 6 asks for >= 2 s)")
     ap.add_argument("--variant", type=int, default=0, help="extra diagnostic variant: 10 = no stores, 11 = no pointer setup")
     a = ap.parse_args()
     lib = _lib.load()
@@ -51,6 +54,15 @@ def main():
         for _ in range(3):
             call(0)
         torch.cuda.synchronize()
+        if a.load_seconds > 0:
+            import time
+            t_end = time.time() + a.load_seconds
+            while time.time() < t_end:
+                for _ in range(200):
+                    call(0)
+                torch.cuda.synchronize()
+            for _ in range(200):
+                call(0)
         call(9)
         torch.cuda.synchronize()
         if a.variant:
@@ -71,6 +83,13 @@ def main():
         print(f"  main loop   (sum over tiles)     : mean {(t[:,2]*us).mean():.2f}  max {(t[:,2]*us).max():.2f} us   per tile {(t[:,2]/t[:,5]*us).mean():.2f}")
         print(f"  epilogue    (sum over tiles)     : mean {(t[:,3]*us).mean():.2f}  max {(t[:,3]*us).max():.2f} us   per tile {(t[:,3]/t[:,5]*us).mean():.2f}")
         print(f"  exit        (end - first begin)  : mean {((t[:,4]-t0)*us).mean():.2f}  min {((t[:,4]-t0)*us).min():.2f} max {((t[:,4]-t0)*us).max():.2f} us")
+        if (t[:, 6] > 0).any():
+            mhz = (t[:, 6] / t[:, 2].clamp(min=1)) * 100.0
+            clk = mhz.median().item() * 1e6
+            busy = (2.0 * t[:, 7] * 256 * K) / (t[:, 2] * 1e-8) / (4 * 1024 * clk)   # per workgroup = per CU
+            print(f"  core clock over the main loop (s_memtime / s_memrealtime): median {mhz.median():.0f} MHz "
+                  f"(min {mhz.min():.0f}, max {mhz.max():.0f}); MFMA pipe busy for {busy.mean():.2f} of the main-loop cycles "
+                  f"(1024 bf16 FLOP/clk/SIMD)")
         print(f"  tiles per workgroup: min {int(t[:,5].min())} max {int(t[:,5].max())}")
         lib.svt_debug_set(0, 0)
 
