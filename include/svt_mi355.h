@@ -75,6 +75,8 @@ typedef struct svt_encoder_config {
                                  * n plain grouped convs, each followed by LayerNorm(no affine) + GELU */
   int32_t rel_pos_buckets;      /* 0: none; > 0: WavLM's gated relative position bias with this many buckets */
   int32_t rel_pos_max_distance; /* WavLM max_bucket_distance */
+  int32_t pos_conv_batch_norm;  /* HuBERT conv_pos_batch_norm (HF modeling_hubert.py HubertPositionalConvEmbedding): eval-mode BatchNorm1d in
+                                   front of a plain (not weight-normed) positional conv; keys encoder.pos_conv_embed.batch_norm.* */
 } svt_encoder_config;
 
 typedef struct svt_encoder svt_encoder;

@@ -151,7 +151,13 @@ def encoder_tail(sd: Dict[str, torch.Tensor], cfg, h: torch.Tensor, output_norm:
         pos = pos.transpose(1, 2)
     else:
         w = _posconv_weight(sd, prefix)
-        pos = F.conv1d(h.transpose(1, 2), w, sd[prefix + "encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=g)
+        xin = h.transpose(1, 2)
+        bn = prefix + "encoder.pos_conv_embed.batch_norm."
+        if getattr(cfg, "conv_pos_batch_norm", False):
+            # HF modeling_hubert.py HubertPositionalConvEmbedding with conv_pos_batch_norm: eval-mode BatchNorm1d (eps 1e-5) in
+            # front of a plain conv; the conv's zero padding is applied AFTER the norm
+            xin = F.batch_norm(xin, sd[bn + "running_mean"], sd[bn + "running_var"], sd[bn + "weight"], sd[bn + "bias"], False, 0.0, 1e-5)
+        pos = F.conv1d(xin, w, sd[prefix + "encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=g)
         if kp % 2 == 0:
             pos = pos[:, :, :-1]
         pos = F.gelu(pos).transpose(1, 2)

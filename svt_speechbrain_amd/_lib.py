@@ -43,6 +43,7 @@ class EncoderConfigC(C.Structure):
         ("pos_conv_depth", C.c_int32),
         ("rel_pos_buckets", C.c_int32),
         ("rel_pos_max_distance", C.c_int32),
+        ("pos_conv_batch_norm", C.c_int32),
     ]
 
 

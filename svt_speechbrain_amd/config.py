@@ -36,6 +36,9 @@ class EncoderConfig:
     # WavLM: gated relative position bias in every self-attention (HF modeling_wavlm.py WavLMAttention); 0 = none
     rel_pos_buckets: int = 0
     rel_pos_max_distance: int = 800
+    # HuBERT ``conv_pos_batch_norm`` (HF modeling_hubert.py HubertPositionalConvEmbedding): BatchNorm1d in front of a plain
+    # positional conv instead of the weight-normed conv
+    conv_pos_batch_norm: bool = False
 
     @property
     def head_dim(self) -> int:
@@ -137,6 +140,11 @@ PRESETS = {
         num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
         num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, feat_extract_norm="layer",
         conv_bias=True, do_stable_layer_norm=True, feat_proj_layer_norm=False),
+    "tiny-hubert-bn": EncoderConfig(
+        name="tiny-hubert-bn", family="hubert", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(32,) * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+        feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False, feat_proj_layer_norm=False,
+        conv_pos_batch_norm=True),
     # AV-HuBERT video branch (features-in: no waveform conv stack; the transformer reads cat([audio, video]) features of
     # width 2 * hidden_size).  LARGE: 24 layers, layer_norm_first (the public large_vox_iter5 / self_large_vox_433h cfg)
     "avhubert-large-video": EncoderConfig(

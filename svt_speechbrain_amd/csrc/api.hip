@@ -212,6 +212,7 @@ struct svt_encoder {
   ParamMap params;
   std::vector<ConvLayerW> conv;
   DevBuf fp_g, fp_b, proj_w, proj_b, pos_w, pos_b, enc_g, enc_b;
+  DevBuf pos_bn_sc, pos_bn_sh;  // HuBERT conv_pos_batch_norm: eval-mode BatchNorm1d folded to a per-channel affine (fp32)
   DevBuf pos_wP, pos_bP;   // multi-frame form of the positional conv (bf16 mode): P frames per GEMM row
   int pos_P = 0;
   std::vector<DevBuf> pos_ws, pos_bs;   // data2vec-audio: one plain grouped conv per stacked positional layer
@@ -243,6 +244,7 @@ static int validate_cfg(const svt_encoder_config& c) {
   if (c.feat_extract_norm != SVT_NORM_GROUP && c.feat_extract_norm != SVT_NORM_LAYER) { set_error("feat_extract_norm"); return SVT_ERR_INVALID; }
   if (c.precision != SVT_PREC_FP32 && c.precision != SVT_PREC_BF16) { set_error("precision"); return SVT_ERR_INVALID; }
   if (c.pos_conv_depth < 1 || c.pos_conv_depth > 16) { set_error("pos_conv_depth must be 1..16"); return SVT_ERR_INVALID; }
+  if (c.pos_conv_batch_norm && c.pos_conv_depth != 1) { set_error("pos_conv_batch_norm applies to the single positional conv only"); return SVT_ERR_INVALID; }
   if (c.rel_pos_buckets < 0 || c.rel_pos_buckets % 4 || (c.rel_pos_buckets > 0 && c.rel_pos_max_distance <= c.rel_pos_buckets / 4)) {
     set_error("rel_pos_buckets must be a multiple of 4 and rel_pos_max_distance > rel_pos_buckets / 4"); return SVT_ERR_INVALID; }
   return SVT_OK;
@@ -481,6 +483,23 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = upload_operand(prec, e->pos_w, wt.data(), wt.size())) return r;
     if (int r = need(P, pc + "bias", {D}, &p)) return r;
     if (int r = upload_f32(e->pos_b, p->v.data(), p->v.size())) return r;
+    if (c.pos_conv_batch_norm) {
+      // y = (x - running_mean) / sqrt(running_var + 1e-5) * weight + bias   (nn.BatchNorm1d defaults, eval mode)
+      const std::string bn = "encoder.pos_conv_embed.batch_norm.";
+      const Param *bw, *bb, *bm, *bv;
+      if (int r = need(P, bn + "weight", {D}, &bw)) return r;
+      if (int r = need(P, bn + "bias", {D}, &bb)) return r;
+      if (int r = need(P, bn + "running_mean", {D}, &bm)) return r;
+      if (int r = need(P, bn + "running_var", {D}, &bv)) return r;
+      std::vector<float> sc(D), sh(D);
+      for (int i = 0; i < D; ++i) {
+        const double k = (double)bw->v[i] / std::sqrt((double)bv->v[i] + 1e-5);
+        sc[i] = (float)k;
+        sh[i] = (float)((double)bb->v[i] - (double)bm->v[i] * k);
+      }
+      if (int r = upload_f32(e->pos_bn_sc, sc.data(), sc.size())) return r;
+      if (int r = upload_f32(e->pos_bn_sh, sh.data(), sh.size())) return r;
+    }
     // Multi-frame form (throughput mode).  The grouped conv has only cg = D/G (48 / 64) output channels per group: a
     // 64-wide product.  With Pf consecutive output frames per GEMM row the product is Pf*cg (240 / 256) wide and K grows
     // only from kp*cg to (kp+Pf-1)*cg (+3 %, the kernel is 128 taps long): row j*cg+co of a group holds the same filter
@@ -758,6 +777,8 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   {
     const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
     const int Pf = e->pos_P;
+    const float* bn_sc = c.pos_conv_batch_norm ? e->pos_bn_sc.as<float>() : nullptr;
+    const float* bn_sh = c.pos_conv_batch_norm ? e->pos_bn_sh.as<float>() : nullptr;
     if (c.pos_conv_depth > 1) {
       // data2vec-audio: pos = stack of [grouped conv -> LayerNorm(no affine, eps 1e-5) -> GELU]; pre = h + pos
       const float* cur = w.hF;
@@ -782,7 +803,7 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
       if (int r = launch_add_f32(w.hF, cur, w.preF, rows * (int64_t)D, s)) return r;
     } else if (Pf && (int64_t)B * ((T + Pf - 1) / Pf) >= 128) {
       const int Tq = (int)((T + Pf - 1) / Pf), Tp = Tq * Pf + kp;
-      if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, Tp, w.posg, s)) return r;
+      if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, Tp, w.posg, s, bn_sc, bn_sh)) return r;
       GemmArgs g;
       g.A = w.posg; g.W = e->pos_wP.p; g.C = w.posy; g.bias = e->pos_bP.as<float>();
       g.M = B * Tq; g.N = Pf * cg; g.K = (kp + Pf - 1) * cg;
@@ -794,7 +815,7 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
       if (int r = launch_gemm(prec, g, s)) return r;
       if (int r = launch_posconv_scatter_add(w.hF, w.posy, B, (int)T, D, G, Pf, Tq, w.preF, s)) return r;
     } else {
-    if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, (int)T + kp, w.posg, s)) return r;
+    if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, (int)T + kp, w.posg, s, bn_sc, bn_sh)) return r;
     GemmArgs g;
     g.A = w.posg; g.W = e->pos_w.p; g.C = w.preF; g.bias = e->pos_b.as<float>(); g.resid = w.hF;
     g.M = (int)T; g.N = cg; g.K = kp * cg;

@@ -193,7 +193,8 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
                        const float* gamma, const float* beta, float eps, void* out, hipStream_t s);
 
 // positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front
-int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s);
+int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s,
+                          const float* sc = nullptr, const float* sh = nullptr);  // sc/sh: per-channel affine on the valid frames
 int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s);
 
 // attention helpers for the materialised-score path

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int6
 
 // ------------------------------------------------------------------------------------------------
 template <typename TO>
-__global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, TO* out) {
+__global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, TO* out, const float* sc, const float* sh) {
   const int cg = D / G;
   const int64_t n = (int64_t)B * G * Tp * cg;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -493,13 +493,14 @@ __global__ void posconv_gather_kernel(const float* h, int B, int T, int D, int G
     const int g = (int)(r % G);
     const int b = (int)(r / G);
     const int t = tp - kp / 2;
-    const float v = (t >= 0 && t < T) ? h[((int64_t)b * T + t) * D + g * cg + ci] : 0.f;
+    float v = (t >= 0 && t < T) ? h[((int64_t)b * T + t) * D + g * cg + ci] : 0.f;
+    if (sc && t >= 0 && t < T) v = fmaf(v, sc[g * cg + ci], sh[g * cg + ci]);  // eval-mode BatchNorm1d in front of the conv: the zero padding stays zero
     st<TO>(out, i, v);
   }
 }
 
 // bf16 output, 8 channels (16 bytes out, 32 bytes in) per thread
-__global__ void posconv_gather_bf16x8_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, bf16_t* out) {
+__global__ void posconv_gather_bf16x8_kernel(const float* h, int B, int T, int D, int G, int kp, int Tp, bf16_t* out, const float* sc, const float* sh) {
   const int cg = D / G, c8 = cg / 8;
   const int64_t n = (int64_t)B * G * Tp * c8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -512,7 +513,13 @@ __global__ void posconv_gather_bf16x8_kernel(const float* h, int B, int T, int D
     bf16x8 o;
     if (t >= 0 && t < T) {
       const float* src = h + ((int64_t)b * T + t) * D + g * cg + ci;
-      const float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+      float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+      if (sc) {
+        const float4 s0 = *(const float4*)(sc + g * cg + ci), s1 = *(const float4*)(sc + g * cg + ci + 4);
+        const float4 t0 = *(const float4*)(sh + g * cg + ci), t1 = *(const float4*)(sh + g * cg + ci + 4);
+        a = float4{fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y), fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w)};
+        c = float4{fmaf(c.x, s1.x, t1.x), fmaf(c.y, s1.y, t1.y), fmaf(c.z, s1.z, t1.z), fmaf(c.w, s1.w, t1.w)};
+      }
       o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
       o[4] = (bf16_t)c.x; o[5] = (bf16_t)c.y; o[6] = (bf16_t)c.z; o[7] = (bf16_t)c.w;
     } else {
@@ -1131,16 +1138,17 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
   return 0;
 }
 
-int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s) {
+int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s, const float* sc,
+                          const float* sh) {
   const int64_t n = (int64_t)B * Tp * D;
   if (prec && (D / G) % 8 == 0 && !((uintptr_t)h & 15) && !((uintptr_t)out & 15))
-    hipLaunchKernelGGL(posconv_gather_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, h, B, T, D, G, kp, Tp, (bf16_t*)out);
+    hipLaunchKernelGGL(posconv_gather_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, h, B, T, D, G, kp, Tp, (bf16_t*)out, sc, sh);
   else if (prec)
     hipLaunchKernelGGL((posconv_gather_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp, Tp,
-                       (bf16_t*)out);
+                       (bf16_t*)out, sc, sh);
   else
     hipLaunchKernelGGL((posconv_gather_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, h, B, T, D, G, kp, Tp,
-                       (float*)out);
+                       (float*)out, sc, sh);
   SVT_LAUNCH_CHECK();
   return 0;
 }

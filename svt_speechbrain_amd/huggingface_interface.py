@@ -37,7 +37,10 @@ class ParamTree(nn.Module):
     def add(self, dotted: str, tensor: torch.Tensor) -> None:
         head, _, rest = dotted.partition(".")
         if not rest:
-            self.register_parameter(head, nn.Parameter(tensor, requires_grad=True))
+            if head in ("running_mean", "running_var", "num_batches_tracked"):  # BatchNorm statistics are buffers in HF too
+                self.register_buffer(head, tensor)
+            else:
+                self.register_parameter(head, nn.Parameter(tensor, requires_grad=True))
             return
         if head not in self._modules:
             self.add_module(head, ParamTree())
@@ -73,6 +76,7 @@ def _config_to_c(cfg: EncoderConfig, normalize_wav: bool, output_norm: bool, pre
     c.pos_conv_depth = cfg.pos_conv_depth
     c.rel_pos_buckets = cfg.rel_pos_buckets
     c.rel_pos_max_distance = cfg.rel_pos_max_distance
+    c.pos_conv_batch_norm = int(cfg.conv_pos_batch_norm)
     return c
 
 
@@ -83,18 +87,31 @@ def _config_from_dir(path: str) -> Optional[EncoderConfig]:
     with open(f) as fh:
         j = json.load(fh)
     mt = j.get("model_type", "wav2vec2")
-    if mt not in ("wav2vec2", "hubert"):
-        raise NotImplementedError(f"model_type {mt!r} is out of scope (SURVEY.md §8 note iii)")
+    fam = {"wav2vec2": "wav2vec2", "hubert": "hubert", "data2vec-audio": "data2vec", "wavlm": "wavlm"}.get(mt)
+    if fam is None:
+        raise NotImplementedError(f"model_type {mt!r}: the reference wrapper only builds wav2vec2 / hubert / data2vec-audio / wavlm "
+                                  f"models (MIR_ST500/huggingface_interface.py:107-119)")
+    kw = {}
+    if fam == "data2vec":  # Data2VecAudioConfig: num_conv_pos_embeddings = number of stacked layers, conv_pos_kernel_size = taps
+        kw = dict(num_conv_pos_embeddings=j.get("conv_pos_kernel_size", 19), pos_conv_depth=j.get("num_conv_pos_embeddings", 5))
+    else:
+        kw = dict(num_conv_pos_embeddings=j.get("num_conv_pos_embeddings", 128))
+    if fam == "wavlm":
+        kw.update(rel_pos_buckets=j.get("num_buckets", 320), rel_pos_max_distance=j.get("max_bucket_distance", 800))
+    # a config.json written with use_diff=True omits the fields that equal the config CLASS defaults: fall back to those
+    # (transformers Wav2Vec2Config / HubertConfig / WavLMConfig / Data2VecAudioConfig)
     return EncoderConfig(
-        name=os.path.basename(path.rstrip("/")), family=mt, hidden_size=j["hidden_size"],
-        num_hidden_layers=j["num_hidden_layers"], num_attention_heads=j["num_attention_heads"],
-        intermediate_size=j["intermediate_size"], conv_dim=tuple(j["conv_dim"]), conv_kernel=tuple(j["conv_kernel"]),
-        conv_stride=tuple(j["conv_stride"]), feat_extract_norm=j.get("feat_extract_norm", "group"),
-        conv_bias=bool(j.get("conv_bias", False)), do_stable_layer_norm=bool(j.get("do_stable_layer_norm", False)),
-        feat_proj_layer_norm=bool(j.get("feat_proj_layer_norm", True)),
-        num_conv_pos_embeddings=j.get("num_conv_pos_embeddings", 128),
+        name=os.path.basename(path.rstrip("/")), family=fam, hidden_size=j.get("hidden_size", 768),
+        num_hidden_layers=j.get("num_hidden_layers", 12), num_attention_heads=j.get("num_attention_heads", 12),
+        intermediate_size=j.get("intermediate_size", 3072), conv_dim=tuple(j.get("conv_dim", (512,) * 7)),
+        conv_kernel=tuple(j.get("conv_kernel", (10, 3, 3, 3, 3, 2, 2))), conv_stride=tuple(j.get("conv_stride", (5, 2, 2, 2, 2, 2, 2))),
+        feat_extract_norm=j.get("feat_extract_norm", "layer" if fam == "data2vec" else "group"),
+        conv_bias=bool(j.get("conv_bias", False)),
+        do_stable_layer_norm=bool(j.get("do_stable_layer_norm", False)) and fam != "data2vec",
+        feat_proj_layer_norm=bool(j.get("feat_proj_layer_norm", True)) or fam != "hubert",
         num_conv_pos_embedding_groups=j.get("num_conv_pos_embedding_groups", 16),
-        layer_norm_eps=j.get("layer_norm_eps", 1e-5))
+        layer_norm_eps=j.get("layer_norm_eps", 1e-5),
+        conv_pos_batch_norm=bool(j.get("conv_pos_batch_norm", False)) and fam == "hubert", **kw)
 
 
 class HuggingFaceWav2Vec2(nn.Module):
@@ -129,10 +146,18 @@ class HuggingFaceWav2Vec2(nn.Module):
         local_ckpt = None
         if cfg is None and isinstance(source, str) and os.path.isdir(source):
             cfg = _config_from_dir(source)
-            for fn in sorted(os.listdir(source)):
-                if fn.endswith(".bin") or fn.endswith(".ckpt"):
-                    local_ckpt = os.path.join(source, fn)
-                    break
+            # reference _check_model_source (:215-262): a directory with a *.bin is a HuggingFace model, otherwise the first
+            # *.ckpt is a SpeechBrain-pretrained one, otherwise FileNotFoundError.  (*.safetensors -- what current transformers
+            # writes -- is accepted as a HuggingFace model too.)
+            files = sorted(os.listdir(source))
+            hf = [fn for fn in files if fn.endswith(".bin")] or [fn for fn in files if fn.endswith(".safetensors")]
+            sb = [fn for fn in files if fn.endswith(".ckpt")]
+            if hf:
+                local_ckpt = os.path.join(source, hf[0])
+            elif sb:
+                local_ckpt = os.path.join(source, sb[0])
+            else:
+                raise FileNotFoundError(f"{source} does not contain a .bin or .ckpt checkpoint !")
             pp = os.path.join(source, "preprocessor_config.json")
             if normalize_wav is None and os.path.isfile(pp):
                 with open(pp) as fh:
@@ -178,21 +203,44 @@ class HuggingFaceWav2Vec2(nn.Module):
 
     # ------------------------------------------------------------------ checkpoint intake
     def _load_local(self, path: str) -> None:
-        sd = torch.load(path, map_location="cpu")
-        own = set(k for k, _ in self.model.named_parameters())
-        # the reference strips a "wav2vec2." prefix when reading SpeechBrain-format checkpoints (:181-215)
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            sd = torch.load(path, map_location="cpu")
+        own = set(self.model.state_dict().keys())
         out = {}
-        for k, v in sd.items():
-            for pre in ("", "model.", "wav2vec2.", "hubert."):
-                if k.startswith(pre) and k[len(pre):] in own:
-                    out[k[len(pre):]] = v
-                    break
+        if path.endswith(".ckpt"):
+            # SpeechBrain-pretrained (HuggingFaceWav2Vec2Pretrain) checkpoint: the reference keeps the keys that contain
+            # "wav2vec2." and strips "model.wav2vec2." (:181-191); everything else is discarded with a warning
+            for k, v in sd.items():
+                if "wav2vec2." in k:
+                    out[k.replace("model.wav2vec2.", "")] = v
+                else:
+                    logger.warning("The param with the key: %s is discarded as it is useless for wav2vec 2.0 finetuning.", k)
+        else:
+            # HuggingFace checkpoint: base-model keys, possibly under the task model's prefix (from_pretrained strips it)
+            for k, v in sd.items():
+                for pre in ("", "wav2vec2.", "hubert.", "data2vec_audio.", "wavlm.", "model."):
+                    if k.startswith(pre) and self._normalise_key(k[len(pre):]) in own:
+                        out[k[len(pre):]] = v
+                        break
+        missing = own - set(self._normalise_keys(out).keys())
+        for k in sorted(missing):
+            logger.warning("During parameter transfer loading from %s, the transferred parameters did not have parameters for "
+                           "the key: %s", path, k)
         self._load_model_state(out, strict=False)
 
     def _load_model_state(self, sd: Dict[str, torch.Tensor], strict: bool) -> None:
         sd = self._normalise_keys(sd)
         self.model.load_state_dict(sd, strict=strict)
         self._sig = None
+
+    @staticmethod
+    def _normalise_key(k: str) -> str:
+        pc = "encoder.pos_conv_embed.conv."
+        return {pc + "weight_g": pc + "parametrizations.weight.original0",
+                pc + "weight_v": pc + "parametrizations.weight.original1"}.get(k, k)
 
     def _normalise_keys(self, sd):
         """Accept both weight-norm spellings of the positional conv and drop the HF-only
@@ -223,7 +271,7 @@ class HuggingFaceWav2Vec2(nn.Module):
 
     # ------------------------------------------------------------------ device-side object
     def _params_signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        return tuple((p.data_ptr(), p._version) for p in list(self.model.parameters()) + list(self.model.buffers()))
 
     def _sync_device(self, device: torch.device) -> None:
         lib = _lib.load()
@@ -241,7 +289,9 @@ class HuggingFaceWav2Vec2(nn.Module):
             cc = _config_to_c(self.config, self.normalize_wav, self.output_norm, self.precision)
             _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
             self._handle, self._handle_dev = h, key
-        for name, p in self.model.named_parameters():
+        for name, p in self.model.state_dict().items():
+            if not p.is_floating_point():
+                continue  # BatchNorm's num_batches_tracked
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(lib.svt_encoder_load_param(self._handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,

@@ -50,6 +50,15 @@ def encoder_param_shapes(cfg: EncoderConfig, old_weight_norm_keys: bool = False)
     pc = "encoder.pos_conv_embed.conv"
     if cfg.pos_conv_depth > 1:
         pass
+    elif cfg.conv_pos_batch_norm:  # HF HubertPositionalConvEmbedding with conv_pos_batch_norm: plain conv, BatchNorm1d in front
+        sh[f"{pc}.weight"] = (D, D // g, kp)
+        sh[f"{pc}.bias"] = (D,)
+        bn = "encoder.pos_conv_embed.batch_norm"
+        sh[f"{bn}.weight"] = (D,)
+        sh[f"{bn}.bias"] = (D,)
+        sh[f"{bn}.running_mean"] = (D,)
+        sh[f"{bn}.running_var"] = (D,)
+        sh[f"{bn}.num_batches_tracked"] = ()
     elif old_weight_norm_keys:
         sh[f"{pc}.bias"] = (D,)
         sh[f"{pc}.weight_g"] = (1, 1, kp)
@@ -87,7 +96,13 @@ def encoder_param_shapes(cfg: EncoderConfig, old_weight_norm_keys: bool = False)
 def _draw(name: str, shape, gen: torch.Generator) -> torch.Tensor:
     x = torch.randn(shape, generator=gen, dtype=torch.float32)
     leaf = name.split(".")[-1]
-    if "layer_norm" in name or "norm" in name.split(".")[-2:-1]:
+    if leaf == "num_batches_tracked":
+        return torch.tensor(7, dtype=torch.int64)
+    if leaf == "running_var":
+        return 0.5 + x.abs()
+    if leaf == "running_mean":
+        return 0.3 * x
+    if "layer_norm" in name or "batch_norm" in name or "norm" in name.split(".")[-2:-1]:
         return 1.0 + 0.1 * x if leaf == "weight" else 0.1 * x
     if leaf == "bias":
         return 0.05 * x

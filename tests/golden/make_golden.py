@@ -80,7 +80,7 @@ def hf_model(cfg):
         m = Data2VecAudioModel(Data2VecAudioConfig(conv_pos_kernel_size=cfg.num_conv_pos_embeddings,
                                                    num_conv_pos_embeddings=cfg.pos_conv_depth, **kw))
     elif cfg.family == "hubert":
-        hc = HubertConfig(feat_proj_layer_norm=cfg.feat_proj_layer_norm, **kw)
+        hc = HubertConfig(feat_proj_layer_norm=cfg.feat_proj_layer_norm, conv_pos_batch_norm=cfg.conv_pos_batch_norm, **kw)
         m = HubertModel(hc)
     else:
         m = Wav2Vec2Model(Wav2Vec2Config(**kw))
@@ -427,6 +427,49 @@ def make_fbank_ext_cases():
     print("fbank_ext", [tuple(c["expect"].shape) for c in out["context"]])
 
 
+def make_local_dirs(hi):
+    """Local model directories as the reference's constructor accepts them (huggingface_interface.py:89-262): a HuggingFace
+    directory (config.json + preprocessor_config.json + pytorch_model.bin) per model class, and a SpeechBrain-pretrained one
+    (config.json + a *.ckpt whose keys carry the "model.wav2vec2." prefix).  The expected outputs come from the reference's
+    REAL constructor (from_pretrained on the directory) and forward."""
+    import shutil
+    import tempfile
+    from transformers import Wav2Vec2FeatureExtractor
+    root = os.path.join(HERE, "local_ckpt")
+    shutil.rmtree(root, ignore_errors=True)
+    cases = [("tiny-wav2vec2-hf", "tiny-group", "bin", True, 31), ("tiny-hubert-bn-hf", "tiny-hubert-bn", "bin", False, 32),
+             ("tiny-wavlm-hf", "tiny-wavlm", "bin", True, 33), ("tiny-data2vec-hf", "tiny-data2vec", "bin", True, 34),
+             ("tiny-wav2vec2-sb", "tiny-layer", "ckpt", True, 35)]
+    out = {}
+    for name, cfg_name, kind, do_norm, seed in cases:
+        cfg = PRESETS[cfg_name]
+        d = os.path.join(root, name)
+        os.makedirs(d)
+        sd = W.seeded_encoder_state_dict(cfg, seed=seed)
+        model = hf_model(cfg)
+        full = dict(model.state_dict())
+        full.update(sd)
+        model.load_state_dict(full, strict=True)
+        model.config.to_json_file(os.path.join(d, "config.json"))
+        Wav2Vec2FeatureExtractor(do_normalize=do_norm).save_pretrained(d)
+        if kind == "bin":
+            torch.save(model.state_dict(), os.path.join(d, "pytorch_model.bin"))
+        else:  # what HuggingFaceWav2Vec2Pretrain's checkpoint looks like: base model under "model.wav2vec2.", plus heads
+            ck = {"model.wav2vec2." + k: v for k, v in model.state_dict().items()}
+            ck["model.project_hid.weight"] = torch.zeros(4, cfg.hidden_size)
+            ck["model.quantizer.codevectors"] = torch.zeros(1, 8, 4)
+            torch.save(ck, os.path.join(d, "wav2vec2.ckpt"))
+        with tempfile.TemporaryDirectory() as tmp:
+            ref = hi.HuggingFaceWav2Vec2(source=d, save_path=tmp)
+        wav = synth_wav(2, 4000, seed=seed + 7)
+        with torch.no_grad():
+            y = ref(wav)
+        out[name] = dict(cfg=cfg_name, wav=wav, out=y.clone(), normalize_wav=bool(ref.normalize_wav),
+                         keys=sorted(ref.model.state_dict().keys()))
+        print(name, tuple(y.shape), "normalize_wav", ref.normalize_wav, type(ref.model).__name__)
+    torch.save(out, os.path.join(HERE, "local_ckpt.pt"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -445,6 +488,7 @@ def main():
         "large_c1": lambda: make_encoder_case(hi, utils, "large_c1", "wav2vec2-large-lv60", 1, 80000, 23, full=False),
         "hubert_large_c1": lambda: make_encoder_case(hi, utils, "hubert_large_c1", "hubert-large-ll60k", 1, 48000, 24,
                                                       full=False),
+        "tiny_hubert_bn": lambda: make_encoder_case(hi, utils, "tiny_hubert_bn", "tiny-hubert-bn", 2, 4000, 18),
         "tiny_wavlm": lambda: make_encoder_case(hi, utils, "tiny_wavlm", "tiny-wavlm", 2, 4000, 16),
         "tiny_wavlm_stable": lambda: make_encoder_case(hi, utils, "tiny_wavlm_stable", "tiny-wavlm-stable", 2, 4000, 17),
         "wavlm_base_c1": lambda: make_encoder_case(hi, utils, "wavlm_base_c1", "wavlm-base", 1, 48000, 26, full=False),
@@ -458,6 +502,7 @@ def main():
         "dataio": make_dataio_cases,
         "fbank_ext": make_fbank_ext_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),
+        "local_ckpt": lambda: make_local_dirs(hi),
     }
     for k, fn in jobs.items():
         if args.only and args.only != k:

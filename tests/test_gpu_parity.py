@@ -55,7 +55,7 @@ def check_decode(logits_gpu, fx, exact=True):
     return mism
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable", "tiny_hubert_bn"])
 def test_tiny_fp32_vs_reference_golden(golden, name):
     fx = golden(name)
     cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp32")
@@ -397,3 +397,21 @@ def test_hubert_base_layout_vs_oracle(prec, tol):
         ref = O.encoder_forward(sd, cfg, wav)
     assert out.shape == ref.shape
     assert (out - ref).abs().max() < tol
+
+
+LOCAL_DIRS = ["tiny-wav2vec2-hf", "tiny-hubert-bn-hf", "tiny-wavlm-hf", "tiny-data2vec-hf", "tiny-wav2vec2-sb"]
+
+
+@pytest.mark.parametrize("name", LOCAL_DIRS)
+def test_local_model_directory_like_the_reference_constructor(golden, name, tmp_path):
+    """Same constructor call on both sides: HuggingFaceWav2Vec2(source=<directory>, save_path=...).  The expected output is
+    the reference's own constructor (from_pretrained on that directory / SpeechBrain *.ckpt transfer) + forward
+    (tests/golden/make_golden.py make_local_dirs; reference huggingface_interface.py:89-262)."""
+    import os
+    fx = golden("local_ckpt")[name]
+    d = os.path.join(os.path.dirname(__file__), "golden", "local_ckpt", name)
+    enc = S.HuggingFaceWav2Vec2(d, str(tmp_path), precision="fp32").to(DEV)
+    assert enc.normalize_wav == fx["normalize_wav"]
+    y = enc(fx["wav"].to(DEV)).cpu()
+    assert y.shape == fx["out"].shape
+    assert (y - fx["out"]).abs().max().item() < 1e-3

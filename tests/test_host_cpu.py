@@ -307,3 +307,36 @@ def test_config_from_source_family_heuristics():
     for name, cfg in PRESETS.items():
         assert cfg.hidden_size % cfg.num_attention_heads == 0 and cfg.hidden_size % cfg.num_conv_pos_embedding_groups == 0, name
         assert len(W.encoder_param_shapes(cfg)) > 0
+
+
+@pytest.mark.parametrize("name", ["tiny-wav2vec2-hf", "tiny-hubert-bn-hf", "tiny-wavlm-hf", "tiny-data2vec-hf", "tiny-wav2vec2-sb"])
+def test_local_model_directory_config_and_weights(golden, name, tmp_path):
+    """Host side of the reference constructor's local-directory rules (huggingface_interface.py:215-262): config.json decides
+    the geometry, preprocessor_config.json the waveform norm, *.bin = HuggingFace weights, *.ckpt = SpeechBrain-pretrained
+    weights under "model.wav2vec2."; the parameter tree ends up with the reference model's keys and values."""
+    import dataclasses
+    import os
+    fx = golden("local_ckpt")[name]
+    d = os.path.join(os.path.dirname(__file__), "golden", "local_ckpt", name)
+    enc = S.HuggingFaceWav2Vec2(d, str(tmp_path))
+    want = dataclasses.asdict(PRESETS[fx["cfg"]])
+    got = dataclasses.asdict(enc.config)
+    for k in ("name", "family"):
+        want.pop(k), got.pop(k)
+    assert got == want
+    assert enc.normalize_wav == fx["normalize_wav"]
+    keys = [k for k in fx["keys"] if not k.endswith("masked_spec_embed")]
+    assert sorted(enc.model.state_dict().keys()) == keys
+    files = os.listdir(d)
+    ck = [f for f in files if f.endswith(".bin") or f.endswith(".ckpt")][0]
+    sd = torch.load(os.path.join(d, ck), map_location="cpu")
+    pre = "model.wav2vec2." if ck.endswith(".ckpt") else ""
+    for k, v in enc.model.state_dict().items():
+        assert torch.equal(v, sd[pre + k]), k
+
+
+def test_local_directory_without_checkpoint_raises_like_the_reference(tmp_path):
+    import json
+    (tmp_path / "config.json").write_text(json.dumps({"model_type": "wav2vec2"}))
+    with pytest.raises(FileNotFoundError, match="does not contain a .bin or .ckpt checkpoint"):
+        S.HuggingFaceWav2Vec2(str(tmp_path), str(tmp_path))

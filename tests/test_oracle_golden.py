@@ -40,7 +40,7 @@ def _run_case(fx):
     return cfg, feats, logits
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_hubert", "tiny_group_ragged", "tiny_data2vec", "tiny_wavlm", "tiny_wavlm_stable", "tiny_hubert_bn"])
 def test_oracle_tiny(golden, name):
     fx = golden(name)
     cfg, feats, logits = _run_case(fx)
