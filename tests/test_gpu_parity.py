@@ -415,3 +415,31 @@ def test_local_model_directory_like_the_reference_constructor(golden, name, tmp_
     y = enc(fx["wav"].to(DEV)).cpu()
     assert y.shape == fx["out"].shape
     assert (y - fx["out"]).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("cfg_name,B,L", [
+    ("wav2vec2-base", 1, 400),        # the receptive field exactly: ONE frame (every whole-batch statistic over a single row)
+    ("wav2vec2-base", 2, 719),        # still one frame, ragged tail samples that no conv window reaches
+    ("wav2vec2-base", 5, 16001),      # odd batch, odd length (T = 49)
+    ("wav2vec2-base", 1, 480000),     # 30 s clip: T = 1499 (3 key tiles more than the bench shape, odd T)
+    ("hubert-large-ll60k", 3, 24000), # pre-LN / layer-norm conv stack at an odd batch
+    ("wavlm-base", 2, 33333),         # relative position bias at T = 103
+])
+def test_odd_shapes_vs_oracle(cfg_name, B, L):
+    """Edge shapes against the oracle on the same seeded weights and input: fp32 features within 1e-3; bf16 within the
+    error bound of the bf16 mode."""
+    cfg = PRESETS[cfg_name]
+    sd = W.seeded_encoder_state_dict(cfg, seed=77)
+    wav = synth_wav(B, L, 78)
+    want = O.encoder_forward(sd, cfg, wav)
+    assert want.shape == (B, cfg.frames(L), cfg.hidden_size)
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=77).to(DEV)
+    got = enc(wav.to(DEV)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"{cfg_name} B={B} L={L} T={want.shape[1]}: fp32 max|err| {err:.2e}")
+    assert err < 1e-3
+    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=77).to(DEV)
+    got16 = enc16(wav.to(DEV)).cpu()
+    d = (got16 - want).abs()
+    print(f"   bf16 mean|err| {d.mean():.4f} max {d.max():.3f}")
+    assert torch.isfinite(got16).all() and d.mean() < 0.08
