@@ -320,6 +320,8 @@ int svt_debug_set(int key, int value) {
   else if (key == 2) g_gemm_ring = value;
   else if (key == 3) g_gemm_variant = value;
   else if (key == 5) g_fuse_outproj_ln = value;
+  else if (key == 6) g_gemm_skinny = value;
+  else if (key == 7) g_gemm_skinny_max_tiles = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -876,7 +878,8 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
       const bool last = l + 1 == c.num_layers;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
       if (int r = attention()) return r;
-      if (outproj_ln_eligible(D, D) && g_fuse_outproj_ln) {
+      // (64 rows per workgroup: below ~190 workgroups the fused kernel leaves CUs idle and the two-kernel form is faster)
+      if (outproj_ln_eligible(D, D) && g_fuse_outproj_ln && rows >= 12288) {
         // out-projection + residual + LayerNorm in one kernel (gemm_ln.hip): the projection result never leaves registers
         if (int r = launch_outproj_ln(w.attn_o, D, Lw.wo.p, Lw.bo.as<float>(), xh, xl, (int)rows, D, Lw.ln1g.as<float>(),
                                       Lw.ln1b.as<float>(), eps, xh, xl, nullptr, s)) return r;

@@ -154,6 +154,11 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
 // large-tile LDS-DMA variant (bf16, K % 64 == 0); launch_gemm dispatches to it
 bool gemm_dma_eligible(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
+// small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
+bool gemm_skinny_eligible(const GemmArgs& a);
+int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
+extern int g_gemm_skinny_max_tiles;
+extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
 extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debug_set)
 extern int g_gemm_force_bm;
 extern int g_gemm_ring;

@@ -344,6 +344,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int g_gemm_skinny = 1;
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
   const int epp = prec ? 8 : 4;
@@ -373,6 +374,7 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
     if (prec) return narrow ? launch_one<bf16_t, 256, 64, true>(g, s) : launch_one<bf16_t, 128, 128, true>(g, s);
     return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);
   }
+  if (prec && g_gemm_skinny && gemm_skinny_eligible(g)) return launch_gemm_skinny(g, s);
   if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
   return narrow ? launch_one<float, 256, 64>(g, s) : launch_one<float, 128, 128>(g, s);

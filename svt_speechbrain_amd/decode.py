@@ -75,6 +75,56 @@ def frame2note(frame_info: Sequence, onset_thres: float, offset_thres: float, fr
     return notes
 
 
+def frames2note(frames: np.ndarray, onset_thres: float, offset_thres: float, frame_size: float = 1 / 49.8) -> List[list]:
+    """``frame2note`` on the structured frame array ``decode_frames`` returns, without the per-frame Python loop: the onset
+    test (threshold and +-3-frame local maximum, window clipped to N-1) and the offset test are evaluated for all frames at
+    once in float32, the scan then visits only the event frames, and the pitch of a note is still CPython's
+    ``max(set(c), key=c.count)`` on the same list the reference builds.  Same results as ``frame2note`` (tested on random and
+    adversarial sequences); a 3-minute song (9 000 frames) takes ~1 ms instead of ~15 ms."""
+    n = int(frames.shape[0])
+    if n == 0:
+        return []
+    p_on = np.ascontiguousarray(frames["p_on"], dtype=np.float32)
+    p_off = np.ascontiguousarray(frames["p_off"], dtype=np.float32)
+    octv = frames["octave"].astype(np.int64)
+    pc = frames["pitch_class"].astype(np.int64)
+    above = p_on >= np.float32(onset_thres)
+    if n == 1:
+        if above[0]:
+            np.amax(p_on[0:0])  # the reference's empty window: ValueError
+        wmax = p_on
+    else:
+        pad = np.full(n + 6, -np.inf, dtype=np.float32)
+        pad[3:3 + n - 1] = p_on[:n - 1]  # the windows never contain the last frame (upper bound min(i + 4, N - 1))
+        wmax = np.lib.stride_tricks.sliding_window_view(pad, 7)[:n].max(axis=1)
+    onset = above & (p_on == wmax)
+    offset = (~onset) & (p_off >= np.float32(offset_thres))
+    valid = (octv != 4) & (pc != 12)
+    pitch = octv * 12 + pc
+    notes: List[list] = []
+    t_on = None
+    i_open = 0
+
+    def close(i_close: int, now: float) -> None:
+        sel = valid[i_open:i_close]
+        if sel.any():
+            bag = pitch[i_open:i_close][sel].tolist()
+            notes.append([t_on, now, max(set(bag), key=bag.count) + 36])
+
+    for i in np.flatnonzero(onset | offset).tolist():
+        now = frame_size * i
+        if onset[i]:
+            if t_on is not None:
+                close(i, now)
+            t_on, i_open = now, i
+        elif t_on is not None:
+            close(i, now)
+            t_on = None
+    if t_on is not None:
+        close(n, frame_size * (n - 1))
+    return notes
+
+
 def filter_ctc_output(string_pred, blank_id=-1):
     if not isinstance(string_pred, list):
         raise ValueError("filter_ctc_out can only filter python lists")

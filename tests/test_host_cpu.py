@@ -340,3 +340,49 @@ def test_local_directory_without_checkpoint_raises_like_the_reference(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps({"model_type": "wav2vec2"}))
     with pytest.raises(FileNotFoundError, match="does not contain a .bin or .ckpt checkpoint"):
         S.HuggingFaceWav2Vec2(str(tmp_path), str(tmp_path))
+
+
+def test_frames2note_equals_the_frame_loop(golden):
+    """The vectorised note assembly against the literal frame loop (itself pinned to the reference by the frame2note golden):
+    the golden cases, random sequences with plateaus / exact-threshold values / pitch ties, and the edge lengths."""
+    import time
+    from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note
+
+    def pack(p_on, p_off, octv, pc):
+        fr = np.zeros(len(p_on), dtype=FRAME_DTYPE)
+        fr["p_on"], fr["p_off"], fr["octave"], fr["pitch_class"] = p_on, p_off, octv, pc
+        return fr
+
+    for k, c in golden("frame2note").items():
+        fr = pack(c["p_on"].numpy(), c["p_off"].numpy(), c["oct"].numpy(), c["pc"].numpy())
+        assert frames2note(fr, 0.4, 0.5, 1 / 49.8) == c["notes"], k
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n = int(rng.integers(0, 400)) if trial else 9000
+        # coarse grid of probabilities: many exact ties, values exactly on both thresholds
+        grid = np.array([0.0, 0.1, 0.4, 0.5, 0.7, 0.7, 0.9, 1.0], dtype=np.float32)
+        p_on = grid[rng.integers(0, len(grid), n)] * (rng.random(n) < 0.3)
+        p_off = grid[rng.integers(0, len(grid), n)] * (rng.random(n) < 0.2)
+        octv = rng.integers(0, 5, n)
+        pc = rng.integers(0, 13, n)
+        if trial % 3 == 0:  # long notes with few distinct pitches -> mode ties
+            octv = np.repeat(rng.integers(0, 5, n // 7 + 1), 7)[:n]
+            pc = np.repeat(rng.integers(0, 13, n // 3 + 1), 3)[:n]
+        fr = pack(p_on.astype(np.float32), p_off.astype(np.float32), octv, pc)
+        if n == 1 and p_on[0] >= np.float32(0.4):
+            with pytest.raises(ValueError):
+                frames2note(fr, 0.4, 0.5)
+            continue
+        t0 = time.time()
+        want = S.frame2note(S.frames_to_info(fr), 0.4, 0.5, 1 / 49.8)
+        t1 = time.time()
+        got = frames2note(fr, 0.4, 0.5, 1 / 49.8)
+        t2 = time.time()
+        assert got == want, (trial, n)
+        if n == 9000:
+            print(f"9000 frames: loop {1e3 * (t1 - t0):.1f} ms, vectorised {1e3 * (t2 - t1):.1f} ms, {len(got)} notes")
+    one = pack(np.float32([0.9]), np.float32([0.1]), [1], [1])
+    with pytest.raises(ValueError):
+        frames2note(one, 0.4, 0.5)
+    assert frames2note(pack(np.float32([0.1]), np.float32([0.1]), [1], [1]), 0.4, 0.5) == []
+    assert frames2note(pack([], [], [], []), 0.4, 0.5) == []

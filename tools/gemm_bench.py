@@ -19,6 +19,19 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("ffn1", 15968, 3072, 768, None, 1, 0, 0),
     ("ffn2", 15968, 768, 3072, None, 0, 1, 0),
     ("large_ffn1", 31936, 4096, 1024, None, 1, 0, 0),
+    ("b1_qkv", 249, 2304, 768, None, 0, 0, 0),       # one 5 s utterance (the recipes' evaluation batch)
+    ("b1_out", 249, 768, 768, None, 0, 0, 0),
+    ("b1_ffn1", 249, 3072, 768, None, 1, 0, 0),
+    ("b1_ffn2", 249, 768, 3072, None, 0, 0, 0),
+    ("b1_ffn2r", 249, 768, 3072, None, 0, 1, 1),
+    ("b1_conv5", 499, 512, 1024, (999, 499, 2, 512), 1, 0, 0),
+    ("b2_ffn2", 998, 768, 3072, None, 0, 0, 0),
+    ("b2_ffn1", 998, 3072, 768, None, 1, 0, 0),
+    ("b4_ffn2", 1996, 768, 3072, None, 0, 0, 0),
+    ("b4_ffn1", 1996, 3072, 768, None, 1, 0, 0),
+    ("b4_out", 1996, 768, 768, None, 0, 0, 0),
+    ("b8_ffn2", 3992, 768, 3072, None, 0, 0, 0),
+    ("b8_out", 3992, 768, 768, None, 0, 0, 0),
     ("sq4096", 4096, 4096, 4096, None, 0, 0, 0),
     ("sq8192", 8192, 8192, 8192, None, 0, 0, 0),
 ]
@@ -59,9 +72,10 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nob
             T_in, T_out, st, cin = conv
             k = K // cin
             idx = (torch.arange(T_out, device=dev) * st)[:, None] + torch.arange(k, device=dev)[None, :]
-            A2 = A[:2, idx].reshape(2 * T_out, K).float()
+            nb = min(2, B)
+            A2 = A[:nb, idx].reshape(nb * T_out, K).float()
             ref = A2 @ W[:, :K].float().t() + bias
-            got = C[: 2 * T_out].float()
+            got = C[: nb * T_out].float()
         else:
             rows = min(M, 4096)
             ref = A[:rows, :K].float() @ W[:, :K].float().t() + bias
@@ -92,12 +106,16 @@ if __name__ == "__main__":
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--no-skinny", action="store_true", help="small problems on the large-tile kernels (A/B)")
+    ap.add_argument("--skinny-max-tiles", type=int, default=32)
     ap.add_argument("--nobias", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
     _lib.load().svt_debug_set(1, a.bm)
     _lib.load().svt_debug_set(2, a.ring)
+    _lib.load().svt_debug_set(6, 0 if a.no_skinny else 1)
+    _lib.load().svt_debug_set(7, a.skinny_max_tiles)
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
