@@ -219,6 +219,10 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * hidden_states; hidden_states = self.layer_norm(hidden_states)` (HF modeling_wav2vec2.py:575-590); test hook. */
 int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const void* rh, const void* rl, int32_t m, int32_t k,
                          const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yf, int device, void* stream);
+/* Diagnostics switches of the contraction kernels (tools/gemm_bench.py, tools/gemm_trace.py; never needed in production):
+ * key 0 = kernel ablation variant, 1 = force the tile height (64/128/192/256), 2 = force the one-tile (2) / persistent (4)
+ * scheduler, 3 = ablation variant while tracing, 5 = fused out-projection + LayerNorm on/off, 6 = small-problem kernel
+ * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles.  Returns 0. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

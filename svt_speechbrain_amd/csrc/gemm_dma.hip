@@ -767,10 +767,10 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   a.dbg = g_gemm_dbg;
   if (a.dbg == 9) { a.trace = (long long*)a.resid; a.resid = nullptr; if (g_gemm_variant) a.dbg = g_gemm_variant; }
   const int tiles_n = (a.N + 255) / 256;
-  const int cands[3] = {256, 192, 128};
+  const int cands[4] = {256, 192, 128, 64};
   long best_cost = -1;
   int best = 256;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int bm = cands[i];
     const long blocks = (long)((a.M + bm - 1) / bm) * tiles_n * a.nz;
     const long rounds = (blocks + 255) / 256;
@@ -799,10 +799,10 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     if (best == 128) return launch_pers<128>(a, s);
     return launch_pers<64>(a, s);
   }
-  if (best == 64) best = 128;
   if (best == 256) return launch_pp8<256>(a, s);
   if (best == 192) return launch_pp8<192>(a, s);
-  return launch_pp8<128>(a, s);
+  if (best == 128) return launch_pp8<128>(a, s);
+  return launch_pp8<64>(a, s);  // mid-size problems (2-16 utterances): twice the workgroups of the 128-row tile
 }
 
 }  // namespace svt
