@@ -386,3 +386,15 @@ def test_frames2note_equals_the_frame_loop(golden):
         frames2note(one, 0.4, 0.5)
     assert frames2note(pack(np.float32([0.1]), np.float32([0.1]), [1], [1]), 0.4, 0.5) == []
     assert frames2note(pack([], [], [], []), 0.4, 0.5) == []
+
+
+def test_plain_c_caller_of_the_cabi_compiles(tmp_path):
+    """tests/cabi/cabi_driver.c (C11, no torch, no Python) builds against include/svt_mi355.h with gcc; it runs in the GPU suite."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "cabi_driver")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(os.path.dirname(here), "include"), "-I", "/opt/rocm/include",
+                        os.path.join(here, "cabi", "cabi_driver.c"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
+                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)
