@@ -1,7 +1,9 @@
 """Summarise rocprofv3 --pmc passes (one directory per pass) per kernel: mean counter value per launch.
 Usage: python tools/pmc_summary.py <dir> [<dir> ...] [--json out.json]
 FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE counts a wide coalesced 128-byte read request as 64 bytes
-(MI355X_MICROARCH.md, HBM section): `hbm_bytes_per_launch` = 2 * FETCH_SIZE + WRITE_SIZE, in bytes."""
+(MI355X_MICROARCH.md, HBM section): `hbm_bytes_per_launch` = 2 * FETCH_SIZE + WRITE_SIZE, in bytes.
+With SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in one pass: the fraction of the kernel's cycles (dispatch to completion, at the clock
+the chip holds) in which the matrix pipes are busy, and the bf16 FLOPs the counter implies."""
 import collections
 import csv
 import glob
@@ -37,6 +39,10 @@ def main():
         e = {"launches": max(len(v) for v in c.values())}
         for n, v in c.items():
             e[n + "_mean"] = sum(v) / len(v)
+        if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in e and e.get("GRBM_GUI_ACTIVE_mean"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs (MI355X_MICROARCH.md, PMC notes)
+            e["mfma_busy_frac_of_kernel_cycles"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (1024.0 * e["GRBM_GUI_ACTIVE_mean"] / 8.0)
+            e["mfma_tflop_per_launch"] = e["SQ_VALU_MFMA_BUSY_CYCLES_mean"] * 1024 / 1e12  # 1024 bf16 FLOP per busy cycle
         if "FETCH_SIZE_mean" in e and "WRITE_SIZE_mean" in e:
             e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_mean"] + e["WRITE_SIZE_mean"]) * 1024
         res[k] = e
