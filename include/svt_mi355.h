@@ -228,6 +228,7 @@ int svt_debug_set(int key, int value);
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----
  * When enabled, forward calls bracket every launch of the dense contraction kernel with hipEvents on
  * the launch stream; svt_prof_read returns accumulated launches / milliseconds / algorithmic flops. */
+/* on = 0: off; 1: a HIP-event pair around every dense-contraction / attention launch; n > 1: around every n-th one */
 int svt_prof_enable(int on);
 int svt_prof_reset(void);
 /* kind: 0 = svt::gemm_uring_kernel (the dominant kernel: every large bf16 dense contraction), 1 = the other dense

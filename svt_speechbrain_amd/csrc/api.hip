@@ -24,6 +24,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 // ---------------------------------------------------------------- profiling (dominant kernel)
 struct ProfState {
   bool on = false;
+  int every = 1;        // record every `every`-th launch (sampling keeps the event pairs out of most launches of a timed region)
+  unsigned tick = 0;
+  bool armed = false;   // prof_begin recorded a start event for the launch in flight
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
   std::vector<int> kind;
@@ -32,7 +35,10 @@ struct ProfState {
 };
 static ProfState g_prof;
 void prof_begin(hipStream_t s) {
+  g_prof.armed = false;
   if (!g_prof.on || g_prof.used >= ProfState::kMax) return;
+  if (g_prof.every > 1 && (g_prof.tick++ % (unsigned)g_prof.every) != 0) return;
+  g_prof.armed = true;
   if (g_prof.used == g_prof.ev.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof.on = false; return; }
@@ -41,7 +47,8 @@ void prof_begin(hipStream_t s) {
   (void)hipEventRecord(g_prof.ev[g_prof.used].first, s);
 }
 void prof_end(hipStream_t s, double flops, double bytes, int kind) {
-  if (!g_prof.on || g_prof.used >= g_prof.ev.size()) return;
+  if (!g_prof.on || !g_prof.armed || g_prof.used >= g_prof.ev.size()) return;
+  g_prof.armed = false;
   (void)hipEventRecord(g_prof.ev[g_prof.used].second, s);
   if (g_prof.kind.size() <= g_prof.used) g_prof.kind.resize(g_prof.used + 1);
   g_prof.kind[g_prof.used] = kind;
@@ -326,7 +333,7 @@ int svt_debug_set(int key, int value) {
   return SVT_OK;
 }
 
-int svt_prof_enable(int on) { g_prof.on = on != 0; return SVT_OK; }
+int svt_prof_enable(int on) { g_prof.on = on != 0; g_prof.every = on > 1 ? on : 1; g_prof.tick = 0; return SVT_OK; }
 int svt_prof_reset(void) {
   g_prof.used = 0;
   for (int k = 0; k < 3; ++k) g_prof.flops[k] = g_prof.bytes[k] = 0;
