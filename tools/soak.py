@@ -1,0 +1,43 @@
+"""Race / stability soak: the same forward N times (alternating two streams over two replicas), every output compared with the
+first one.  The whole-batch norms accumulate with fp64 atomics, so the last bits may move (<= ~1e-5); anything larger is a
+race (a missing barrier or wait in a kernel shows up as a rare large difference)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import svt_speechbrain_amd as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="wav2vec2-base")
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--seconds", type=float, default=10.0)
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--precision", default="bf16")
+a = ap.parse_args()
+dev = "cuda:0"
+cfg = S.PRESETS[a.model]
+enc = S.HuggingFaceWav2Vec2(a.model, None, config=cfg, precision=a.precision, seed=3).to(dev)
+encs = [enc, enc.replica()]
+streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+g = torch.Generator().manual_seed(9)
+wav = (0.1 * torch.randn(a.batch, int(16000 * a.seconds), generator=g)).clamp_(-1, 1).to(dev)
+ref = enc(wav).clone()
+torch.cuda.synchronize()
+worst, bad = 0.0, 0
+t0 = time.time()
+outs = []
+for i in range(a.iters):
+    k = i % 2
+    with torch.cuda.stream(streams[k]):
+        y = encs[k](wav)
+        d = (y - ref).abs().max()
+    outs.append(d)
+    if len(outs) == 20 or i + 1 == a.iters:
+        torch.cuda.synchronize()
+        for d in outs:
+            v = d.item()
+            worst = max(worst, v)
+            bad += v > 1e-4
+        outs = []
+print(f"{a.model} B={a.batch} {a.seconds:g}s {a.precision}: {a.iters} forwards in {time.time() - t0:.1f} s, max |y - y0| = {worst:.3e}, "
+      f"{bad} forwards above 1e-4")
+sys.exit(1 if bad else 0)
