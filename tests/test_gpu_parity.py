@@ -224,7 +224,8 @@ def test_errors_are_exceptions():
         enc(torch.zeros(4000, device=DEV))
 
 
-@pytest.mark.parametrize("cfg_name,B,L", [("wav2vec2-base", 4, 160000), ("wav2vec2-base", 3, 52345)])
+@pytest.mark.parametrize("cfg_name,B,L", [("wav2vec2-base", 4, 160000), ("wav2vec2-base", 3, 52345),
+                                          ("wav2vec2-base", 32, 160000)])  # the last one is BASELINE config C2 itself
 def test_full_size_properties(cfg_name, B, L):
     """Size-independent properties at BASELINE sizes (oracle too slow to run per test):
     determinism (bitwise), whole-batch output norm (zero mean / unit variance), permutation equivariance
