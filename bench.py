@@ -127,10 +127,13 @@ def main():
     counter = [0]
     active = [ns]  # streams in use (the roofline leg sets this to 1)
 
+    import contextlib
+
     def step():
         i = counter[0] % active[0]
         counter[0] += 1
-        with torch.cuda.stream(streams[i]):
+        # one stream: launch on whatever stream is current (during hipGraph capture that is the capture stream)
+        with (torch.cuda.stream(streams[i]) if ns > 1 else contextlib.nullcontext()):
             feats = encs[i](wav)
             logits = head(feats)
             _lib.check(lib.svt_decode_frames(_lib.ptr(logits), B * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
@@ -181,6 +184,9 @@ def main():
     lib.svt_prof_enable(0)
     elapsed = D.max_over_ranks(elapsed, world, dev)
     assert out.shape[0] == n_total
+    # a step is >= ~110 kernels: anything faster than this did not run the work (e.g. an empty captured graph)
+    if 1e3 * elapsed / args.steps < 0.05:
+        raise SystemExit("[bench] implausible step time: the timed region did not execute the step")
 
     def prof(kind):
         n, ms_, fl_, by_ = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
