@@ -115,6 +115,13 @@ int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t
 /* replaces: HuggingFaceWav2Vec2.extract_features (:279-297): wav f32 (B,L) -> feats f32 (B,T,D) */
 int svt_encoder_forward(svt_encoder* e, const float* wav_dev, int32_t batch, int64_t n_samples,
                         float* feats_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Same, with the wrapper's two whole-tensor layer norms (huggingface_interface.py:289-295) taken over groups of
+ * `clips_per_norm_group` consecutive clips instead of the whole batch (0 = whole batch = svt_encoder_forward).  With 1, a batch
+ * of B equal-length clips gives what B batch-1 calls give: the reference's evaluation loop (MIR_ST500/train_audio_ssl.py:90
+ * asserts batch 1; utterances of a song are 5 s each) run as ONE batch.  batch must be a multiple of the group size. */
+int svt_encoder_forward_ex(svt_encoder* e, const float* wav_dev, int32_t batch, int64_t n_samples,
+                           float* feats_dev, void* workspace_dev, size_t workspace_bytes, void* stream,
+                           int32_t clips_per_norm_group);
 
 /* ---- frame head + per-frame decode: replaces speechbrain.nnet.linear.Linear (linear.py:41-76)
  *      and the sigmoid/argmax loop (train_audio_ssl.py:41-46,93-100) ---- */

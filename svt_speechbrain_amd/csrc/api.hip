@@ -640,7 +640,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   const size_t es = esize(c.precision);
   Carver cv(base);
   EncWs w;
-  w.mom_bytes = align_up((4 + (size_t)B * 65) * sizeof(double));
+  w.mom_bytes = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments
   w.mom = (double*)cv.take(w.mom_bytes);
   w.coef = (float*)cv.take((size_t)B * c.conv_dim[0] * 11 * 4);
   size_t max_act = 0, max_f = 0;
@@ -697,6 +697,11 @@ int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t
 
 int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, float* feats, void* workspace,
                         size_t workspace_bytes, void* stream) {
+  return svt_encoder_forward_ex(e, wav, B, L, feats, workspace, workspace_bytes, stream, 0);
+}
+
+int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t L, float* feats, void* workspace,
+                           size_t workspace_bytes, void* stream, int32_t clips_per_norm_group) {
   if (!e || !wav || !feats || !workspace) { set_error("encoder_forward: null argument"); return SVT_ERR_INVALID; }
   if (!e->finalized) { set_error("encoder_forward: parameters not finalized"); return SVT_ERR_STATE; }
   if (B < 1) { set_error("encoder_forward: batch < 1"); return SVT_ERR_INVALID; }
@@ -708,13 +713,23 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   if (w.total > workspace_bytes) { set_error("encoder_forward: workspace too small (" + std::to_string(workspace_bytes) + " < " + std::to_string(w.total) + ")"); return SVT_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   SVT_HIP(hipSetDevice(e->device));
+  // the wrapper's two whole-tensor layer norms run over groups of `cpg` consecutive clips: cpg = B is the reference on a
+  // batch (and per device shard under DataParallel / DDP), cpg = 1 makes a batch of B clips equal to B batch-1 forwards --
+  // the reference's evaluation loop (train_audio_ssl.py:90 asserts batch 1) without its one-utterance-at-a-time cost
+  const int cpg = clips_per_norm_group > 0 ? clips_per_norm_group : B;
+  if (B % cpg) { set_error("encoder_forward: batch must be a multiple of clips_per_norm_group"); return SVT_ERR_INVALID; }
+  const int groups = B / cpg;
+  if (groups > 1 && ((L & 3) || c.num_conv_layers == 0)) {
+    set_error("encoder_forward: norm groups need a waveform length that is a multiple of 4 samples");
+    return SVT_ERR_INVALID;
+  }
   SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_bytes, s));
   double* wav_mom = c.normalize_wav ? w.mom : nullptr;
-  double* out_mom = w.mom + 2;
-  double* wm = w.mom + 4;
-  const int64_t n_wav = (int64_t)B * L;
+  double* out_mom = w.mom + 2 * (size_t)B;
+  double* wm = w.mom + 4 * (size_t)B;
+  const int64_t n_wav = (int64_t)cpg * L;
   if (c.normalize_wav)
-    if (int r = launch_moments(wav, n_wav, wav_mom, s)) return r;
+    if (int r = launch_moments(wav, n_wav, wav_mom, s, groups)) return r;
 
   // ---- conv feature extractor (channels-last activations) ----
   int64_t tin = L;
@@ -731,13 +746,13 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
     if (int r = launch_conv0_window_moments(wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, wm, s)) return r;
     if (int r = launch_conv0_group_coef(wav_mom, n_wav, wm, B, t1, c.conv_dim[0], c.conv_kernel[0], c0.w.as<float>(),
                                         c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
-                                        c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s)) return r;
+                                        c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s, cpg)) return r;
     if (int r = launch_conv0_group_apply(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], w.coef,
                                          w.act[0], s)) return r;
   } else {
     if (int r = launch_conv0_layer(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], wav_mom, n_wav,
                                    1e-5f, c0.w.as<float>(), c.conv_bias ? c0.bias.as<float>() : nullptr,
-                                   c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s)) return r;
+                                   c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s, cpg)) return r;
   }
   tin = t1;
   }
@@ -948,8 +963,8 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
   // ---- wrapper's whole-batch output LayerNorm ----
   const int64_t n_out = rows * D;
   if (c.output_norm) {
-    if (int r = launch_moments(final_x, n_out, out_mom, s)) return r;
-    if (int r = launch_global_norm(final_x, feats, n_out, out_mom, 1e-5f, s)) return r;
+    if (int r = launch_moments(final_x, n_out / groups, out_mom, s, groups)) return r;
+    if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups)) return r;
   } else {
     SVT_HIP(hipMemcpyAsync(feats, final_x, (size_t)n_out * 4, hipMemcpyDeviceToDevice, s));
   }

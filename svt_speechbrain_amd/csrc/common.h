@@ -172,9 +172,9 @@ void prof_end(hipStream_t s, double flops, double bytes, int kind = 1);
 // ---- elementwise / reduction kernels (kernels.hip) ----
 int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // moments[0] += sum(x), moments[1] += sum(x^2) over n fp32 values (fp64 accumulation); caller zeroes moments
-int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s);
+int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
 // y = (x - mean) * rsqrt(var + eps) from global moments over n elements (no affine)
-int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s);
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups = 1);
 
 // row LayerNorm over D: in fp32 or operand type; outputs: yT (operand type, may be null) and yF (fp32, may be null)
 // optional `add` (fp32, same shape) is summed into x before the statistics (residual add fused into the norm);
@@ -189,13 +189,13 @@ int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int s
 int launch_conv0_group_coef(const double* wav_moments /*2, or null*/, int64_t n_wav, const double* wm, int B,
                             int64_t T1, int C, int k, const float* w0 /*C x k*/, const float* b0 /*C or null*/,
                             const float* gamma, const float* beta, float eps_wav, float eps_gn,
-                            float* coef /*B x C x (k+1)*/, hipStream_t s);
+                            float* coef /*B x C x (k+1)*/, hipStream_t s, int clips_per_norm_group);  // wav_moments: 2 per group
 int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
                              const float* coef, void* out /*B x T1 x C*/, hipStream_t s);
 // conv layer 0 in "layer" mode: conv + bias + LayerNorm over channels + GELU
 int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
                        const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
-                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s);
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int clips_per_norm_group);
 
 // positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front
 int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s,

@@ -35,8 +35,11 @@ __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, int64_t n) {
 }
 
 // sum / sum of squares in fp64 (two whole-batch layer norms of the wrapper)
+// blockIdx.y = norm group: group g covers x[g*n, (g+1)*n) and accumulates into mom[2g], mom[2g+1]
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n, double* mom) {
   __shared__ double sh[2][4];
+  x += (int64_t)blockIdx.y * n;
+  mom += 2 * blockIdx.y;
   double s = 0.0, ss = 0.0;
   const int64_t n4 = n >> 2;
   const float4* x4 = (const float4*)x;
@@ -65,6 +68,9 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n,
 }
 
 __global__ void global_norm_kernel(const float* x, float* y, int64_t n, const double* mom, float eps) {
+  x += (int64_t)blockIdx.y * n;
+  y += (int64_t)blockIdx.y * n;
+  mom += 2 * blockIdx.y;
   const double mean = mom[0] / (double)n;
   const double var = mom[1] / (double)n - mean * mean;
   const float mu = (float)mean;
@@ -292,8 +298,9 @@ __global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* 
 
 __global__ void conv0_group_coef_kernel(const double* wav_mom, int64_t n_wav, const double* wm, int64_t T1, int C,
                                         const float* w0, const float* b0, const float* gamma, const float* beta,
-                                        float eps_wav, float eps_gn, float* coef) {
+                                        float eps_wav, float eps_gn, float* coef, int cpg) {
   const int b = blockIdx.y;
+  if (wav_mom) wav_mom += 2 * (b / cpg);  // the waveform norm group of this clip
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double mu = 0.0, r = 1.0;
@@ -396,9 +403,10 @@ template <typename TO>
 __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int64_t L, int stride, int64_t T1, int C,
                                                           const double* wav_mom, int64_t n_wav, float eps_wav,
                                                           const float* w0, const float* b0, const float* gamma,
-                                                          const float* beta, float eps, TO* out) {
+                                                          const float* beta, float eps, TO* out, int cpg) {
   constexpr int FPW = 16;
   const int b = blockIdx.y;
+  if (wav_mom) wav_mom += 2 * (b / cpg);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * FPW;
   if (t0 >= T1) return;
@@ -1004,14 +1012,17 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
   return 0;
 }
 
-int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s) {
-  hipLaunchKernelGGL(moments_kernel, dim3(grid_for(n / 4 + 1, 256, 512)), dim3(256), 0, s, x, n, moments);
+int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups) {
+  if (groups > 1 && (n & 3)) { set_error("moments: per-group length must be a multiple of 4 elements"); return -1; }
+  const int gx = groups > 1 ? grid_for(n / 4 + 1, 256, 512 / (groups < 64 ? groups : 64) + 1) : grid_for(n / 4 + 1, 256, 512);
+  hipLaunchKernelGGL(moments_kernel, dim3(gx, groups), dim3(256), 0, s, x, n, moments);
   SVT_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(global_norm_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, y, n, moments, eps);
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups) {
+  if (groups > 1 && (n & 3)) { set_error("global_norm: per-group length must be a multiple of 4 elements"); return -1; }
+  hipLaunchKernelGGL(global_norm_kernel, dim3(grid_for(n / 4 + 1), groups), dim3(256), 0, s, x, y, n, moments, eps);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -1100,11 +1111,11 @@ int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int s
 
 int launch_conv0_group_coef(const double* wav_moments, int64_t n_wav, const double* wm, int B, int64_t T1, int C,
                             int k, const float* w0, const float* b0, const float* gamma, const float* beta,
-                            float eps_wav, float eps_gn, float* coef, hipStream_t s) {
+                            float eps_wav, float eps_gn, float* coef, hipStream_t s, int cpg) {
   if (k != K0) { set_error("conv layer 0 kernel size must be 10"); return -1; }
   dim3 grid((C + 63) / 64, B);
   hipLaunchKernelGGL(conv0_group_coef_kernel, grid, dim3(64), 0, s, wav_moments, n_wav, wm, T1, C, w0, b0, gamma, beta,
-                     eps_wav, eps_gn, coef);
+                     eps_wav, eps_gn, coef, cpg);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -1125,15 +1136,15 @@ int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k
 
 int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
                        const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
-                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s) {
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int cpg) {
   if (k != K0 || C > 512 || C % 8) { set_error("conv0: unsupported geometry"); return -1; }
   dim3 grid((unsigned)((T1 + 63) / 64), B);
   if (prec)
     hipLaunchKernelGGL((conv0_layer_kernel<bf16_t>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav,
-                       eps_wav, w0, b0, gamma, beta, eps, (bf16_t*)out);
+                       eps_wav, w0, b0, gamma, beta, eps, (bf16_t*)out, cpg);
   else
     hipLaunchKernelGGL((conv0_layer_kernel<float>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav,
-                       eps_wav, w0, b0, gamma, beta, eps, (float*)out);
+                       eps_wav, w0, b0, gamma, beta, eps, (float*)out, cpg);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -330,15 +330,18 @@ class HuggingFaceWav2Vec2(nn.Module):
         return self.config.frames(n_samples)
 
     # ------------------------------------------------------------------ forward (reference :263-297)
-    def forward(self, wav: torch.Tensor) -> torch.Tensor:
+    def forward(self, wav: torch.Tensor, clips_per_norm_group: int = 0) -> torch.Tensor:
+        """``clips_per_norm_group`` (extension; 0 = the reference: both whole-tensor layer norms over the entire batch):
+        with 1, a batch of B equal-length utterances returns what B batch-1 forwards return, which is how the reference
+        evaluates (``train_audio_ssl.py:90`` asserts batch 1) -- one batched launch sequence instead of B."""
         if not self.freeze and torch.is_grad_enabled() and not self._warned_grad:
             warnings.warn("svt_speechbrain_amd.HuggingFaceWav2Vec2 is forward-only: the output is detached "
                           "(fine-tuning the encoder is out of scope of the MI355X path)")
             self._warned_grad = True
         with torch.no_grad():
-            return self.extract_features(wav).detach()
+            return self.extract_features(wav, clips_per_norm_group).detach()
 
-    def extract_features(self, wav: torch.Tensor) -> torch.Tensor:
+    def extract_features(self, wav: torch.Tensor, clips_per_norm_group: int = 0) -> torch.Tensor:
         if wav.dim() != 2:
             raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")
         if not wav.is_cuda:
@@ -357,6 +360,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             self._ws = None
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=x.device)
-        _lib.check(lib.svt_encoder_forward(self._handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(self._ws),
-                                           self._ws.numel(), _lib.stream_ptr(x.device)), "svt_encoder_forward")
+        _lib.check(lib.svt_encoder_forward_ex(self._handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(self._ws),
+                                              self._ws.numel(), _lib.stream_ptr(x.device), int(clips_per_norm_group)),
+                   "svt_encoder_forward")
         return out

@@ -444,3 +444,44 @@ def test_odd_shapes_vs_oracle(cfg_name, B, L):
     d = (got16 - want).abs()
     print(f"   bf16 mean|err| {d.mean():.4f} max {d.max():.3f}")
     assert torch.isfinite(got16).all() and d.mean() < 0.08
+
+
+@pytest.mark.parametrize("cfg_name,B,L,prec,tol", [("tiny-group", 3, 4000, "fp32", 1e-5), ("tiny-layer", 4, 4000, "fp32", 1e-5),
+                                                  ("wav2vec2-base", 5, 80000, "fp32", 2e-4), ("wav2vec2-base", 5, 80000, "bf16", 0.25),
+                                                  ("wav2vec2-large-lv60", 3, 80000, "bf16", 0.25)])
+def test_per_clip_norm_groups_equal_batch1_forwards(cfg_name, B, L, prec, tol):
+    """clips_per_norm_group = 1: a batch of B equal-length utterances == B batch-1 forwards (the reference's evaluation loop,
+    train_audio_ssl.py:90), and != the whole-batch norm of the default call.  In bf16 the batch runs on other GEMM tilings
+    than a single utterance, so the two agree to bf16 rounding only."""
+    cfg = PRESETS[cfg_name]
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision=prec, seed=21).to(DEV)
+    wav = synth_wav(B, L, 22)
+    wav[1] *= 3.0  # clips of different loudness: the whole-batch norm and the per-clip norm differ visibly
+    wav = wav.to(DEV)
+    one_by_one = torch.cat([enc(wav[b:b + 1]) for b in range(B)])
+    batched = enc(wav, clips_per_norm_group=1)
+    d = (batched - one_by_one).abs()
+    print(f"{cfg_name} {prec}: per-clip-norm batch vs batch-1 forwards max|d| {d.max():.2e} mean {d.mean():.2e}")
+    assert d.max().item() < tol and d.mean().item() < tol / 8
+    if prec == "fp32":
+        whole = enc(wav)
+        assert (whole - one_by_one).abs().max().item() > 10 * max(d.max().item(), 1e-4)
+    if prec == "fp32" and cfg_name.startswith("tiny"):
+        sd = W.seeded_encoder_state_dict(cfg, seed=21)
+        want = torch.cat([O.encoder_forward(sd, cfg, wav[b:b + 1].cpu()) for b in range(B)])
+        assert (batched.cpu() - want).abs().max().item() < 1e-3
+    with pytest.raises(Exception):
+        enc(wav, clips_per_norm_group=2 if B % 2 else 3)  # batch not a multiple of the group
+
+
+def test_song_transcriber_batched_utterances_same_notes():
+    cfg = PRESETS["wav2vec2-base"]
+    enc = S.HuggingFaceWav2Vec2("wav2vec2-base", None, config=cfg, precision="fp32", seed=31).to(DEV)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict(W.seeded_head_state_dict(cfg.hidden_size, 20, seed=32))
+    head = head.to(DEV)
+    song = synth_wav(1, int(16000 * 27.3), 33)[0].to(DEV)  # 5 utterances: 4 x 5 s + 7.3 s
+    a, fa = S.SongTranscriber(enc, head, batch_utterances=True).transcribe(song, return_feats=True)
+    b, fb = S.SongTranscriber(enc, head, batch_utterances=False).transcribe(song, return_feats=True)
+    assert fa.shape == fb.shape and (fa - fb).abs().max().item() < 2e-4
+    assert a == b and len(a) > 0
