@@ -10,7 +10,7 @@ from typing import List, Optional
 
 import torch
 
-from .decode import decode_frames, frame2note, frames_to_info
+from .decode import decode_frames, frame2note, frames_to_info, frames2note
 
 
 class AMTForward:
@@ -56,5 +56,5 @@ class AMTForward:
     def transcribe_batch(self, logits: torch.Tensor) -> List[List[list]]:
         """Throughput path: every clip of a batch is its own song (one kernel + one D2H for the batch)."""
         frames = decode_frames(logits, self.pitch_octave_num, self.pitch_class_num)
-        return [frame2note(frames_to_info(frames[b]), self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
+        return [frames2note(frames[b], self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
                 for b in range(frames.shape[0])]
