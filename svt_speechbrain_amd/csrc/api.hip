@@ -719,8 +719,12 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
   const int cpg = clips_per_norm_group > 0 ? clips_per_norm_group : B;
   if (B % cpg) { set_error("encoder_forward: batch must be a multiple of clips_per_norm_group"); return SVT_ERR_INVALID; }
   const int groups = B / cpg;
-  if (groups > 1 && ((L & 3) || c.num_conv_layers == 0)) {
+  if (groups > 1 && c.num_conv_layers > 0 && (L & 3)) {
     set_error("encoder_forward: norm groups need a waveform length that is a multiple of 4 samples");
+    return SVT_ERR_INVALID;
+  }
+  if (groups > 1 && c.num_conv_layers == 0 && c.normalize_wav) {
+    set_error("encoder_forward: features-in mode has no input norm to group");
     return SVT_ERR_INVALID;
   }
   SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_bytes, s));

@@ -259,11 +259,13 @@ class FairseqAVHubertPretrain(nn.Module):
         except Exception:
             pass
 
-    def forward(self, wav):
+    def forward(self, wav, clips_per_norm_group: int = 0):
+        """``clips_per_norm_group`` (extension, 0 = the reference): the wrapper's whole-tensor output norm over groups of that
+        many clips; 1 makes a batch of equal-length clips equal to batch-1 forwards (see HuggingFaceWav2Vec2.forward)."""
         with torch.no_grad():
-            return self.extract_features(wav).detach()
+            return self.extract_features(wav, clips_per_norm_group).detach()
 
-    def extract_features(self, wav):
+    def extract_features(self, wav, clips_per_norm_group: int = 0):
         if not isinstance(wav, dict) or "video" not in wav:
             raise ValueError('expected {"video": (B,1,T,H,W) tensor, "audio": None}')
         if wav.get("audio") is not None:
@@ -282,6 +284,7 @@ class FairseqAVHubertPretrain(nn.Module):
             self._ws = None
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=feats.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=feats.device)
-        _lib.check(lib.svt_encoder_forward(self._handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(self._ws),
-                                           self._ws.numel(), _lib.stream_ptr(feats.device)), "svt_encoder_forward")
+        _lib.check(lib.svt_encoder_forward_ex(self._handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(self._ws),
+                                              self._ws.numel(), _lib.stream_ptr(feats.device), int(clips_per_norm_group)),
+                   "svt_encoder_forward")
         return out

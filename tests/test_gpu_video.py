@@ -83,3 +83,21 @@ def test_avhubert_video_encoder_vs_oracle(prec, tol):
         m({"video": video.to(DEV), "audio": torch.zeros(1)})
     with pytest.raises(RuntimeError):
         m.load_fairseq_model_state({"layer_norm.weight": torch.zeros(128)})
+
+
+def test_avhubert_per_clip_norm_batch_equals_batch1():
+    """The video wrapper's output norm per clip: a batch of clips == the clips forwarded one at a time (fp32: to the last bits)."""
+    from svt_speechbrain_amd.video import FairseqAVHubertPretrain
+    cfg = S.PRESETS["tiny-avhubert-video"]
+    m = FairseqAVHubertPretrain(config=cfg, precision="fp32", seed=78, output_norm=True)
+    m.load_fairseq_model_state(W.seeded_avhubert_video_state_dict(cfg, seed=124))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    video = torch.randn(3, 1, 8, 40, 40, generator=g)
+    video[1] *= 2.5
+    video = video.to(DEV)
+    one = torch.cat([m({"video": video[b:b + 1], "audio": None}) for b in range(3)])
+    batched = m({"video": video, "audio": None}, clips_per_norm_group=1)
+    whole = m({"video": video, "audio": None})
+    assert (batched - one).abs().max().item() < 1e-5
+    assert (whole - one).abs().max().item() > 1e-3
