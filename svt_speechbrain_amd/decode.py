@@ -101,27 +101,45 @@ def frames2note(frames: np.ndarray, onset_thres: float, offset_thres: float, fra
     offset = (~onset) & (p_off >= np.float32(offset_thres))
     valid = (octv != 4) & (pc != 12)
     pitch = octv * 12 + pc
+    on_idx = np.flatnonzero(onset)
+    K = int(on_idx.shape[0])
+    if K == 0:
+        return []
+    # note k opens at its onset frame and closes at the next onset or the first offset after it, whichever comes first
+    # (later offsets find no open note and do nothing); a note still open at the end closes with the last frame's time
+    BIG = n + 1
+    off_idx = np.flatnonzero(offset)
+    nxt_on = np.append(on_idx[1:], BIG)
+    if off_idx.shape[0]:
+        pos = np.searchsorted(off_idx, on_idx, side="right")
+        nxt_off = np.where(pos < off_idx.shape[0], off_idx[np.minimum(pos, off_idx.shape[0] - 1)], BIG)
+    else:
+        nxt_off = np.full(K, BIG, dtype=on_idx.dtype)
+    close = np.minimum(nxt_on, nxt_off)
+    at_end = close == BIG
+    close_idx = np.where(at_end, n, close)
+    t_on = (frame_size * on_idx).tolist()                       # frame_size * i in double, like the reference's Python floats
+    t_off = (frame_size * np.where(at_end, n - 1, close)).tolist()
+    # pitch histogram of every note at once; CPython's max(set(bag), key=bag.count) is only needed where the top count is tied
+    fr = np.flatnonzero(valid)
+    nid = np.searchsorted(on_idx, fr, side="right") - 1
+    inside = (nid >= 0) & (fr < close_idx[np.maximum(nid, 0)])
+    fr, nid = fr[inside], nid[inside]
+    P = int(pitch.max()) + 1 if pitch.shape[0] else 1
+    counts = np.zeros((K, max(P, 1)), dtype=np.int64)
+    np.add.at(counts, (nid, pitch[fr]), 1)
+    top = counts.max(axis=1)
+    mode = counts.argmax(axis=1)
+    tied = (counts == top[:, None]).sum(axis=1) > 1
     notes: List[list] = []
-    t_on = None
-    i_open = 0
-
-    def close(i_close: int, now: float) -> None:
-        sel = valid[i_open:i_close]
-        if sel.any():
-            bag = pitch[i_open:i_close][sel].tolist()
-            notes.append([t_on, now, max(set(bag), key=bag.count) + 36])
-
-    for i in np.flatnonzero(onset | offset).tolist():
-        now = frame_size * i
-        if onset[i]:
-            if t_on is not None:
-                close(i, now)
-            t_on, i_open = now, i
-        elif t_on is not None:
-            close(i, now)
-            t_on = None
-    if t_on is not None:
-        close(n, frame_size * (n - 1))
+    for k in np.flatnonzero(top > 0).tolist():
+        if tied[k]:
+            lo, hi = int(on_idx[k]), int(close_idx[k])
+            bag = pitch[lo:hi][valid[lo:hi]].tolist()
+            m = max(set(bag), key=bag.count)
+        else:
+            m = int(mode[k])
+        notes.append([t_on[k], t_off[k], m + 36])
     return notes
 
 
