@@ -767,14 +767,19 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   a.dbg = g_gemm_dbg;
   if (a.dbg == 9) { a.trace = (long long*)a.resid; a.resid = nullptr; if (g_gemm_variant) a.dbg = g_gemm_variant; }
   const int tiles_n = (a.N + 255) / 256;
+  // Tile height: minimise (rounds of 256 CUs) x (time of one K slab at that height).  The slab times are measured
+  // (tools/gemm_trace.py / gemm_bench.py --bm): 1.67 / 1.37 / 1.05 / 0.85 us for 256 / 192 / 128 / 64 rows -- a shorter tile
+  // does proportionally less MFMA work but moves the same 32 KiB of W per slab through the CU, so it only pays when it
+  // saves whole rounds.  Ties go to the larger tile.
   const int cands[4] = {256, 192, 128, 64};
+  const int slab_cost[4] = {167, 137, 105, 85};
   long best_cost = -1;
   int best = 256;
   for (int i = 0; i < 4; ++i) {
     const int bm = cands[i];
     const long blocks = (long)((a.M + bm - 1) / bm) * tiles_n * a.nz;
     const long rounds = (blocks + 255) / 256;
-    const long cost = rounds * bm;
+    const long cost = rounds * slab_cost[i];
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
   }
   if (g_gemm_force_bm) best = g_gemm_force_bm;

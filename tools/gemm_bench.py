@@ -32,6 +32,10 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("b4_out", 1996, 768, 768, None, 0, 0, 0),
     ("b8_ffn2", 3992, 768, 3072, None, 0, 0, 0),
     ("b8_out", 3992, 768, 768, None, 0, 0, 0),
+    ("s35_qkv", 8715, 2304, 768, None, 0, 0, 0),      # a 3-minute song as one batch: 35 x 5 s
+    ("s35_out", 8715, 768, 768, None, 0, 0, 0),
+    ("s35_ffn1", 8715, 3072, 768, None, 1, 0, 0),
+    ("s35_ffn2", 8715, 768, 3072, None, 0, 0, 0),
     ("sq4096", 4096, 4096, 4096, None, 0, 0, 0),
     ("sq8192", 8192, 8192, 8192, None, 0, 0, 0),
 ]
