@@ -1,5 +1,7 @@
+"""Where the time of SongTranscriber.transcribe goes (3-minute song, wav2vec2-base, bf16): batched forward, last utterance,
+head, frame decode + D2H, note assembly."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import svt_speechbrain_amd as S
 from svt_speechbrain_amd.decode import decode_frames, frames2note
