@@ -153,13 +153,20 @@ struct AttnBufs {
 static size_t esize(int prec) { return prec ? 2 : 4; }
 
 // out[b,t,h*dh+d] = softmax(scale * q k^T) v ; q rows at Q + (b*T+t)*ldq + h*dh, likewise K (ldkv), V (ldkv)
-static bool use_flash(int prec, int dh) { return prec == 1 && (dh == 64 || dh == 128); }
-static int attn_tp(int prec, int dh, int T) { return use_flash(prec, dh) ? round_up_int(T, 64) : round_up_int(T, 8); }
+// fused attention: bf16, head_dim 64 / 128; its relative-position-bias variant (WavLM) exists for head_dim 64 with the
+// (2T-1)-entry table of a head in LDS -- other WavLM geometries take the score-matrix path
+static bool use_flash(int prec, int dh, bool bias = false, int64_t T = 0) {
+  if (!(prec == 1 && (dh == 64 || dh == 128))) return false;
+  return !bias || (dh == 64 && 2 * T - 1 <= 8192);
+}
+static int attn_tp(int prec, int dh, int T, bool bias = false) {
+  return use_flash(prec, dh, bias, T) ? round_up_int(T, 64) : round_up_int(T, 8);
+}
 
 static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
                                  long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr) {
-  if (use_flash(prec, dh)) {  // (with a gate: head_dim 64 and 2T-1 <= 8192, else the launcher reports an error)
+  if (use_flash(prec, dh, gate != nullptr, T)) {
     (void)vt_ready;
     return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
                                   scale, s, gate, gate ? relpb : nullptr);
@@ -658,8 +665,8 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.convF = c.feat_extract_norm == SVT_NORM_LAYER ? (float*)cv.take(max_f) : nullptr;
   const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
   const size_t rows = (size_t)B * T;
-  const int Tp = attn_tp(c.precision, dh, (int)T);
-  const bool flash = use_flash(c.precision, dh);
+  const int Tp = attn_tp(c.precision, dh, (int)T, c.rel_pos_buckets > 0);
+  const bool flash = use_flash(c.precision, dh, c.rel_pos_buckets > 0, (int64_t)T);
   w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers > 0 ? c.num_conv_layers - 1 : 0] * es);
   w.hF = (float*)cv.take(rows * D * 4);
   w.preF = (float*)cv.take(rows * D * 4);

@@ -1,0 +1,70 @@
+"""Differential fuzz of the encoder against the oracle over random geometries (seeded): hidden size / heads / head_dim, conv
+widths, both conv-norm and encoder-norm layouts, odd positional-conv kernels and group counts, batch and length.  Exercises the
+dispatch edges of the contraction kernels (small-problem kernel eligibility, 64/128-row tiles, narrow N, K not a multiple of 64)
+and of the attention paths (head_dim 16..128) that the fixed goldens do not reach."""
+import dataclasses
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import svt_speechbrain_amd as S  # noqa: E402
+from oracle import svt_oracle as O  # noqa: E402
+from svt_speechbrain_amd import weights as W  # noqa: E402
+from svt_speechbrain_amd.config import EncoderConfig  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def random_case(seed):
+    r = random.Random(seed)
+    dh = r.choice([16, 32, 64, 64, 128])
+    heads = r.choice([1, 2, 3, 4, 6])
+    hidden = dh * heads
+    groups = r.choice([g for g in (1, 2, 4, 8, 16) if hidden % g == 0 and (hidden // g) % 8 == 0])
+    family = r.choice(["wav2vec2", "hubert", "wavlm", "data2vec"])
+    kw = {}
+    if family == "wavlm":
+        kw = dict(rel_pos_buckets=r.choice([16, 32, 64]), rel_pos_max_distance=r.choice([40, 128]))
+    if family == "data2vec":
+        kw = dict(pos_conv_depth=r.choice([2, 3]), feat_extract_norm="layer", do_stable_layer_norm=False)
+    cfg = EncoderConfig(
+        name=f"fuzz-{seed}", family=family, hidden_size=hidden, num_hidden_layers=r.choice([1, 2, 3]), num_attention_heads=heads,
+        intermediate_size=r.choice([64, 128, 192, 256, 512]), conv_dim=(r.choice([32, 64, 96, 128]),) * 7,
+        feat_extract_norm=kw.pop("feat_extract_norm", r.choice(["group", "layer"])), conv_bias=r.random() < 0.5,
+        do_stable_layer_norm=kw.pop("do_stable_layer_norm", r.random() < 0.5),
+        feat_proj_layer_norm=(family != "hubert") or r.random() < 0.5,
+        num_conv_pos_embeddings=r.choice([4, 8, 15, 16, 19, 31, 32]) if family != "data2vec" else r.choice([5, 9, 19]),
+        num_conv_pos_embedding_groups=groups, **kw)
+    B = r.choice([1, 1, 2, 3, 5])
+    L = r.choice([400, 719, 1600, 4000, 8001, 16000, 23456])
+    return cfg, B, L
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_geometry_vs_oracle(seed):
+    cfg, B, L = random_case(1000 + seed)
+    sd = W.seeded_encoder_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    wav = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+    want = O.encoder_forward(sd, cfg, wav)
+    desc = (f"{cfg.family} D={cfg.hidden_size} H={cfg.num_attention_heads} F={cfg.intermediate_size} C={cfg.conv_dim[0]} "
+            f"{cfg.feat_extract_norm}/{'pre' if cfg.do_stable_layer_norm else 'post'}-LN kp={cfg.num_conv_pos_embeddings} "
+            f"g={cfg.num_conv_pos_embedding_groups} B={B} L={L}")
+    for prec, bound in (("fp32", 1e-3), ("bf16", None)):
+        enc = S.HuggingFaceWav2Vec2(cfg.name, None, config=cfg, precision=prec, seed=seed).to(DEV)
+        got = enc(wav.to(DEV)).cpu()
+        assert got.shape == want.shape, desc
+        d = (got - want).abs()
+        print(f"[{seed}] {desc} {prec}: max {d.max():.2e} mean {d.mean():.2e}")
+        assert torch.isfinite(got).all(), desc
+        if bound is not None:
+            assert d.max().item() < bound, desc
+        else:
+            assert d.mean().item() < 0.12 and d.max().item() < 2.5, desc
+        if B > 1 and L % 4 == 0 and prec == "fp32":
+            per_clip = enc(wav.to(DEV), clips_per_norm_group=1).cpu()
+            one = torch.cat([enc(wav[b:b + 1].to(DEV)).cpu() for b in range(B)])
+            assert (per_clip - one).abs().max().item() < 1e-5, desc
