@@ -43,7 +43,7 @@ def random_case(seed):
     return cfg, B, L
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SVT_FUZZ_CASES", "24")))))
 def test_random_geometry_vs_oracle(seed):
     cfg, B, L = random_case(1000 + seed)
     sd = W.seeded_encoder_state_dict(cfg, seed=seed)
@@ -68,3 +68,53 @@ def test_random_geometry_vs_oracle(seed):
             per_clip = enc(wav.to(DEV), clips_per_norm_group=1).cpu()
             one = torch.cat([enc(wav[b:b + 1].to(DEV)).cpu() for b in range(B)])
             assert (per_clip - one).abs().max().item() < 1e-5, desc
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_fusion_ctc_fbank_losses_vs_oracle(seed):
+    """The other entry points on random sizes: FusionRCA (pad / truncate branch, odd lengths, several widths), ctc_greedy_decode
+    (ragged relative lengths, blank at either end), the Fbank chain, the frame head + decode, bce / nll losses with lengths."""
+    r = random.Random(5000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    # ---- fusion
+    d_model = r.choice([64, 128, 256, 1024])
+    nhead = r.choice([h for h in (1, 2, 4, 8) if d_model % h == 0 and (d_model // h) % 8 == 0])
+    d_ffn = r.choice([64, 128, 256])
+    B, T1 = r.choice([1, 2, 3]), r.choice([1, 7, 33, 100, 250])
+    T2 = max(1, T1 + r.choice([-5, -1, 0, 1, 4]))
+    sd = W.seeded_fusion_state_dict(d_model, d_ffn, seed=seed, max_len=300)
+    a = torch.randn(B, T1, d_model, generator=g)
+    v = torch.randn(B, T2, d_model, generator=g)
+    want = O.fusion_forward(sd, a, v, alpha=0.5, nhead=nhead)
+    for prec, tol in (("fp32", 1e-3), ("bf16", 0.25)):
+        fus = S.FusionRCA(nhead=nhead, d_ffn=d_ffn, d_model=d_model, precision=prec, max_length=300, seed=seed).to(DEV)
+        fus.load_state_dict(sd)
+        got = fus(a.to(DEV), v.to(DEV)).cpu()
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < tol, (d_model, nhead, d_ffn, B, T1, T2, prec)
+    # ---- ctc greedy
+    Bc, Tc, V = r.choice([1, 3, 6]), r.choice([1, 5, 40, 200]), r.choice([2, 5, 31])
+    probs = torch.rand(Bc, Tc, V, generator=g)
+    probs[:, :, r.randrange(V)] += 0.3  # repeated winners -> collapses
+    lens = torch.rand(Bc, generator=g) * 0.9 + 0.1
+    blank = r.choice([0, -1, V - 1])
+    assert S.ctc_greedy_decode(probs.to(DEV), lens.to(DEV), blank) == O.ctc_greedy_decode(probs, lens, blank)
+    # ---- fbank
+    Lw = r.choice([400, 1600, 4801, 16000, 23457])
+    wav = 0.1 * torch.randn(r.choice([1, 2, 5]), Lw, generator=g)
+    fb = S.Fbank()(wav.to(DEV)).cpu()
+    ref = O.fbank(wav)
+    assert fb.shape == ref.shape and (fb - ref).abs().max().item() < 5e-3, Lw
+    # ---- head + frame decode
+    n_in, rows = r.choice([64, 512, 768, 1024]), r.choice([1, 7, 249, 1000])
+    head = S.Linear(20, input_size=n_in)
+    hd = W.seeded_head_state_dict(n_in, 20, seed=seed)
+    head.load_state_dict(hd)
+    feats = torch.randn(2, rows, n_in, generator=g)
+    logits = head.to(DEV)(feats.to(DEV))
+    ref_logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
+    assert (logits.cpu() - ref_logits).abs().max().item() < 1e-3
+    fr = S.decode_frames(logits)
+    p_on, p_off, octv, pc = O.decode_frames(logits.cpu())
+    assert (torch.from_numpy(fr["octave"].astype("int64")) == octv).all() and (torch.from_numpy(fr["pitch_class"].astype("int64")) == pc).all()
+    assert (torch.from_numpy(fr["p_on"].copy()) - p_on).abs().max().item() < 1e-6
