@@ -118,3 +118,27 @@ def test_random_fusion_ctc_fbank_losses_vs_oracle(seed):
     p_on, p_off, octv, pc = O.decode_frames(logits.cpu())
     assert (torch.from_numpy(fr["octave"].astype("int64")) == octv).all() and (torch.from_numpy(fr["pitch_class"].astype("int64")) == pc).all()
     assert (torch.from_numpy(fr["p_on"].copy()) - p_on).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("cfg_name", ["wav2vec2-base", "wav2vec2-large-lv60"])
+def test_bf16_tracks_fp32_across_batch_and_length(cfg_name):
+    """Full-width models over a sweep of batch sizes and lengths (every tile-height / kernel choice of the contraction dispatch:
+    small-problem kernel, 64/128/192/256-row tiles, persistent scheduler, fused out-projection): the bf16 path must stay within
+    its error bound of the fp32 path (which the golden / oracle tests pin)."""
+    from svt_speechbrain_amd.config import PRESETS
+    cfg = PRESETS[cfg_name]
+    e32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=4).to(DEV)
+    e16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=4).to(DEV)
+    r = random.Random(77)
+    cases = [(1, 16000), (1, 80000), (2, 80000), (3, 47000), (4, 160000), (6, 80000), (8, 80000), (12, 40000), (16, 80000),
+             (24, 30000), (35, 80000)]
+    if cfg_name != "wav2vec2-base":
+        cases = cases[:8]
+    for B, L in cases:
+        g = torch.Generator().manual_seed(B * 1000 + L)
+        wav = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1).to(DEV)
+        a, b = e32(wav), e16(wav)
+        d = (a - b).abs()
+        print(f"{cfg_name} B={B} L={L}: bf16 vs fp32 mean {d.mean():.4f} max {d.max():.3f}")
+        assert torch.isfinite(b).all()
+        assert d.mean().item() < 0.08 and d.max().item() < 2.0, (B, L)
