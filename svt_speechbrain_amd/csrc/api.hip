@@ -336,6 +336,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 5) g_fuse_outproj_ln = value;
   else if (key == 6) g_gemm_skinny = value;
   else if (key == 7) g_gemm_skinny_max_tiles = value;
+  else if (key == 8) g_flash_wide = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }

@@ -4,7 +4,8 @@
 // (wav2vec2/HuBERT) or 128 (RCA fusion).
 //
 // Mapping (wave64, v_mfma_f32_32x32x16_bf16):
-//   * block = 4 waves = 128 queries of one (clip, head); each wave owns 32 queries for the whole sweep.
+//   * block = 4 waves = 128 queries of one (clip, head), or 8 waves = 256 queries when the launch has enough workgroups
+//     (half the K / V traffic per query); each wave owns 32 queries for the whole sweep.
 //   * K and V tiles of 64 keys are moved global -> LDS by LDS-DMA (no staging registers, no ds_write) into a row-major
 //     image with an XOR swizzle of the 16-byte chunks, applied on the SOURCE address (8 consecutive lanes fetch one
 //     128-byte row: one request per line); two stages, the next tile is in flight during the current tile's MFMAs,
@@ -31,8 +32,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 // BIAS: WavLM's gated relative position bias, scores += gate[b,h,q] * pb[h][key - q + T - 1] (pb row of 2T-1 floats kept
 // in LDS; added in the scaled log2 domain before the row max).
-template <int DH, bool BIAS = false>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
+template <int DH, bool BIAS = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
                                                          const bf16_t* __restrict__ K, long ldk, long k_bstride,
                                                          const bf16_t* __restrict__ V, int /*unused*/, bf16_t* __restrict__ O,
                                                          long ldo, long o_bstride, int T, int H, float c,
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;  // NW waves x 32 queries: every workgroup streams all of K and V once
   const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
   const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
   const bf16_t* Vb = V + (long)b * k_bstride + (long)h * DH;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
   float gq = 0.f;   // gate of this lane's query, pre-multiplied by log2(e)
   int qrel = 0;     // T - 1 - query
   if constexpr (BIAS) {
-    for (int i = tid; i < 2 * T - 1; i += 256) pbl[i] = pbias[(long)h * (2 * T - 1) + i];
+    for (int i = tid; i < 2 * T - 1; i += 64 * NW) pbl[i] = pbias[(long)h * (2 * T - 1) + i];
     int q = q0 + (lane & 31);
     if (q > T - 1) q = T - 1;
     gq = gate[((long)b * H + h) * T + q] * 1.44269504088896340736f;
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
   // 128-byte rows, key&15 for 256-byte rows; V: (key>>1 & 1) << 2, resp. (key & 3) << 2).  No staging registers, no
   // ds_write; the next tile is in flight while the current one is multiplied (two stages, one barrier per tile).
   constexpr int ROWS_PER_DMA = 64 / CPR;                 // 8 (dh 64) / 4 (dh 128)
-  constexpr int DMA_PER_WAVE = 64 / ROWS_PER_DMA / 4;    // 2 / 4 instructions per wave per tile and operand
+  constexpr int DMA_PER_WAVE = 64 / ROWS_PER_DMA / NW;   // instructions per wave per tile and operand (2 / 4 with four waves)
+  static_assert(DMA_PER_WAVE >= 1, "too many waves for the tile's fill");
   int dkey[DMA_PER_WAVE], kch[DMA_PER_WAVE], vch[DMA_PER_WAVE];
 #pragma unroll
   for (int i = 0; i < DMA_PER_WAVE; ++i) {
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
 #undef SVT_STAGE_DMA
 }  // namespace
 
+int g_flash_wide = 1;  // svt_debug_set key 8
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
@@ -264,20 +267,32 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8) { set_error("flash_attention: strides must be multiples of 8"); return -1; }
   const float c = scale * 1.44269504088896340736f;
   dim3 grid((T + 127) / 128, H, B);
+  // eight-wave workgroups (256 queries) halve the K / V traffic per query; used when a head has more than 128 queries
+  // (measured 45.7 vs 46.9 us at 32 x 12 heads x 499 frames, 114.2 vs 118.7 us at 64 x 16; with few workgroups -- one 5 s
+  // utterance: 12 -- the four-wave form spreads over more CUs and stays)
+  const bool wide = g_flash_wide && dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512;
+  if (wide) grid.x = (T + 255) / 256;
   const double flops = 4.0 * B * H * (double)T * T * dh;
   if (gate && pb) {
     if (dh != 64) { set_error("flash_attention: the relative-position-bias variant is built for head_dim 64"); return -1; }
     const size_t dyn = (size_t)(2 * T - 1) * 4;
     if (dyn > 32768) { set_error("flash_attention: sequence too long for the LDS-resident position-bias row"); return -1; }
     prof_begin(s);
-    hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), dyn, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
-                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, gate, pb);
+    if (wide)
+      hipLaunchKernelGGL((flash_attn_kernel<64, true, 8>), grid, dim3(512), dyn, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                         ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, gate, pb);
+    else
+      hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), dyn, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                         ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, gate, pb);
     prof_end(s, flops, 0.0, 2);
     SVT_LAUNCH_CHECK();
     return 0;
   }
   prof_begin(s);
-  if (dh == 64)
+  if (dh == 64 && wide)
+    hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
+  else if (dh == 64)
     hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else if (dh == 128)
