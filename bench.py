@@ -101,6 +101,9 @@ def main():
     dev = torch.device(f"cuda:{local}")
     lib = _lib.load()
     _lib.require_gpu()
+    for kv in os.environ.get("SVT_DEBUG_SET", "").split(","):  # diagnostics: "key=value,..." -> svt_debug_set (A/B of kernel variants)
+        if "=" in kv:
+            lib.svt_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
     cfg = S.PRESETS[args.model]
     L = int(16000 * args.seconds)
