@@ -229,7 +229,8 @@ int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const 
 /* Diagnostics switches of the contraction kernels (tools/gemm_bench.py, tools/gemm_trace.py; never needed in production):
  * key 0 = kernel ablation variant, 1 = force the tile height (64/128/192/256), 2 = force the one-tile (2) / persistent (4)
  * scheduler, 3 = ablation variant while tracing, 5 = fused out-projection + LayerNorm on/off, 6 = small-problem kernel
- * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles.  Returns 0. */
+ * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles, 8 = 8-wave fused-attention workgroups on/off,
+ * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode.  Returns 0. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

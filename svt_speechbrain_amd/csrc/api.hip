@@ -204,6 +204,7 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
 
 using namespace svt;
 
+static int g_conv_ln_bf16 = 1;     // svt_debug_set(9, 0): fp32 conv output + LayerNorm (A/B)
 static int g_fuse_outproj_ln = 1;  // svt_debug_set(5, 0) falls back to GEMM + LayerNorm kernels (A/B measurements)
 
 // =================================================================================================
@@ -337,6 +338,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 6) g_gemm_skinny = value;
   else if (key == 7) g_gemm_skinny_max_tiles = value;
   else if (key == 8) g_flash_wide = value;
+  else if (key == 9) g_conv_ln_bf16 = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -779,7 +781,15 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     g.ldw = g.K; g.ldc = co;
     g.bias = c.conv_bias ? Lw.bias.as<float>() : nullptr;
     if ((int64_t)B * tout > 2147483647LL) { set_error("encoder_forward: batch*frames exceeds 2^31"); return SVT_ERR_INVALID; }
-    if (c.feat_extract_norm == SVT_NORM_LAYER) {
+    if (c.feat_extract_norm == SVT_NORM_LAYER && prec && co == 512 && g_conv_ln_bf16) {
+      // throughput mode: the conv output goes to HBM once, in the operand type, and is normalised in place (a wave owns a
+      // row: it reads all of it before it writes) -- the fp32 round trip below moves 3x the bytes (conv1 at 64 x 10 s:
+      // 2.1 GB written + 2.1 GB read + 1.05 GB written)
+      g.C = w.act[cur ^ 1]; g.out_f32 = 0; g.act = ACT_NONE;
+      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_layernorm(prec, w.act[cur ^ 1], 0, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(),
+                                   1e-5f, 1, w.act[cur ^ 1], nullptr, s)) return r;
+    } else if (c.feat_extract_norm == SVT_NORM_LAYER) {
       g.C = w.convF; g.out_f32 = 1; g.act = ACT_NONE;
       if (int r = launch_gemm(prec, g, s)) return r;
       if (int r = launch_layernorm(prec, w.convF, 1, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(),
