@@ -447,8 +447,8 @@ def test_odd_shapes_vs_oracle(cfg_name, B, L):
 
 
 @pytest.mark.parametrize("cfg_name,B,L,prec,tol", [("tiny-group", 3, 4000, "fp32", 1e-5), ("tiny-layer", 4, 4000, "fp32", 1e-5),
-                                                  ("wav2vec2-base", 5, 80000, "fp32", 2e-4), ("wav2vec2-base", 5, 80000, "bf16", 0.25),
-                                                  ("wav2vec2-large-lv60", 3, 80000, "bf16", 0.25)])
+                                                  ("wav2vec2-base", 5, 80000, "fp32", 2e-4), ("wav2vec2-base", 5, 80000, "bf16", 0.5),
+                                                  ("wav2vec2-large-lv60", 3, 80000, "bf16", 0.5)])
 def test_per_clip_norm_groups_equal_batch1_forwards(cfg_name, B, L, prec, tol):
     """clips_per_norm_group = 1: a batch of B equal-length utterances == B batch-1 forwards (the reference's evaluation loop,
     train_audio_ssl.py:90), and != the whole-batch norm of the default call.  In bf16 the batch runs on other GEMM tilings
