@@ -485,3 +485,8 @@ def test_song_transcriber_batched_utterances_same_notes():
     b, fb = S.SongTranscriber(enc, head, batch_utterances=False).transcribe(song, return_feats=True)
     assert fa.shape == fb.shape and (fa - fb).abs().max().item() < 2e-4
     assert a == b and len(a) > 0
+    # several batched jobs (max_batch smaller than the run of equal-length utterances), round-robin on the two streams
+    c, fc = S.SongTranscriber(enc, head, batch_utterances=True, max_batch=3).transcribe(song, return_feats=True)
+    assert (fc - fb).abs().max().item() < 2e-4 and c == b
+    d = S.SongTranscriber(enc, head, streams=1, max_batch=2).transcribe(song)
+    assert d == b
