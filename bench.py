@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
+                    "(the PCIe-inclusive rate; never the reported metric, whose inputs are resident in HBM)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured: no gain, the GPU is never idle)")
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
                     "object and workspace), so one step's HBM-bound kernels (LayerNorm, conv0, norms) run under the next step's MFMA-bound "
@@ -127,6 +129,8 @@ def main():
     head = head.to(dev)
     frames_l = [torch.empty((B * T, 4), dtype=torch.int32, device=dev) for _ in range(ns)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    wav_host = wav.cpu().pin_memory() if args.h2d else None
+    wav_in = [torch.empty_like(wav) for _ in range(ns)] if args.h2d else None
     counter = [0]
     active = [ns]  # streams in use (the roofline leg sets this to 1)
 
@@ -137,7 +141,9 @@ def main():
         counter[0] += 1
         # one stream: launch on whatever stream is current (during hipGraph capture that is the capture stream)
         with (torch.cuda.stream(streams[i]) if ns > 1 else contextlib.nullcontext()):
-            feats = encs[i](wav)
+            if args.h2d:
+                wav_in[i].copy_(wav_host, non_blocking=True)
+            feats = encs[i](wav_in[i] if args.h2d else wav)
             logits = head(feats)
             _lib.check(lib.svt_decode_frames(_lib.ptr(logits), B * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
                                              _lib.stream_ptr(dev)), "svt_decode_frames")
@@ -251,7 +257,7 @@ def main():
                        "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
                        "launch": "hipGraph replay" if graph is not None else "eager",
-                       "streams": ns,
+                       "streams": ns, "inputs": "pinned host memory, copied every step (diagnostic)" if args.h2d else "resident in HBM",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # dominant kernel = svt::gemm_pp8_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
             # launches / HIP-event time of those launches on their stream, over the timed region
