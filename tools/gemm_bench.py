@@ -12,6 +12,8 @@ from svt_speechbrain_amd import _lib  # noqa: E402
 SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f32, resid
     ("conv1", 32 * 15999, 512, 1536, (31999, 15999, 2, 512), 1, 0, 0),
     ("conv2", 32 * 7999, 512, 1536, (15999, 7999, 2, 512), 1, 0, 0),
+    ("conv3", 32 * 3999, 512, 1536, (7999, 3999, 2, 512), 1, 0, 0),
+    ("conv4", 32 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, 0, 0),
     ("conv5", 32 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, 0),
     ("proj", 15968, 768, 512, None, 0, 1, 0),
     ("qkv", 15968, 2304, 768, None, 0, 0, 0),
@@ -112,12 +114,14 @@ if __name__ == "__main__":
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--no-skinny", action="store_true", help="small problems on the large-tile kernels (A/B)")
     ap.add_argument("--skinny-max-tiles", type=int, default=32)
+    ap.add_argument("--variant", type=int, default=0, help="svt_debug_set key 3 (experimental kernel variants)")
     ap.add_argument("--nobias", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
     _lib.load().svt_debug_set(1, a.bm)
     _lib.load().svt_debug_set(2, a.ring)
+    _lib.load().svt_debug_set(3, a.variant)
     _lib.load().svt_debug_set(6, 0 if a.no_skinny else 1)
     _lib.load().svt_debug_set(7, a.skinny_max_tiles)
     for s in SHAPES:
