@@ -30,7 +30,9 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X dense peaks (MI355X_MICROARCH.md)
+# MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
+# multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
 
 
 def synth_wav(B, L, seed=1986):
@@ -82,7 +84,7 @@ def main():
     ap.add_argument("--model", default="wav2vec2-base")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
                     "(the PCIe-inclusive rate; never the reported metric, whose inputs are resident in HBM)")

@@ -45,7 +45,15 @@ typedef enum {
   SVT_ERR_NO_DEVICE = -6    /* no gfx950 device visible                   */
 } svt_status;
 
-typedef enum { SVT_PREC_FP32 = 0, SVT_PREC_BF16 = 1 } svt_precision;
+/* Operand handling of the dense products (conv 1-6 as implicit GEMM, projections, attention, FFN; HF:254-802):
+ *   SVT_PREC_FP32    fp32 operands, exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the parity mode, 157 TFLOP/s peak
+ *   SVT_PREC_BF16    bf16 operands and activations, fp32 accumulate: the throughput mode
+ *   SVT_PREC_BF16X3  fp32 activations / weights in memory; inside the product kernels every operand is cut into bf16
+ *                    (hi, lo) and Ah*Wh + Al*Wh + Ah*Wl is accumulated in fp32 on the bf16 matrix pipe (3 MFMAs of 16
+ *                    cycles instead of 8 fp32 MFMAs of 32): ~2^-17 relative operand error, fp32 range
+ *   SVT_PREC_FP16X3  the same with fp16 pieces (~2^-22 relative; operands must stay below 65504 in magnitude, which
+ *                    holds for the fp16-trained wav2vec2 / HuBERT / WavLM checkpoints the wrapper loads) */
+typedef enum { SVT_PREC_FP32 = 0, SVT_PREC_BF16 = 1, SVT_PREC_BF16X3 = 2, SVT_PREC_FP16X3 = 3 } svt_precision;
 typedef enum { SVT_NORM_GROUP = 0, SVT_NORM_LAYER = 1 } svt_feat_norm;
 typedef enum { SVT_F32 = 0 } svt_dtype;
 

@@ -151,6 +151,11 @@ struct AttnBufs {
   void* Vt;   // (B,H,dh,Tp)
 };
 static size_t esize(int prec) { return prec ? 2 : 4; }
+// svt_precision -> storage type of activations / weights in HBM (0 = fp32, 1 = bf16).  The split-operand modes
+// (SVT_PREC_BF16X3 / SVT_PREC_FP16X3) keep the fp32 parity pipeline and change only the engine of the dense products:
+// launch_gemm(gp = precision) cuts the fp32 operands into 16-bit pieces on their way into LDS (gemm.hip).
+static inline int storage_prec(int precision) { return precision >= 2 ? 0 : precision; }
+static inline bool valid_precision(int p) { return p >= SVT_PREC_FP32 && p <= SVT_PREC_FP16X3; }
 
 // out[b,t,h*dh+d] = softmax(scale * q k^T) v ; q rows at Q + (b*T+t)*ldq + h*dh, likewise K (ldkv), V (ldkv)
 // fused attention: bf16, head_dim 64 / 128; its relative-position-bias variant (WavLM) exists for head_dim 64 with the
@@ -165,7 +170,9 @@ static int attn_tp(int prec, int dh, int T, bool bias = false) {
 
 static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
-                                 long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr) {
+                                 long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr,
+                                 int gp = -1) {
+  if (gp < 0) gp = prec;
   if (use_flash(prec, dh, gate != nullptr, T)) {
     (void)vt_ready;
     return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
@@ -182,7 +189,7 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
   g.w_z1 = (long)T * ldkv; g.w_z2 = dh;
   g.c_z1 = (long)H * T * Tp; g.c_z2 = (long)T * Tp;
   g.alpha = scale; g.out_f32 = 1;
-  if (int r = launch_gemm(prec, g, s)) return r;
+  if (int r = launch_gemm(gp, g, s)) return r;
   if (gate)
     if (int r = launch_scores_add_relbias(ab.S, (int64_t)B * H, H, T, Tp, gate, relpb, s)) return r;
   if (int r = launch_softmax_rows(prec, ab.S, (int64_t)B * H * T, T, Tp, ab.P, s)) return r;
@@ -197,7 +204,7 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
   o.a_z1 = (long)H * T * Tp; o.a_z2 = (long)T * Tp;
   o.w_z1 = (long)H * dh * Tp; o.w_z2 = (long)dh * Tp;
   o.c_z1 = (long)T * ldo; o.c_z2 = dh;
-  return launch_gemm(prec, o, s);
+  return launch_gemm(gp, o, s);
 }
 
 }  // namespace svt
@@ -257,7 +264,7 @@ static int validate_cfg(const svt_encoder_config& c) {
   if (c.hidden_size % c.pos_conv_groups || (c.hidden_size / c.pos_conv_groups) % 8) { set_error("hidden_size/pos_conv_groups must be a multiple of 8"); return SVT_ERR_INVALID; }
   if (c.intermediate_size % 8 || c.hidden_size % 8) { set_error("sizes must be multiples of 8"); return SVT_ERR_INVALID; }
   if (c.feat_extract_norm != SVT_NORM_GROUP && c.feat_extract_norm != SVT_NORM_LAYER) { set_error("feat_extract_norm"); return SVT_ERR_INVALID; }
-  if (c.precision != SVT_PREC_FP32 && c.precision != SVT_PREC_BF16) { set_error("precision"); return SVT_ERR_INVALID; }
+  if (!valid_precision(c.precision)) { set_error("precision"); return SVT_ERR_INVALID; }
   if (c.pos_conv_depth < 1 || c.pos_conv_depth > 16) { set_error("pos_conv_depth must be 1..16"); return SVT_ERR_INVALID; }
   if (c.pos_conv_batch_norm && c.pos_conv_depth != 1) { set_error("pos_conv_batch_norm applies to the single positional conv only"); return SVT_ERR_INVALID; }
   if (c.rel_pos_buckets < 0 || c.rel_pos_buckets % 4 || (c.rel_pos_buckets > 0 && c.rel_pos_max_distance <= c.rel_pos_buckets / 4)) {
@@ -405,7 +412,7 @@ int svt_encoder_finalize(svt_encoder* e) {
   if (!e) { set_error("null encoder"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(e->device));
   const svt_encoder_config& c = e->cfg;
-  const int prec = c.precision;
+  const int prec = storage_prec(c.precision);
   const ParamMap& P = e->params;
   const Param* p = nullptr;
   e->conv.clear();
@@ -647,7 +654,8 @@ struct EncWs {
 
 EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   const svt_encoder_config& c = e->cfg;
-  const size_t es = esize(c.precision);
+  const int sp = storage_prec(c.precision);
+  const size_t es = esize(sp);
   Carver cv(base);
   EncWs w;
   w.mom_bytes = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments
@@ -668,14 +676,14 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.convF = c.feat_extract_norm == SVT_NORM_LAYER ? (float*)cv.take(max_f) : nullptr;
   const int D = c.hidden_size, F = c.intermediate_size, H = c.num_heads, dh = D / H;
   const size_t rows = (size_t)B * T;
-  const int Tp = attn_tp(c.precision, dh, (int)T, c.rel_pos_buckets > 0);
-  const bool flash = use_flash(c.precision, dh, c.rel_pos_buckets > 0, (int64_t)T);
+  const int Tp = attn_tp(sp, dh, (int)T, c.rel_pos_buckets > 0);
+  const bool flash = use_flash(sp, dh, c.rel_pos_buckets > 0, (int64_t)T);
   w.xln = cv.take(rows * c.conv_dim[c.num_conv_layers > 0 ? c.num_conv_layers - 1 : 0] * es);
   w.hF = (float*)cv.take(rows * D * 4);
   w.preF = (float*)cv.take(rows * D * 4);
   w.xb = cv.take(rows * D * es);
-  w.xF = c.precision ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
-  w.xlo = c.precision ? cv.take(rows * D * 2) : nullptr;  // low half of the (hi, lo) bf16 residual stream (post-LN, bf16 mode)
+  w.xF = sp ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
+  w.xlo = sp ? cv.take(rows * D * 2) : nullptr;  // low half of the (hi, lo) bf16 residual stream (post-LN, bf16 mode)
   {
     const int Pf = e->pos_P;
     const size_t Tq = Pf ? (T + Pf - 1) / Pf : 0;
@@ -718,7 +726,8 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
   const int64_t T = svt_encoder_num_frames(e, L);
   if (T < 1) { set_error("encoder_forward: waveform shorter than the receptive field"); return SVT_ERR_INVALID; }
   const svt_encoder_config& c = e->cfg;
-  const int prec = c.precision;
+  const int prec = storage_prec(c.precision);  // storage type of activations / weights
+  const int gp = c.precision;                  // engine of the dense products (launch_gemm)
   EncWs w = carve_encoder(e, B, L, workspace);
   if (w.total > workspace_bytes) { set_error("encoder_forward: workspace too small (" + std::to_string(workspace_bytes) + " < " + std::to_string(w.total) + ")"); return SVT_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
@@ -786,17 +795,17 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
       // row: it reads all of it before it writes) -- the fp32 round trip below moves 3x the bytes (conv1 at 64 x 10 s:
       // 2.1 GB written + 2.1 GB read + 1.05 GB written)
       g.C = w.act[cur ^ 1]; g.out_f32 = 0; g.act = ACT_NONE;
-      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_gemm(gp, g, s)) return r;
       if (int r = launch_layernorm(prec, w.act[cur ^ 1], 0, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(),
                                    1e-5f, 1, w.act[cur ^ 1], nullptr, s)) return r;
     } else if (c.feat_extract_norm == SVT_NORM_LAYER) {
       g.C = w.convF; g.out_f32 = 1; g.act = ACT_NONE;
-      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_gemm(gp, g, s)) return r;
       if (int r = launch_layernorm(prec, w.convF, 1, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(),
                                    1e-5f, 1, w.act[cur ^ 1], nullptr, s)) return r;
     } else {
       g.C = w.act[cur ^ 1]; g.act = ACT_GELU;
-      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_gemm(gp, g, s)) return r;
     }
     cur ^= 1;
     tin = tout;
@@ -817,7 +826,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     GemmArgs g;
     g.A = proj_in; g.W = e->proj_w.p; g.C = w.hF; g.bias = e->proj_b.as<float>();
     g.M = (int)rows; g.N = D; g.K = C; g.a_rpb = (int)rows; g.a_rstride = C; g.ldw = C; g.ldc = D; g.out_f32 = 1;
-    if (int r = launch_gemm(prec, g, s)) return r;
+    if (int r = launch_gemm(gp, g, s)) return r;
   }
   // ---- positional conv embedding: pre = h + gelu(grouped_conv(h) + b) ----
   {
@@ -841,7 +850,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
         g.w_z1 = 0; g.w_z2 = (long)cg * g.K;
         g.c_z1 = (long)T * D; g.c_z2 = cg; g.bias_z2 = cg;
         g.act = ACT_NONE; g.out_f32 = 1;
-        if (int r = launch_gemm(prec, g, s)) return r;
+        if (int r = launch_gemm(gp, g, s)) return r;
         if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->ones.as<float>(), e->zeros.as<float>(), 1e-5f, 1, nullptr,
                                      lnout, s)) return r;
         cur = lnout;
@@ -858,7 +867,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
       g.nz = G; g.nz2 = G;
       g.a_z2 = (long)Tp * cg; g.w_z2 = (long)g.N * g.K; g.c_z2 = (long)B * Tq * g.N; g.bias_z2 = g.N;
       g.act = ACT_GELU; g.out_f32 = 0;
-      if (int r = launch_gemm(prec, g, s)) return r;
+      if (int r = launch_gemm(gp, g, s)) return r;
       if (int r = launch_posconv_scatter_add(w.hF, w.posy, B, (int)T, D, G, Pf, Tq, w.preF, s)) return r;
     } else {
     if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, (int)T + kp, w.posg, s, bn_sc, bn_sh)) return r;
@@ -872,7 +881,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     g.w_z1 = 0; g.w_z2 = (long)cg * g.K;
     g.c_z1 = (long)T * D; g.c_z2 = cg; g.bias_z2 = cg;
     g.act = ACT_GELU; g.out_f32 = 1;
-    if (int r = launch_gemm(prec, g, s)) return r;
+    if (int r = launch_gemm(gp, g, s)) return r;
     }
   }
   const float scale = 1.0f / std::sqrt((float)dh);
@@ -891,7 +900,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     ++cur_layer;
     return attention_scores_path(prec, w.qkv, 3L * D, (const char*)w.qkv + (size_t)D * esize(prec),
                                  (const char*)w.qkv + (size_t)2 * D * esize(prec), 3L * D, B, (int)T, H, dh, scale, w.ab,
-                                 false, w.attn_o, D, s, gate, w.relpb);
+                                 false, w.attn_o, D, s, gate, w.relpb, gp);
   };
   auto gemm_rows = [&](const void* A, int K, const DevBuf& W, const DevBuf& bias, int N, void* Cout, int out_f32, int act,
                        const float* resid) -> int {
@@ -899,7 +908,7 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     g.A = A; g.W = W.p; g.C = Cout; g.bias = bias.as<float>(); g.resid = resid;
     g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N;
     g.out_f32 = out_f32; g.act = act;
-    return launch_gemm(prec, g, s);
+    return launch_gemm(gp, g, s);
   };
   float* final_x = nullptr;
   // The residual add lives in the LayerNorm kernel (LN(x + branch)), not in the GEMM epilogue: the GEMM epilogue
@@ -1066,7 +1075,7 @@ struct RcaLayerW {
   DevBuf win, bin, wo, bo, w1, b1, w2, b2, n1g, n1b, n2g, n2b;
 };
 struct svt_rca {
-  int D = 0, H = 0, F = 0, max_len = 0, prec = 0, device = 0;
+  int D = 0, H = 0, F = 0, max_len = 0, prec = 0, gp = 0, device = 0;  // prec: storage type, gp: product engine
   float alpha = 0.5f;
   bool finalized = false;
   ParamMap params;
@@ -1125,10 +1134,10 @@ int svt_rca_create(int32_t d_model, int32_t nhead, int32_t d_ffn, float alpha, i
     set_error("svt_rca_create: bad geometry");
     return SVT_ERR_INVALID;
   }
-  if (precision != SVT_PREC_FP32 && precision != SVT_PREC_BF16) { set_error("svt_rca_create: precision"); return SVT_ERR_INVALID; }
+  if (!valid_precision(precision)) { set_error("svt_rca_create: precision"); return SVT_ERR_INVALID; }
   if (int r = check_device(device)) return r;
   svt_rca* r = new svt_rca();
-  r->D = d_model; r->H = nhead; r->F = d_ffn; r->alpha = alpha; r->max_len = max_len; r->prec = precision; r->device = device;
+  r->D = d_model; r->H = nhead; r->F = d_ffn; r->alpha = alpha; r->max_len = max_len; r->prec = storage_prec(precision); r->gp = precision; r->device = device;
   *out = r;
   return SVT_OK;
 }
@@ -1210,7 +1219,7 @@ int svt_rca_forward(svt_rca* r, const float* audio, int32_t T1, const float* vid
     GemmArgs g;
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
     g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N; g.out_f32 = out_f32; g.act = act;
-    return launch_gemm(prec, g, s);
+    return launch_gemm(r->gp, g, s);
   };
   auto layer = [&](const RcaLayerW& L, const void* kvT, const float* kvF, const void* qT, float* outF) -> int {
     // one packed in-projection of the kv stream gives the self-attention q, and k, v for BOTH attentions
@@ -1218,8 +1227,8 @@ int svt_rca_forward(svt_rca* r, const float* audio, int32_t T1, const float* vid
     if (int rc = gemm_rows(qT, D, L.win.p, L.bin.as<float>(), D, w.qc, 0, ACT_NONE, nullptr)) return rc;
     const char* kp = (const char*)w.qkv + (size_t)D * es;
     const char* vp = (const char*)w.qkv + (size_t)2 * D * es;
-    if (int rc = attention_scores_path(prec, w.qkv, 3L * D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, false, w.att_s, D, s)) return rc;
-    if (int rc = attention_scores_path(prec, w.qc, D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, true, w.att_c, D, s)) return rc;
+    if (int rc = attention_scores_path(prec, w.qkv, 3L * D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, false, w.att_s, D, s, nullptr, nullptr, r->gp)) return rc;
+    if (int rc = attention_scores_path(prec, w.qc, D, kp, vp, 3L * D, B, T, H, dh, scale, w.ab, true, w.att_c, D, s, nullptr, nullptr, r->gp)) return rc;
     // out_proj is linear: alpha*Wo(a_s) + (1-alpha)*Wo(a_c) + bo = Wo(alpha*a_s + (1-alpha)*a_c) + bo
     if (int rc = launch_axpby(prec, w.att_s, w.att_c, r->alpha, 1.f - r->alpha, w.blend, rows * D, s)) return rc;
     if (int rc = gemm_rows(w.blend, D, L.wo.p, L.bo.as<float>(), D, w.preF, 1, ACT_NONE, nullptr)) return rc;
@@ -1255,7 +1264,7 @@ struct VConv {
   DevBuf w, bias, slope;  // w: operand type [Cout][k*k*Cin] tap-major with the BN scale folded; bias / slope fp32
 };
 struct svt_video {
-  int E = 0, prec = 0, device = 0;
+  int E = 0, prec = 0, gp = 0, device = 0;  // prec: storage type, gp: product engine
   bool finalized = false;
   ParamMap params;
   DevBuf stem_w, stem_bias, stem_slope;
@@ -1373,10 +1382,10 @@ extern "C" {
 
 int svt_video_create(int32_t embed_dim, int32_t precision, int device, svt_video** out) {
   if (!out || embed_dim < 8 || embed_dim % 8) { set_error("svt_video_create: embed_dim must be a positive multiple of 8"); return SVT_ERR_INVALID; }
-  if (precision != SVT_PREC_FP32 && precision != SVT_PREC_BF16) { set_error("svt_video_create: precision"); return SVT_ERR_INVALID; }
+  if (!valid_precision(precision)) { set_error("svt_video_create: precision"); return SVT_ERR_INVALID; }
   if (int r = check_device(device)) return r;
   svt_video* v = new svt_video();
-  v->E = embed_dim; v->prec = precision; v->device = device;
+  v->E = embed_dim; v->prec = storage_prec(precision); v->gp = precision; v->device = device;
   *out = v;
   return SVT_OK;
 }
@@ -1500,7 +1509,7 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
     a.c_base = (Wpo + 1) * Cout;
     a.act = slope ? ACT_PRELU : ACT_NONE; a.slope = slope;
     a.resid = (const float*)resid; a.resid_first = 1; a.resid_op_type = 1;
-    return launch_gemm(prec, a, s);
+    return launch_gemm(v->gp, a, s);
   };
   // stage 1 in bf16 mode: G output pixels per GEMM row (see fold_conv_group).  G = 4 may compute up to two pixels past the
   // end of a row (they land on the right halo and on the next row's left halo, re-zeroed afterwards); G = 2 needs an even
@@ -1528,7 +1537,7 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
     a.c_base = (Wp + 1) * 64;
     a.act = ACT_PRELU; a.slope = slope_rep;
     a.resid = (const float*)resid; a.resid_first = 1; a.resid_op_type = 1;
-    if (int r = launch_gemm(prec, a, s)) return r;
+    if (int r = launch_gemm(v->gp, a, s)) return r;
     if (Wq * grp != Ww) return launch_zero_halo(prec, out, F, (int)Hp, (int)Wp, 64, s);
     return 0;
   };
@@ -1565,7 +1574,7 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   GemmArgs pj;
   pj.A = ws.pooled; pj.W = v->proj_w.p; pj.C = out_dev; pj.bias = v->proj_b.as<float>();
   pj.M = (int)F; pj.N = v->E; pj.K = 512; pj.a_rpb = (int)F; pj.a_rstride = 512; pj.ldw = 512; pj.ldc = v->E; pj.out_f32 = 1;
-  if (launch_gemm(prec, pj, s)) return SVT_ERR_HIP;
+  if (launch_gemm(v->gp, pj, s)) return SVT_ERR_HIP;
   return SVT_OK;
 }
 

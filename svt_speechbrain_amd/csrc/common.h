@@ -133,6 +133,7 @@ struct GemmArgs {
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
+  int raster_gm = 8;  // set by the register-staged launcher: M-tiles per band of the block -> tile map (gemm.hip)
   // ---- generalised addressing / epilogue (gen = 1): 2-D convolution as implicit GEMM over a zero-padded
   // channels-last tensor (the lip front-end's ResNet), served by the register-staged kernel ----
   int gen = 0;

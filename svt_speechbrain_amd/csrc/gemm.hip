@@ -18,6 +18,7 @@
 //   * fp32 operands use v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chain) with the same staging and
 //     fragment layout: a fragment is 8 k-consecutive elements per lane for both types.
 #include "common.h"
+#include <type_traits>
 
 namespace svt {
 namespace {
@@ -34,14 +35,57 @@ template <> struct OpTraits<bf16_t> {
 
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_fast(x); }
 
+// ---- split-operand engine (precision "bf16x3" / "fp16x3") -------------------------------------------------------
+// Operands stay fp32 in HBM (the fp32 parity pipeline is unchanged); on its way into LDS every fp32 value x is cut
+// into two 16-bit pieces hi = round16(x), lo = round16(x - hi) and the product is accumulated in fp32 as
+// Wh*Xh + Wh*Xl + Wl*Xh on the 16-bit matrix pipe (v_mfma_f32_16x16x32_{bf16,f16}): three MFMAs of 16 cycles instead of
+// eight fp32 MFMAs of 32 cycles per 16x16x32 block (5.3x fewer matrix cycles), dropped term Wl*Xl ~ 2^-18 (bf16) /
+// 2^-24 (f16) relative.  Measured against the reference goldens (tools/sim_split.py, base 5 s clip): max |dlogit|
+// 8.3e-4 (bf16x3) / 9.3e-5 (fp16x3) vs 3.8e-1 with plain bf16 operands; fp16 pieces need |x| < 65504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int SPLIT> __device__ __forceinline__ void split4(const uint4& raw, uint2& hi, uint2& lo) {
+  const f32x4 x = __builtin_bit_cast(f32x4, raw);
+  if constexpr (SPLIT == 1) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (bf16_t)x[j];
+      l[j] = (bf16_t)(x[j] - (float)h[j]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+  } else {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (_Float16)x[j];
+      l[j] = (_Float16)(x[j] - (float)h[j]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+  }
+}
+template <int SPLIT> __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (SPLIT == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_GELU) return gelu_erf(v);
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
 
-template <typename T, int BM, int BN, bool GEN = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+// SPLIT (T = float only): 0 = exact fp32 MFMA, 1 = bf16x3, 2 = fp16x3 split-operand products (see above)
+// NSET = register sets of the global -> LDS staging, i.e. K slabs in flight per workgroup (the exact-fp32 and bf16 forms
+// multiply a slab for longer than a load takes: one set; the split form's 48 MFMAs per slab last ~0.35 us: two).
+// MINW = waves per SIMD the register allocation must allow.
+template <typename T, int BM, int BN, bool GEN = false, int SPLIT = 0, int NSET = 1, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmArgs p) {
+  static_assert(SPLIT == 0 || sizeof(T) == 4, "split-operand products read fp32 operands");
   constexpr int EPP = OpTraits<T>::EPP;
   constexpr int BK = OpTraits<T>::BK;
   constexpr int KS = BK / 32;         // 32-element MFMA k-steps per slab (2 bf16, 1 fp32)
@@ -60,10 +104,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
 
-  // block -> tile.  blockIdx.x walks M fastest so that consecutive blocks share the same W panel (L2).
+  // block -> tile.  Blocks b, b+8, b+16 ... run on one XCD (round-robin dispatch) and share its 4 MiB L2: each XCD gets
+  // a contiguous range of the logical tile list, and the list walks bands of `raster_gm` M-tiles x all N-tiles (M
+  // fastest inside a band), so the ~64 workgroups an XCD has in flight cover ~8 A panels x ~8 W panels and every panel
+  // is fetched into that L2 once per band instead of once per tile.  (M-fastest over the whole problem streamed A from
+  // the Infinity Cache once per N-tile: the fp32-operand kernels ran at its ~6 TB/s, 190 TFLOP/s in split mode.)
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % tiles_m;
-  const int tile_n = blockIdx.x / tiles_m;
+  int tile_m, tile_n;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles_n = nblk / tiles_m;
+    const int per_band = p.raster_gm * tiles_n;
+    const int band = l / per_band, rem = l - band * per_band;
+    const int left = tiles_m - band * p.raster_gm;
+    const int gm = left < p.raster_gm ? left : p.raster_gm;
+    tile_m = band * p.raster_gm + rem % gm;
+    tile_n = rem / gm;
+  }
   const int z = blockIdx.y;
   const int z1 = z / p.nz2, z2 = z % p.nz2;
   const int m0 = tile_m * BM;
@@ -88,7 +147,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     xsrc[i] = A + off + pc * EPP;
     const int e0 = pc * EPP;
     const int ks = e0 / 32, cq = (e0 % 32) / 8, h = (e0 % 8) / EPP;
-    xdst[i] = (((r >> 4) * KS + ks) * PPC + h) * 64 + cq * 16 + (r & 15);
+    if constexpr (SPLIT) xdst[i] = (((r >> 4) * 2) * 64 + cq * 16 + (r & 15)) * 2 + h;  // uint2 index of the hi piece; lo plane = +128
+    else xdst[i] = (((r >> 4) * KS + ks) * PPC + h) * 64 + cq * 16 + (r & 15);
   }
   const T* wsrc[WP];
   int wdst[WP];
@@ -102,7 +162,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int ks = e0 / 32, cq = (e0 % 32) / 8, h = (e0 % 8) / EPP;
     // row permutation inside each 64-row group: tile row (q*16 + nb*4 + rr) -> MFMA block nb, row 4q+rr
     const int g = r >> 6, q = (r & 63) >> 4, nb = (r & 15) >> 2, rr = r & 3;
-    wdst[i] = X_PIECES + ((((g * 4 + nb) * KS + ks) * PPC + h) * 64 + cq * 16 + (4 * q + rr));
+    if constexpr (SPLIT) wdst[i] = (X_PIECES + ((g * 4 + nb) * 2) * 64 + cq * 16 + (4 * q + rr)) * 2 + h;
+    else wdst[i] = X_PIECES + ((((g * 4 + nb) * KS + ks) * PPC + h) * 64 + cq * 16 + (4 * q + rr));
   }
 
   f32x4 acc[4][4];  // [nb][mb]
@@ -112,41 +173,92 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  uint4 xr[XP], wr[WP];
+  uint4 xr[NSET][XP], wr[NSET][WP];
 
-  auto stage_load = [&](int kt) {
-    const int kbase = kt * BK;
-    const bool ok = (kbase + pc * EPP) < p.K;
+  auto stage_load = [&](auto set_c, int kt) {
+    constexpr int S = decltype(set_c)::value;
+    // The loads are unconditional: a "load or zero" select per piece makes hipcc branch around every load and drain
+    // vmcnt(0) at the top of each iteration (nothing stays in flight across the MFMAs).  A piece past the end of K
+    // (last slab only) re-reads the piece of slab 0 -- valid memory -- and is zeroed when the slab is written to LDS.
+    int kbase = kt * BK;
+    if ((kbase + pc * EPP) >= p.K) kbase = 0;
     long ka = kbase;
     if constexpr (GEN) {
       if (p.kseg) ka = (long)(kbase / p.kseg) * p.kseg_stride + (kbase % p.kseg);
     }
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      xr[i] = ok ? *(const uint4*)(xsrc[i] + ka) : uint4{0, 0, 0, 0};
-    }
+    for (int i = 0; i < XP; ++i) xr[S][i] = *(const uint4*)(xsrc[i] + ka);
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      wr[i] = ok ? *(const uint4*)(wsrc[i] + kbase) : uint4{0, 0, 0, 0};
-    }
+    for (int i = 0; i < WP; ++i) wr[S][i] = *(const uint4*)(wsrc[i] + kbase);
   };
-  auto stage_write = [&](int buf) {
+  const bool k_tail = (p.K % BK) != 0;
+  auto stage_write = [&](auto set_c, int buf, int kt, bool maybe_last = true) {
+    constexpr int S = decltype(set_c)::value;
     uint4* base = lds + buf * STAGE_PIECES;
+    if (maybe_last && k_tail && kt == nk - 1 && (kt * BK + pc * EPP) >= p.K) {
 #pragma unroll
-    for (int i = 0; i < XP; ++i) base[xdst[i]] = xr[i];
+      for (int i = 0; i < XP; ++i) xr[S][i] = uint4{0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < WP; ++i) base[wdst[i]] = wr[i];
+      for (int i = 0; i < WP; ++i) wr[S][i] = uint4{0, 0, 0, 0};
+    }
+    if constexpr (SPLIT) {
+      uint2* b2 = (uint2*)base;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        uint2 hi, lo;
+        split4<SPLIT>(xr[S][i], hi, lo);
+        b2[xdst[i]] = hi;
+        b2[xdst[i] + 128] = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < WP; ++i) {
+        uint2 hi, lo;
+        split4<SPLIT>(wr[S][i], hi, lo);
+        b2[wdst[i]] = hi;
+        b2[wdst[i] + 128] = lo;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) base[xdst[i]] = xr[S][i];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) base[wdst[i]] = wr[S][i];
   };
-
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
+  // slab kt lives in register set kt % NSET until it is written to LDS buffer kt & 1 (during iteration kt - 1); iteration
+  // kt then refills that set with slab kt + NSET, multiplies buffer kt & 1 and writes slab kt + 1
+  // STEADY iterations (kt + NSET < nk guaranteed by the caller) carry no conditionals around the loads and the LDS
+  // writes: with them hipcc cannot prove at the loop header which loads were waited for and drains vmcnt(0) before it
+  // reuses a register of the set, i.e. before every refill.
+  auto iteration = [&](auto u_c, auto steady_c, int kt) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
     const int buf = kt & 1;
-    if (kt + 1 < nk) stage_load(kt + 1);
+    if (STEADY || kt + NSET < nk) stage_load(std::integral_constant<int, U>{}, kt + NSET);
     const uint4* xb = lds + buf * STAGE_PIECES;
     const uint4* wb = xb + X_PIECES;
+    if constexpr (SPLIT) {
+      // one 32-deep k-step per slab: fragments of both planes, then three rounds of 16 independent MFMAs (small terms first)
+      uint4 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        xh[b] = xb[((wm * 4 + b) * 2) * 64 + lane];
+        xl[b] = xb[((wm * 4 + b) * 2 + 1) * 64 + lane];
+        wh[b] = wb[((wn * 4 + b) * 2) * 64 + lane];
+        wl[b] = wb[((wn * 4 + b) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = mfma16<SPLIT>(wl[nb], xh[mb], acc[nb][mb]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = mfma16<SPLIT>(wh[nb], xl[mb], acc[nb][mb]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = mfma16<SPLIT>(wh[nb], xh[mb], acc[nb][mb]);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 xf[4][PPC], wf[4][PPC];
@@ -176,8 +288,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
           }
         }
     }
-    if (kt + 1 < nk) stage_write(buf ^ 1);
+    }
+    if (STEADY || kt + 1 < nk) stage_write(std::integral_constant<int, (U + 1) % NSET>{}, buf ^ 1, kt + 1, !STEADY);
     __syncthreads();
+  };
+
+  stage_load(std::integral_constant<int, 0>{}, 0);
+  if constexpr (NSET > 1) { if (1 < nk) stage_load(std::integral_constant<int, 1>{}, 1); }
+  if constexpr (NSET > 2) { if (2 < nk) stage_load(std::integral_constant<int, 2>{}, 2); }
+  stage_write(std::integral_constant<int, 0>{}, 0, 0);
+  __syncthreads();
+  int kt0 = 0;
+  if constexpr (NSET > 1) {
+    for (; kt0 + 2 * NSET <= nk; kt0 += NSET) {
+      iteration(std::integral_constant<int, 0>{}, std::true_type{}, kt0);
+      iteration(std::integral_constant<int, 1>{}, std::true_type{}, kt0 + 1);
+      if constexpr (NSET > 2) iteration(std::integral_constant<int, 2>{}, std::true_type{}, kt0 + 2);
+    }
+  }
+  for (; kt0 < nk; kt0 += NSET) {
+    iteration(std::integral_constant<int, 0>{}, std::false_type{}, kt0);
+    if constexpr (NSET > 1) { if (kt0 + 1 < nk) iteration(std::integral_constant<int, 1>{}, std::false_type{}, kt0 + 1); }
+    if constexpr (NSET > 2) { if (kt0 + 2 < nk) iteration(std::integral_constant<int, 2>{}, std::false_type{}, kt0 + 2); }
   }
 
   // ---- epilogue: lane holds C[m][nbase .. nbase+15] for each of its 4 row blocks ----
@@ -321,14 +453,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <typename T, int BM, int BN, bool GEN = false>
+template <typename T, int BM, int BN, bool GEN = false, int SPLIT = 0, int NSET = 1, int MINW = 1>
 int launch_one(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
+  GemmArgs ar = a;
+  ar.raster_gm = tiles_n >= 8 ? 8 : 64 / tiles_n;
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, GEN, SPLIT, NSET, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes));
     attr_set = true;
   }
@@ -336,8 +470,8 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.nz +
                        (double)a.M * a.N * a.nz * ((a.out_f32 || sizeof(T) == 4) ? 4 : 2);
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, GEN>), grid, dim3(256), lds_bytes, s, a);
-  prof_end(s, flops, bytes);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, GEN, SPLIT, NSET, MINW>), grid, dim3(256), lds_bytes, s, ar);
+  prof_end(s, flops, bytes, SPLIT ? 0 : 1);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -345,8 +479,12 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_skinny = 1;
-int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
+// prec: 0 = fp32 operands, exact fp32 MFMA; 1 = bf16 operands; 2 / 3 = fp32 operands in memory, bf16x3 / fp16x3
+// split-operand products (every other argument as for prec 0)
+int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
+  const int split = prec_in >= 2 ? prec_in - 1 : 0;
+  const int prec = prec_in >= 2 ? 0 : prec_in;
   const int epp = prec ? 8 : 4;
   if (a.K % epp != 0) { set_error("gemm: K must be a multiple of the 16-byte piece"); return -1; }
   auto mult = [](long v, long m) { return v % m == 0; };
@@ -372,11 +510,18 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
         (!a.resid || a.resid_op_type) && a.alpha == 1.f && (a.kseg == 0 || a.kseg % 64 == 0))
       return launch_gemm_dma(g, s);
     if (prec) return narrow ? launch_one<bf16_t, 256, 64, true>(g, s) : launch_one<bf16_t, 128, 128, true>(g, s);
+    if (split == 1) return narrow ? launch_one<float, 256, 64, true, 1, 1>(g, s) : launch_one<float, 128, 128, true, 1, 2, 2>(g, s);
+    if (split == 2) return narrow ? launch_one<float, 256, 64, true, 2, 1>(g, s) : launch_one<float, 128, 128, true, 2, 2, 2>(g, s);
     return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);
   }
   if (prec && g_gemm_skinny && gemm_skinny_eligible(g)) return launch_gemm_skinny(g, s);
   if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
+  // split engine: two slabs in flight per workgroup, capped at 256 registers so that two workgroups share a CU (measured
+  // on the encoder's shapes, tools/gemm_bench.py --prec 2: one set 185-212, two sets 186-212, three sets (one workgroup per
+  // CU) 150-192 TFLOP/s: the kernel is bound by issue / barrier stalls of its four-wave lockstep, not by the loads)
+  if (split == 1) return narrow ? launch_one<float, 256, 64, false, 1, 1>(g, s) : launch_one<float, 128, 128, false, 1, 2, 2>(g, s);
+  if (split == 2) return narrow ? launch_one<float, 256, 64, false, 2, 1>(g, s) : launch_one<float, 128, 128, false, 2, 2, 2>(g, s);
   return narrow ? launch_one<float, 256, 64>(g, s) : launch_one<float, 128, 128>(g, s);
 }
 

@@ -28,7 +28,7 @@ from .weights import encoder_param_shapes, seeded_encoder_state_dict
 
 logger = logging.getLogger(__name__)
 
-PRECISIONS = {"fp32": 0, "bf16": 1}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x3": 3}
 
 
 class ParamTree(nn.Module):

@@ -14,7 +14,7 @@ DEV = "cuda:0"
 def run_gemm(prec, M, N, K, conv=None, act=0, out_f32=0, resid=False, bias=True, seed=0):
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
-    dt = torch.bfloat16 if prec else torch.float32
+    dt = torch.bfloat16 if prec == 1 else torch.float32  # prec 2 / 3 (bf16x3 / fp16x3): fp32 operands in memory
     if conv:
         T_in, T_out, st, cin = conv
         B = M // T_out
@@ -30,12 +30,12 @@ def run_gemm(prec, M, N, K, conv=None, act=0, out_f32=0, resid=False, bias=True,
     W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(DEV, dt)
     b = torch.randn(N, generator=g).to(DEV) if bias else None
     R = torch.randn(M, N, generator=g).to(DEV) if resid else None
-    C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if (out_f32 or not prec) else dt)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if (out_f32 or prec != 1) else dt)
     _lib.check(lib.svt_debug_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), b.data_ptr() if bias else None,
                                   R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, K, act, out_f32, 0,
                                   torch.cuda.current_stream().cuda_stream), "svt_debug_gemm")
     torch.cuda.synchronize()
-    ref = A_rows @ W.cpu().float().t()
+    ref = (A_rows.double() @ W.cpu().double().t()).float() if prec >= 2 else A_rows @ W.cpu().float().t()
     if bias:
         ref = ref + b.cpu()
     if act == 1:
@@ -62,6 +62,15 @@ CASES = [
     ("fp32_conv", 0, 2 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, False),
     ("fp32_tiny", 0, 24, 64, 32, None, 0, 0, False),
     ("fp32_head", 0, 499, 20, 768, None, 0, 0, False),
+    # split-operand engine (fp32 operands cut into 16-bit (hi, lo) pieces inside the kernel, three MFMAs per block)
+    ("bf16x3", 2, 1000, 768, 512, None, 1, 0, True),
+    ("bf16x3_conv", 2, 2 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, False),
+    ("bf16x3_tiny", 2, 24, 64, 32, None, 0, 0, False),
+    ("bf16x3_narrow_ktail", 2, 499, 20, 772, None, 0, 0, False),
+    ("fp16x3", 3, 1000, 768, 512, None, 1, 0, True),
+    ("fp16x3_conv", 3, 2 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, False),
+    ("fp16x3_ntail", 3, 777, 200, 3072, None, 2, 0, False),
+    ("fp16x3_narrow_ktail", 3, 499, 20, 772, None, 0, 0, False),
 ]
 
 
@@ -71,7 +80,9 @@ def test_gemm_vs_torch(name, prec, M, N, K, conv, act, out_f32, resid):
     assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
     err = (got - ref).abs().max().item()
     # bf16 output rounding dominates in bf16 mode (values O(1..3)); fp32 path is an exact fp32 fma chain
-    tol = 3e-2 if (prec and not out_f32) else (2e-4 if prec else 1e-4)
+    # split-operand products: ~2^-17 (bf16 pieces) / ~2^-22 (fp16 pieces) relative operand error, against an fp64 reference
+    tol = {0: 1e-4, 1: 3e-2 if not out_f32 else 2e-4, 2: 3e-5, 3: 4e-6}[prec]
+    print(f"{name}: max|err| {err:.3e} (tol {tol:g})")
     assert err < tol, (name, err)
 
 

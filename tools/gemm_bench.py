@@ -46,7 +46,7 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
 def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nobias=False):
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    dt = torch.bfloat16 if prec else torch.float32
+    dt = torch.bfloat16 if prec == 1 else torch.float32  # prec 2 / 3: split-operand engine, fp32 operands in memory
     g = torch.Generator(device="cpu").manual_seed(1)
     if conv:
         T_in, T_out, st, cin = conv
@@ -62,7 +62,7 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nob
     if nobias:
         bias.zero_()
     R = torch.randn(M, N, generator=g).to(dev) if resid else None
-    C = torch.empty(M, N, device=dev, dtype=torch.float32 if (out_f32 or not prec) else dt)
+    C = torch.empty(M, N, device=dev, dtype=torch.float32 if (out_f32 or prec != 1) else dt)
     st_ = torch.cuda.current_stream().cuda_stream
 
     def call():
@@ -99,7 +99,7 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nob
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * M * N * K / ms / 1e9
-    print(f"{name:12s} M={M:7d} N={N:5d} K={K:5d} prec={'bf16' if prec else 'fp32'} {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s"
+    print(f"{name:12s} M={M:7d} N={N:5d} K={K:5d} prec={('fp32', 'bf16', 'bf16x3', 'fp16x3')[prec]} {ms * 1e3:9.1f} us  {tf:8.1f} TFLOP/s"
           + (f"  max|err|={err:.3e}" if err is not None else ""), flush=True)
 
 

@@ -1,0 +1,83 @@
+"""CPU simulation (build container, test infrastructure): what does a split-operand MFMA mode cost in accuracy?
+
+Every dense product of the oracle (F.linear / F.conv1d / torch.matmul) is replaced by a sum of products of
+low-precision pieces of its operands, accumulated in fp32 -- the arithmetic a `precision="bf16x3"` GEMM performs on
+v_mfma_f32_16x16x32_bf16 -- and the result is compared with the reference golden of the same case.
+
+    python tools/sim_split.py base_c1 bf16x1 bf16x3 bf16x6 f16x1 f16x3
+"""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from oracle import svt_oracle as O  # noqa: E402
+from svt_speechbrain_amd import weights as W  # noqa: E402
+from svt_speechbrain_amd.config import PRESETS  # noqa: E402
+
+
+def pieces(x, dt, n):
+    out, r = [], x.float()
+    for _ in range(n):
+        p = r.to(dt).float()
+        out.append(p)
+        r = r - p
+    return out
+
+
+def make_ops(mode):
+    dt = torch.bfloat16 if mode.startswith("bf16") else torch.float16
+    nprod = int(mode.split("x")[1])
+    # product list: (index of A piece, index of W piece), smallest terms dropped
+    plan = {1: [(0, 0)], 3: [(0, 0), (1, 0), (0, 1)], 6: [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]}[nprod]
+    npieces = max(max(a, b) for a, b in plan) + 1
+    lin, conv, mm = F.linear, F.conv1d, torch.matmul
+
+    def linear(x, w, b=None):
+        xs, ws = pieces(x, dt, npieces), pieces(w, dt, npieces)
+        y = sum(lin(xs[i], ws[j]) for i, j in reversed(plan))
+        return y if b is None else y + b
+
+    def conv1d(x, w, b=None, **kw):
+        if x.shape[1] == 1:  # conv0 is not an MFMA product in the kernels (fp32 VALU)
+            return conv(x, w, b, **kw)
+        xs, ws = pieces(x, dt, npieces), pieces(w, dt, npieces)
+        y = sum(conv(xs[i], ws[j], None, **kw) for i, j in reversed(plan))
+        return y if b is None else y + b[None, :, None]
+
+    def matmul(a, b):
+        xs, ws = pieces(a, dt, npieces), pieces(b, dt, npieces)
+        return sum(mm(xs[i], ws[j]) for i, j in reversed(plan))
+
+    return linear, conv1d, matmul
+
+
+def main():
+    name = sys.argv[1]
+    fx = torch.load(f"tests/golden/{name}.pt", weights_only=False)
+    cfg = PRESETS[fx["cfg"]]
+    sd = W.seeded_encoder_state_dict(cfg, seed=fx["weight_seed"])
+    hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=fx["head_seed"])
+    g = torch.Generator().manual_seed(fx["wav_seed"])
+    wav = (0.1 * torch.randn(fx["B"], fx["L"], generator=g)).clamp_(-1, 1)
+    torch.set_num_threads(8)
+    keep = (F.linear, F.conv1d, torch.matmul)
+    for mode in sys.argv[2:]:
+        F.linear, F.conv1d, torch.matmul = make_ops(mode)
+        try:
+            with torch.no_grad():
+                feats = O.encoder_forward(sd, cfg, wav)
+        finally:
+            F.linear, F.conv1d, torch.matmul = keep
+        with torch.no_grad():
+            logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
+        err = (logits - fx["logits"]).abs()
+        _, _, octv, pc = O.decode_frames(logits)
+        d = fx["decode"][0]
+        mism = int(((octv[0] != d["oct"]) | (pc[0] != d["pc"])).sum())
+        print(f"{name} {mode}: max|dlogit| {err.max():.3e} mean {err.mean():.3e} argmax mismatches {mism}/{octv.shape[1]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
