@@ -162,6 +162,27 @@ PRESETS = {
 }
 
 
+# ``do_normalize`` of the hub models' preprocessor_config.json (the reference sets ``normalize_wav`` from it,
+# MIR_ST500/huggingface_interface.py:103,130).  The files cannot be fetched offline; the values are restated from the
+# fairseq task configs the checkpoints were trained with (``task.normalize``: False for the LibriSpeech-960 BASE models
+# of HuBERT and WavLM, True for wav2vec 2.0, data2vec and every LARGE model).  A local model directory's own
+# preprocessor_config.json always wins; a source that is not in the table gets True with a warning.
+PRESET_DO_NORMALIZE = {
+    "wav2vec2-base": True, "wav2vec2-base-960h": True, "wav2vec2-large-lv60": True, "wav2vec2-large-960h-lv60": True,
+    "hubert-base-ls960": False, "hubert-large-ll60k": True, "hubert-large-ls960-ft": True, "hubert-xlarge-ll60k": True,
+    "wavlm-base": False, "wavlm-base-plus": False, "wavlm-large": True,
+    "data2vec-audio-base": True, "data2vec-audio-large": True,
+}
+
+
+def preset_do_normalize(source: str):
+    """``do_normalize`` for a hub id / preset name, or None when it is not known offline."""
+    key = str(source).rstrip("/").split("/")[-1]
+    if key.startswith("tiny-") or key.startswith("avhubert"):
+        return True  # this package's own test geometries
+    return PRESET_DO_NORMALIZE.get(key)
+
+
 def config_from_source(source: str) -> EncoderConfig:
     """Pick a preset from a HF hub id / local name the way the reference picks the model class:
     by substring (``MIR_ST500/huggingface_interface.py:107-119``)."""

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._device import DeviceObjects
 from .huggingface_interface import ParamTree, PRECISIONS
 from .weights import seeded_fusion_state_dict
 
@@ -42,10 +43,7 @@ class FusionRCA(nn.Module):
         for name in ("positional_encoding", "layer1", "layer2"):
             ordered.add_module(name, tree._modules[name])
         self.fusion = ordered
-        self._handle = None
-        self._key = None
-        self._sig = None
-        self._ws = None
+        self._dev = DeviceObjects("svt_rca_destroy")  # one C object per device, shared with DataParallel replicas
 
     def _tensors(self):
         for n, p in self.fusion.named_parameters():
@@ -57,38 +55,23 @@ class FusionRCA(nn.Module):
         lib = _lib.load()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        key = (idx, self.precision, float(self.alpha))
+        slot = self._dev.slot(idx, (self.precision, float(self.alpha)))
         sig = tuple((t.data_ptr(), t._version) for _, t in self._tensors())
-        if self._handle is not None and key == self._key and sig == self._sig:
-            return
-        if self._handle is not None and key != self._key:
-            lib.svt_rca_destroy(self._handle)
-            self._handle = None
-        if self._handle is None:
+        if slot.handle is not None and sig == slot.sig:
+            return slot
+        if slot.handle is None:
             h = C.c_void_p()
             _lib.check(lib.svt_rca_create(self.d_model, self.nhead, self.d_ffn, float(self.alpha), self.max_length,
                                           PRECISIONS[self.precision], idx, C.byref(h)), "svt_rca_create")
-            self._handle, self._key = h, key
+            slot.handle = h
         for name, t in self._tensors():
             c = t.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * c.dim())(*c.shape)
-            _lib.check(lib.svt_rca_load_param(self._handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
+            _lib.check(lib.svt_rca_load_param(slot.handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
                        f"svt_rca_load_param({name})")
-        _lib.check(lib.svt_rca_finalize(self._handle), "svt_rca_finalize")
-        self._sig = sig
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        self._sig = None
-        return r
-
-    def __del__(self):
-        try:
-            if getattr(self, "_handle", None) is not None:
-                _lib.load().svt_rca_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+        _lib.check(lib.svt_rca_finalize(slot.handle), "svt_rca_finalize")
+        slot.sig = sig
+        return slot
 
     def forward(self, audio_feats: torch.Tensor, video_feats: torch.Tensor) -> torch.Tensor:
         if not (audio_feats.is_cuda and video_feats.is_cuda):
@@ -101,17 +84,15 @@ class FusionRCA(nn.Module):
         if abs(T1 - T2) > 15:
             print("Alignment is wrong")  # the reference's diagnostic (fusion.py:204-205)
         lib = _lib.load()
-        self._sync(audio_feats.device)
+        slot = self._sync(audio_feats.device)
         a = audio_feats.detach().to(torch.float32).contiguous()
         v = video_feats.detach().to(torch.float32).contiguous()
-        need = lib.svt_rca_workspace_bytes(self._handle, B, T1)
+        need = lib.svt_rca_workspace_bytes(slot.handle, B, T1)
         if need < 0:
             raise _lib.SvtError(_lib.last_error())
-        if self._ws is None or self._ws.numel() < need or self._ws.device != a.device:
-            self._ws = None
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=a.device)
+        ws = slot.workspace(need, a.device)
         out = torch.empty((B, T1, D), dtype=torch.float32, device=a.device)
-        _lib.check(lib.svt_rca_forward(self._handle, _lib.ptr(a), T1, _lib.ptr(v), T2, B, _lib.ptr(out),
-                                       _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(a.device)),
+        _lib.check(lib.svt_rca_forward(slot.handle, _lib.ptr(a), T1, _lib.ptr(v), T2, B, _lib.ptr(out),
+                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr(a.device)),
                    "svt_rca_forward")
         return out

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._device import DeviceObjects
 from .config import EncoderConfig, PRESETS, config_from_source
 from .weights import encoder_param_shapes, seeded_encoder_state_dict
 
@@ -128,17 +129,23 @@ class HuggingFaceWav2Vec2(nn.Module):
         kept for signature compatibility (the reference caches downloads there); unused offline.
     pretrain, output_norm, freeze, freeze_feature_extractor, apply_spec_augment : as the reference.
         There is no network in this build, so ``pretrain=True`` loads a local checkpoint when ``source``
-        is a directory that has one and otherwise keeps the seeded initialisation (a warning is logged);
-        load real weights afterwards with ``load_state_dict`` (checkpointer path of the recipes).
+        is a directory that has one.  With a hub id / preset name and ``pretrain=True`` there is nothing to
+        download from: the weights stay seeded-random until ``load_state_dict`` / a ``Checkpointer`` recovers
+        the fine-tuned checkpoint (the recipes' evaluation path) -- a warning says so; pass
+        ``allow_random_init=False`` to make that case an error instead.
 
-    Extra keyword-only arguments: ``config`` (an ``EncoderConfig``), ``precision`` ("bf16" throughput mode /
-    "fp32" parity mode; env ``SVT_PRECISION`` sets the default), ``normalize_wav`` (the reference reads
-    ``feature_extractor.do_normalize``; default True), ``seed``.
+    Extra keyword-only arguments: ``config`` (an ``EncoderConfig``), ``precision`` ("bf16" throughput mode, "fp32"
+    exact-fp32 parity mode, "fp16x3" / "bf16x3" split-operand parity modes on the 16-bit matrix pipe; env
+    ``SVT_PRECISION`` sets the default), ``normalize_wav`` (the reference reads ``feature_extractor.do_normalize`` of the
+    checkpoint's ``preprocessor_config.json``: a local directory is read the same way, presets carry the published value
+    of their hub model -- ``config.PRESET_DO_NORMALIZE`` -- and an unknown hub id falls back to True with a warning),
+    ``seed``.
     """
 
     def __init__(self, source, save_path=None, pretrain=True, output_norm=True, freeze=True,
                  freeze_feature_extractor=False, apply_spec_augment=False, *, config: Optional[EncoderConfig] = None,
-                 precision: Optional[str] = None, normalize_wav: Optional[bool] = None, seed: int = 1986):
+                 precision: Optional[str] = None, normalize_wav: Optional[bool] = None, seed: int = 1986,
+                 allow_random_init: bool = True):
         super().__init__()
         if apply_spec_augment:
             raise NotImplementedError("apply_spec_augment is a training-time mask; the MI355X path is forward-only")
@@ -150,7 +157,16 @@ class HuggingFaceWav2Vec2(nn.Module):
             # *.ckpt is a SpeechBrain-pretrained one, otherwise FileNotFoundError.  (*.safetensors -- what current transformers
             # writes -- is accepted as a HuggingFace model too.)
             files = sorted(os.listdir(source))
-            hf = [fn for fn in files if fn.endswith(".bin")] or [fn for fn in files if fn.endswith(".safetensors")]
+            # the weights file among the *.bin (optimizer.bin / training_args.bin / scheduler.bin sit beside it in a
+            # Trainer output directory): pytorch_model.bin / model.safetensors first, then their shards via the
+            # *.index.json, then any other *.bin / *.safetensors that is not a known non-weights file
+            not_weights = ("optimizer.bin", "training_args.bin", "scheduler.bin", "rng_state.pth", "scaler.pt")
+            hf = [fn for fn in ("pytorch_model.bin", "model.safetensors") if fn in files]
+            if not hf:
+                hf = [fn for fn in ("pytorch_model.bin.index.json", "model.safetensors.index.json") if fn in files]
+            if not hf:
+                hf = ([fn for fn in files if fn.endswith(".bin") and fn not in not_weights]
+                      or [fn for fn in files if fn.endswith(".safetensors")])
             sb = [fn for fn in files if fn.endswith(".ckpt")]
             if hf:
                 local_ckpt = os.path.join(source, hf[0])
@@ -170,7 +186,14 @@ class HuggingFaceWav2Vec2(nn.Module):
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}")
         self.precision = precision
-        self.normalize_wav = True if normalize_wav is None else bool(normalize_wav)
+        if normalize_wav is None:
+            from .config import preset_do_normalize
+            normalize_wav = preset_do_normalize(source if isinstance(source, str) else cfg.name)
+            if normalize_wav is None:
+                logger.warning("HuggingFaceWav2Vec2(%s): do_normalize of this source is not known offline (the reference reads "
+                               "it from the hub's preprocessor_config.json); assuming True -- pass normalize_wav= to set it", source)
+                normalize_wav = True
+        self.normalize_wav = bool(normalize_wav)
         self.output_norm = output_norm
         self.freeze = freeze
         self.freeze_feature_extractor = freeze_feature_extractor
@@ -179,12 +202,27 @@ class HuggingFaceWav2Vec2(nn.Module):
         self.model = ParamTree()
         for k, v in seeded_encoder_state_dict(cfg, seed=seed).items():
             self.model.add(k, v)
+        # device side: one C object per device (shared with nn.DataParallel replicas, see _device.py) and ONE generation
+        # counter of the parameter values, shared BY REFERENCE with every replica(): whoever changes the weights bumps it,
+        # every device object compares it before a forward
+        self._dev = DeviceObjects("svt_encoder_destroy")
+        self._gen = [0]
+        self._dp_replica = False
+        self._warned_grad = False
+        # state loaded through a PARENT module (nn.ModuleDict.load_state_dict, Brain.modules, Checkpointer on the whole
+        # model) never calls this object's load_state_dict: nn.Module recursion goes through _load_from_state_dict of the
+        # children.  The hooks do the key normalisation and the invalidation on that path too.
+        self.model._register_load_state_dict_pre_hook(self._pre_load_hook)
+        self.model.register_load_state_dict_post_hook(self._post_load_hook)
         if pretrain:
             if local_ckpt is not None:
                 self._load_local(local_ckpt)
+            elif not allow_random_init:
+                raise FileNotFoundError(f"HuggingFaceWav2Vec2({source!r}, pretrain=True): no local checkpoint and no network "
+                                        "in this build; point `source` at a model directory or pass allow_random_init=True")
             else:
-                logger.warning("HuggingFaceWav2Vec2(%s): no network / local checkpoint in this build; weights are "
-                               "seeded random until load_state_dict() is called", source)
+                logger.warning("HuggingFaceWav2Vec2(%s): pretrain=True but there is no network / local checkpoint in this build; "
+                               "the weights are SEEDED RANDOM until load_state_dict() / a Checkpointer loads real ones", source)
         if self.freeze:
             self.model.eval()
             for p in self.model.parameters():
@@ -195,19 +233,40 @@ class HuggingFaceWav2Vec2(nn.Module):
                 for n, p in self.model.named_parameters():
                     if n.startswith("feature_extractor."):
                         p.requires_grad = False
-        self._handle = None
-        self._handle_dev = None
-        self._sig = None
-        self._ws = None
-        self._warned_grad = False
 
     # ------------------------------------------------------------------ checkpoint intake
-    def _load_local(self, path: str) -> None:
+    @staticmethod
+    def _read_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
+        if path.endswith(".index.json"):  # sharded HuggingFace checkpoint: weight_map = {key: shard file}
+            with open(path) as fh:
+                shards = sorted(set(json.load(fh)["weight_map"].values()))
+            sd = {}
+            for fn in shards:
+                sd.update(HuggingFaceWav2Vec2._read_checkpoint_file(os.path.join(os.path.dirname(path), fn)))
+            return sd
         if path.endswith(".safetensors"):
             from safetensors.torch import load_file
-            sd = load_file(path)
-        else:
-            sd = torch.load(path, map_location="cpu")
+            return load_file(path)
+        return torch.load(path, map_location="cpu")
+
+    def _pre_load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Runs at the top of ``self.model``'s ``_load_from_state_dict`` (whatever module ``load_state_dict`` was called
+        on): both weight-norm spellings of the positional conv are accepted, HF's ``masked_spec_embed`` is dropped."""
+        pc = prefix + "encoder.pos_conv_embed.conv."
+        for old, new in ((pc + "weight_g", pc + "parametrizations.weight.original0"),
+                         (pc + "weight_v", pc + "parametrizations.weight.original1")):
+            if old in state_dict:
+                state_dict[new] = state_dict.pop(old)
+        state_dict.pop(prefix + "masked_spec_embed", None)
+
+    def _post_load_hook(self, module, incompatible_keys):
+        self._invalidate()
+
+    def _invalidate(self) -> None:
+        self._gen[0] += 1
+
+    def _load_local(self, path: str) -> None:
+        sd = self._read_checkpoint_file(path)
         own = set(self.model.state_dict().keys())
         out = {}
         if path.endswith(".ckpt"):
@@ -234,7 +293,7 @@ class HuggingFaceWav2Vec2(nn.Module):
     def _load_model_state(self, sd: Dict[str, torch.Tensor], strict: bool) -> None:
         sd = self._normalise_keys(sd)
         self.model.load_state_dict(sd, strict=strict)
-        self._sig = None
+        self._invalidate()
 
     @staticmethod
     def _normalise_key(k: str) -> str:
@@ -261,69 +320,78 @@ class HuggingFaceWav2Vec2(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(self._normalise_keys(dict(state_dict)), strict=strict, **kw)
-        self._sig = None
+        self._invalidate()
         return res
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._sig = None
+        self._invalidate()
+        return r
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel (the reference's multi-GPU mode): the replica shares the registry of device objects and the
+        # generation counter by reference; its parameters are per-forward broadcast copies, so it never compares tensor
+        # identities -- the slot of its device is (re)filled only when the generation moved
+        r = super()._replicate_for_data_parallel()
+        r._dp_replica = True
         return r
 
     # ------------------------------------------------------------------ device-side object
     def _params_signature(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.model.parameters()) + list(self.model.buffers()))
 
-    def _sync_device(self, device: torch.device) -> None:
+    def _sync_device(self, device: torch.device):
+        """Make the C object of ``device`` current with the parameters; returns its slot (handle + workspace)."""
         lib = _lib.load()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        key = (idx, self.normalize_wav, self.output_norm, self.precision)
-        # frozen (the reference default): the parameters only change through load_state_dict / .to() / refresh(), which drop
-        # the signature -- walking the ~200 tensors on every forward costs ~0.4 ms of host time, half of a one-clip forward
-        if self._handle is not None and key == self._handle_dev and self._sig is not None and self.freeze:
-            return
-        sig = self._params_signature()
-        if self._handle is not None and key == self._handle_dev and sig == self._sig:
-            return
-        if self._handle is not None and key != self._handle_dev:
-            lib.svt_encoder_destroy(self._handle)
-            self._handle = None
-        if self._handle is None:
+        slot = self._dev.slot(idx, (self.normalize_wav, self.output_norm, self.precision))
+        gen = self._gen[0]
+        if slot.handle is not None and slot.gen == gen:
+            # frozen (the reference default) or a DataParallel replica: the values only change through load_state_dict (on
+            # this module, a parent or a replica's original) / .to() / refresh(), all of which move the generation.  A
+            # two-tensor sentinel still catches an in-place edit of the weights; walking all ~200 tensors on every
+            # forward costs ~0.4 ms of host time, half of a one-clip forward.
+            if self._dp_replica:
+                return slot
+            if self.freeze:
+                if slot.sig is not None and self._sentinel() == slot.sig[1]:
+                    return slot
+            elif slot.sig is not None and self._params_signature() == slot.sig[0]:
+                return slot
+        if slot.handle is None:
             h = C.c_void_p()
             cc = _config_to_c(self.config, self.normalize_wav, self.output_norm, self.precision)
             _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
-            self._handle, self._handle_dev = h, key
+            slot.handle = h
         for name, p in self.model.state_dict().items():
             if not p.is_floating_point():
                 continue  # BatchNorm's num_batches_tracked
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(lib.svt_encoder_load_param(self._handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
+            _lib.check(lib.svt_encoder_load_param(slot.handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
                                                   t.dim()), f"svt_encoder_load_param({name})")
-        _lib.check(lib.svt_encoder_finalize(self._handle), "svt_encoder_finalize")
-        self._sig = sig
+        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize")
+        slot.sig = (None if self.freeze else self._params_signature(), self._sentinel())
+        slot.gen = gen
+        return slot
 
-    def __del__(self):
-        try:
-            if getattr(self, "_handle", None) is not None:
-                _lib.load().svt_encoder_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+    def _sentinel(self):
+        ts = list(self.model.parameters())
+        return tuple((t.data_ptr(), t._version) for t in (ts[0], ts[len(ts) // 2], ts[-1]))
 
     def refresh(self) -> None:
         """Re-upload the parameters on the next forward (after editing them in place while ``freeze=True``)."""
-        self._sig = None
+        self._invalidate()
 
     def replica(self):
         """A second encoder object over the SAME parameter tensors with its own device handle and workspace: what a caller
-        needs to keep two forwards in flight on two HIP streams (bench.py, SongTranscriber)."""
+        needs to keep two forwards in flight on two HIP streams (bench.py, SongTranscriber).  It shares the generation
+        counter with this object: ``load_state_dict`` / ``refresh`` / ``.to()`` on either one re-uploads both."""
         import copy
         c = copy.copy(self)
-        c._handle = None
-        c._handle_dev = None
-        c._sig = None
-        c._ws = None
+        c._dev = DeviceObjects("svt_encoder_destroy")
+        # copy.copy shares _parameters / _modules dicts and the _gen list; the load hooks of self.model fire for both
         return c
 
     def num_frames(self, n_samples: int) -> int:
@@ -347,20 +415,18 @@ class HuggingFaceWav2Vec2(nn.Module):
         if not wav.is_cuda:
             raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
         lib = _lib.load()
-        self._sync_device(wav.device)
+        slot = self._sync_device(wav.device)
         x = wav.detach().to(torch.float32).contiguous()
         B, L = x.shape
         T = self.config.frames(L)
         if B < 1 or T < 1:
             raise ValueError(f"waveform of {L} samples is shorter than the encoder's receptive field")
-        need = lib.svt_encoder_workspace_bytes(self._handle, B, L)
+        need = lib.svt_encoder_workspace_bytes(slot.handle, B, L)
         if need < 0:
             raise _lib.SvtError(_lib.last_error())
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
-            self._ws = None
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        ws = slot.workspace(need, x.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=x.device)
-        _lib.check(lib.svt_encoder_forward_ex(self._handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(self._ws),
-                                              self._ws.numel(), _lib.stream_ptr(x.device), int(clips_per_norm_group)),
+        _lib.check(lib.svt_encoder_forward_ex(slot.handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream_ptr(x.device), int(clips_per_norm_group)),
                    "svt_encoder_forward")
         return out

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._device import DeviceObjects
 
 
 class Linear(nn.Module):
@@ -23,37 +24,28 @@ class Linear(nn.Module):
             if len(input_shape) == 4 and self.combine_dims:
                 input_size = input_shape[2] * input_shape[3]
         self.w = nn.Linear(input_size, n_neurons, bias=bias)
-        self._handle = None
-        self._key = None
+        self._dev = DeviceObjects("svt_linear_destroy")  # one C object per device, shared with DataParallel replicas
 
     def _sync(self, device):
         lib = _lib.load()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        key = (idx, self.w.weight.data_ptr(), self.w.weight._version,
+        slot = self._dev.slot(idx, (self.w.in_features, self.w.out_features, self.w.bias is not None))
+        sig = (self.w.weight.data_ptr(), self.w.weight._version,
                None if self.w.bias is None else (self.w.bias.data_ptr(), self.w.bias._version))
-        if self._handle is not None and key == self._key:
-            return
-        if self._handle is None or self._key[0] != idx:
-            if self._handle is not None:
-                lib.svt_linear_destroy(self._handle)
+        if slot.handle is not None and sig == slot.sig:
+            return slot
+        if slot.handle is None:
             h = C.c_void_p()
             _lib.check(lib.svt_linear_create(self.w.in_features, self.w.out_features, int(self.w.bias is not None), idx,
                                              C.byref(h)), "svt_linear_create")
-            self._handle = h
+            slot.handle = h
         w = self.w.weight.detach().to("cpu", torch.float32).contiguous()
         b = None if self.w.bias is None else self.w.bias.detach().to("cpu", torch.float32).contiguous()
-        _lib.check(lib.svt_linear_load(self._handle, C.c_void_p(w.data_ptr()),
+        _lib.check(lib.svt_linear_load(slot.handle, C.c_void_p(w.data_ptr()),
                                        C.c_void_p(b.data_ptr()) if b is not None else None), "svt_linear_load")
-        self._key = key
-
-    def __del__(self):
-        try:
-            if getattr(self, "_handle", None) is not None:
-                _lib.load().svt_linear_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+        slot.sig = sig
+        return slot
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4 and self.combine_dims:
@@ -61,11 +53,11 @@ class Linear(nn.Module):
         if not x.is_cuda:
             raise _lib.SvtError("svt_speechbrain_amd.Linear needs its input on the GPU; there is no CPU fallback")
         lib = _lib.load()
-        self._sync(x.device)
+        slot = self._sync(x.device)
         xf = x.detach().to(torch.float32).contiguous()
         rows = xf.numel() // xf.shape[-1] if xf.numel() else 0
         y = torch.empty(xf.shape[:-1] + (self.w.out_features,), dtype=torch.float32, device=x.device)
         if rows:
-            _lib.check(lib.svt_linear_forward(self._handle, _lib.ptr(xf), rows, _lib.ptr(y), _lib.stream_ptr(x.device)),
+            _lib.check(lib.svt_linear_forward(slot.handle, _lib.ptr(xf), rows, _lib.ptr(y), _lib.stream_ptr(x.device)),
                        "svt_linear_forward")
         return y

@@ -95,6 +95,9 @@ class SongTranscriber:
                 else:
                     feats = encs[k](song[lo:hi].unsqueeze(0))  # batch of one utterance, as in the reference eval
                 logits = self.head(feats)
+                if k:  # produced on a side stream, consumed (cat + decode) on the main one: tell the caching allocator
+                    logits.record_stream(main)
+                    feats.record_stream(main)
                 logits_all.append(logits.reshape(-1, logits.shape[-1]))
                 if return_feats:
                     feats_all.append(feats.reshape(-1, feats.shape[-1]))

@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._device import DeviceObjects
 from .huggingface_interface import ParamTree, PRECISIONS
 from .weights import seeded_video_frontend_state_dict
 
@@ -52,10 +53,7 @@ class SubModel(nn.Module):
                 if ("frontend3D" in key or "trunk" in key) and new_key in own:
                     own[new_key] = val
             self.load_state_dict(own)
-        self._handle = None
-        self._key = None
-        self._sig = None
-        self._ws = None
+        self._dev = DeviceObjects("svt_video_destroy")  # one C object per device, shared with DataParallel replicas
 
     def _tensors(self):
         for n, p in self.named_parameters():
@@ -67,39 +65,24 @@ class SubModel(nn.Module):
         lib = _lib.load()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        key = (idx, self.precision)
+        slot = self._dev.slot(idx, (self.precision,))
         sig = tuple((t.data_ptr(), t._version) for _, t in self._tensors())
-        if self._handle is not None and key == self._key and sig == self._sig:
-            return
-        if self._handle is not None and key != self._key:
-            lib.svt_video_destroy(self._handle)
-            self._handle = None
-        if self._handle is None:
+        if slot.handle is not None and sig == slot.sig:
+            return slot
+        if slot.handle is None:
             h = C.c_void_p()
             _lib.check(lib.svt_video_create(self.embed_dim, PRECISIONS[self.precision], idx, C.byref(h)), "svt_video_create")
-            self._handle, self._key = h, key
+            slot.handle = h
         for name, t in self._tensors():
             if name.endswith("num_batches_tracked"):
                 continue
             c = t.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * c.dim())(*c.shape)
-            _lib.check(lib.svt_video_load_param(self._handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
+            _lib.check(lib.svt_video_load_param(slot.handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
                        f"svt_video_load_param({name})")
-        _lib.check(lib.svt_video_finalize(self._handle), "svt_video_finalize")
-        self._sig = sig
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        self._sig = None
-        return r
-
-    def __del__(self):
-        try:
-            if getattr(self, "_handle", None) is not None:
-                _lib.load().svt_video_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+        _lib.check(lib.svt_video_finalize(slot.handle), "svt_video_finalize")
+        slot.sig = sig
+        return slot
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
@@ -108,17 +91,15 @@ class SubModel(nn.Module):
             raise ValueError(f"expected a (B, 1, T, H, W) lip ROI tensor, got {tuple(x.shape)}")
         B, _, T, H, W = x.shape
         lib = _lib.load()
-        self._sync(x.device)
+        slot = self._sync(x.device)
         v = x.detach().to(torch.float32).contiguous()
-        need = lib.svt_video_workspace_bytes(self._handle, B, T, H, W)
+        need = lib.svt_video_workspace_bytes(slot.handle, B, T, H, W)
         if need < 0:
             raise ValueError(f"unsupported geometry {tuple(x.shape)}")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != v.device:
-            self._ws = None
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=v.device)
+        ws = slot.workspace(need, v.device)
         out = torch.empty((B, T, self.embed_dim), dtype=torch.float32, device=v.device)
-        _lib.check(lib.svt_video_forward(self._handle, _lib.ptr(v), B, T, H, W, _lib.ptr(out), _lib.ptr(self._ws),
-                                         self._ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward")
+        _lib.check(lib.svt_video_forward(slot.handle, _lib.ptr(v), B, T, H, W, _lib.ptr(out), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward")
         return out.transpose(1, 2)  # (B, embed_dim, T), the reference's layout
 
 
@@ -183,10 +164,7 @@ class FairseqAVHubertPretrain(nn.Module):
             self.eval()
             for p in self.parameters():
                 p.requires_grad = False
-        self._handle = None
-        self._key = None
-        self._sig = None
-        self._ws = None
+        self._dev = DeviceObjects("svt_encoder_destroy")  # one C object per device, shared with DataParallel replicas
 
     @staticmethod
     def _read_fairseq_checkpoint(path):
@@ -212,7 +190,6 @@ class FairseqAVHubertPretrain(nn.Module):
             if k not in sd:
                 sd[k] = own[k]
         self.model.load_state_dict(sd, strict=True)
-        self._sig = None
 
     def _transformer_tensors(self):
         for n, p in self.model.named_parameters():
@@ -223,41 +200,26 @@ class FairseqAVHubertPretrain(nn.Module):
         lib = _lib.load()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        key = (idx, self.precision, bool(self.output_norm))
+        slot = self._dev.slot(idx, (self.precision, bool(self.output_norm)))
         sig = tuple((p.data_ptr(), p._version) for _, p in self._transformer_tensors())
-        if self._handle is not None and key == self._key and sig == self._sig:
-            return
-        if self._handle is not None and key != self._key:
-            lib.svt_encoder_destroy(self._handle)
-            self._handle = None
-        if self._handle is None:
+        if slot.handle is not None and sig == slot.sig:
+            return slot
+        if slot.handle is None:
             h = C.c_void_p()
             cc = _config_to_c(self.config, False, bool(self.output_norm), self.precision)
             _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
-            self._handle, self._key = h, key
+            slot.handle = h
         for name, p in self._transformer_tensors():
             hf = fairseq_to_hf_key(name)
             if hf is None:
                 raise _lib.SvtError(f"no encoder slot for parameter {name}")
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(lib.svt_encoder_load_param(self._handle, hf.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()),
+            _lib.check(lib.svt_encoder_load_param(slot.handle, hf.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()),
                        f"svt_encoder_load_param({hf})")
-        _lib.check(lib.svt_encoder_finalize(self._handle), "svt_encoder_finalize")
-        self._sig = sig
-
-    def _apply(self, fn, *a, **k):
-        r = super()._apply(fn, *a, **k)
-        self._sig = None
-        return r
-
-    def __del__(self):
-        try:
-            if getattr(self, "_handle", None) is not None:
-                _lib.load().svt_encoder_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize")
+        slot.sig = sig
+        return slot
 
     def forward(self, wav, clips_per_norm_group: int = 0):
         """``clips_per_norm_group`` (extension, 0 = the reference): the wrapper's whole-tensor output norm over groups of that
@@ -276,15 +238,13 @@ class FairseqAVHubertPretrain(nn.Module):
         feats = torch.zeros((B, T, 2 * E), dtype=torch.float32, device=fv.device)
         feats[:, :, E:] = fv.transpose(1, 2)                       # audio half = zeros (hubert.py:700-702)
         lib = _lib.load()
-        self._sync(feats.device)
-        need = lib.svt_encoder_workspace_bytes(self._handle, B, T)
+        slot = self._sync(feats.device)
+        need = lib.svt_encoder_workspace_bytes(slot.handle, B, T)
         if need < 0:
             raise _lib.SvtError(_lib.last_error())
-        if self._ws is None or self._ws.numel() < need or self._ws.device != feats.device:
-            self._ws = None
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=feats.device)
+        ws = slot.workspace(need, feats.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=feats.device)
-        _lib.check(lib.svt_encoder_forward_ex(self._handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(self._ws),
-                                              self._ws.numel(), _lib.stream_ptr(feats.device), int(clips_per_norm_group)),
+        _lib.check(lib.svt_encoder_forward_ex(slot.handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream_ptr(feats.device), int(clips_per_norm_group)),
                    "svt_encoder_forward")
         return out

@@ -70,7 +70,7 @@ def test_plain_c_caller_matches_python_binding_and_golden(golden, tmp_path, name
     raw = open(out, "rb").read()
     B, T, D = struct.unpack("<iqi", raw[:16])
     got = torch.from_numpy(np.frombuffer(raw[16:], dtype=np.float32).reshape(B, T, D).copy())
-    enc = S.HuggingFaceWav2Vec2(fx["cfg"], None, config=cfg, precision=precision, seed=fx["weight_seed"]).to("cuda:0")
+    enc = S.HuggingFaceWav2Vec2(fx["cfg"], None, config=cfg, normalize_wav=True, precision=precision, seed=fx["weight_seed"]).to("cuda:0")
     py = enc(wav.to("cuda:0")).cpu()
     assert got.shape == py.shape
     # same library, same kernels, same inputs: the two callers agree to the last bits (fp64 atomics in the whole-batch norms)

@@ -54,7 +54,7 @@ def test_random_geometry_vs_oracle(seed):
             f"{cfg.feat_extract_norm}/{'pre' if cfg.do_stable_layer_norm else 'post'}-LN kp={cfg.num_conv_pos_embeddings} "
             f"g={cfg.num_conv_pos_embedding_groups} B={B} L={L}")
     for prec, bound in (("fp32", 1e-3), ("bf16", None)):
-        enc = S.HuggingFaceWav2Vec2(cfg.name, None, config=cfg, precision=prec, seed=seed).to(DEV)
+        enc = S.HuggingFaceWav2Vec2(cfg.name, None, config=cfg, normalize_wav=True, precision=prec, seed=seed).to(DEV)
         got = enc(wav.to(DEV)).cpu()
         assert got.shape == want.shape, desc
         d = (got - want).abs()
@@ -127,8 +127,8 @@ def test_bf16_tracks_fp32_across_batch_and_length(cfg_name):
     its error bound of the fp32 path (which the golden / oracle tests pin)."""
     from svt_speechbrain_amd.config import PRESETS
     cfg = PRESETS[cfg_name]
-    e32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=4).to(DEV)
-    e16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=4).to(DEV)
+    e32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="fp32", seed=4).to(DEV)
+    e16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="bf16", seed=4).to(DEV)
     r = random.Random(77)
     cases = [(1, 16000), (1, 80000), (2, 80000), (3, 47000), (4, 160000), (6, 80000), (8, 80000), (12, 40000), (16, 80000),
              (24, 30000), (35, 80000)]

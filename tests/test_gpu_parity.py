@@ -25,7 +25,7 @@ def synth_wav(B, L, seed):
 
 def build(cfg_name, weight_seed, head_seed, precision):
     cfg = PRESETS[cfg_name]
-    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision=precision, seed=weight_seed).to(DEV)
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision=precision, seed=weight_seed).to(DEV)
     head = S.Linear(20, input_size=cfg.hidden_size)
     head.load_state_dict(W.seeded_head_state_dict(cfg.hidden_size, 20, seed=head_seed))
     return cfg, enc, head.to(DEV)
@@ -240,8 +240,8 @@ def test_full_size_properties(cfg_name, B, L):
     determinism (bitwise), whole-batch output norm (zero mean / unit variance), permutation equivariance
     over clips (the batch statistics are permutation invariant), fp32 vs bf16 agreement."""
     cfg = PRESETS[cfg_name]
-    enc32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=5).to(DEV)
-    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=5).to(DEV)
+    enc32 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="fp32", seed=5).to(DEV)
+    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="bf16", seed=5).to(DEV)
     wav = synth_wav(B, L, 123).to(DEV)
     a = enc32(wav)
     b = enc32(wav)
@@ -443,12 +443,12 @@ def test_odd_shapes_vs_oracle(cfg_name, B, L):
     wav = synth_wav(B, L, 78)
     want = O.encoder_forward(sd, cfg, wav)
     assert want.shape == (B, cfg.frames(L), cfg.hidden_size)
-    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="fp32", seed=77).to(DEV)
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="fp32", seed=77).to(DEV)
     got = enc(wav.to(DEV)).cpu()
     err = (got - want).abs().max().item()
     print(f"{cfg_name} B={B} L={L} T={want.shape[1]}: fp32 max|err| {err:.2e}")
     assert err < 1e-3
-    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision="bf16", seed=77).to(DEV)
+    enc16 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision="bf16", seed=77).to(DEV)
     got16 = enc16(wav.to(DEV)).cpu()
     d = (got16 - want).abs()
     print(f"   bf16 mean|err| {d.mean():.4f} max {d.max():.3f}")
@@ -463,7 +463,7 @@ def test_per_clip_norm_groups_equal_batch1_forwards(cfg_name, B, L, prec, tol):
     train_audio_ssl.py:90), and != the whole-batch norm of the default call.  In bf16 the batch runs on other GEMM tilings
     than a single utterance, so the two agree to bf16 rounding only."""
     cfg = PRESETS[cfg_name]
-    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, precision=prec, seed=21).to(DEV)
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision=prec, seed=21).to(DEV)
     wav = synth_wav(B, L, 22)
     wav[1] *= 3.0  # clips of different loudness: the whole-batch norm and the per-clip norm differ visibly
     wav = wav.to(DEV)
@@ -499,3 +499,36 @@ def test_song_transcriber_batched_utterances_same_notes():
     assert (fc - fb).abs().max().item() < 2e-4 and c == b
     d = S.SongTranscriber(enc, head, streams=1, max_batch=2).transcribe(song)
     assert d == b
+
+
+def test_reload_reaches_replicas_and_parent_module_loads():
+    """Advisor round 1: a replica() kept by a caller (SongTranscriber lanes, bench.py streams) must serve the NEW weights after
+    load_state_dict on the original, and a state dict loaded through a parent nn.ModuleDict (Brain.modules / Checkpointer)
+    must both normalise the old weight-norm keys and re-upload, with freeze=True (the reference default)."""
+    cfg = PRESETS["tiny-layer"]
+    enc = S.HuggingFaceWav2Vec2("tiny-layer", None, config=cfg, precision="fp32", seed=1).to(DEV)
+    rep = enc.replica()
+    wav = synth_wav(2, 3000, 2).to(DEV)
+    a0, r0 = enc(wav).cpu(), rep(wav).cpu()
+    assert torch.equal(a0, r0)
+    sd77 = W.seeded_encoder_state_dict(cfg, seed=77)
+    enc.load_state_dict({"model." + k: v for k, v in sd77.items()})
+    with torch.no_grad():
+        ref77 = O.encoder_forward(sd77, cfg, wav.cpu())
+    a1, r1 = enc(wav).cpu(), rep(wav).cpu()
+    assert (a1 - ref77).abs().max() < 1e-3
+    assert torch.equal(a1, r1), "the replica kept serving the previous checkpoint"
+    # through a parent module, old key spelling + HF-only key, strict
+    parent = torch.nn.ModuleDict({"wav2vec2": enc})
+    sd5 = W.seeded_encoder_state_dict(cfg, seed=5)
+    new = {"wav2vec2.model." + k: v for k, v in W.seeded_encoder_state_dict(cfg, seed=5, old_weight_norm_keys=True).items()}
+    new["wav2vec2.model.masked_spec_embed"] = torch.zeros(cfg.hidden_size)
+    parent.load_state_dict(new, strict=True)
+    with torch.no_grad():
+        ref5 = O.encoder_forward(sd5, cfg, wav.cpu())
+    assert (enc(wav).cpu() - ref5).abs().max() < 1e-3
+    assert (rep(wav).cpu() - ref5).abs().max() < 1e-3
+    # an in-place edit without any hook: the sentinel tensors catch the first / middle / last parameter
+    with torch.no_grad():
+        next(iter(enc.model.parameters())).mul_(1.5)
+    assert (enc(wav).cpu() - ref5).abs().max() > 1e-3

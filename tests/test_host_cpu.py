@@ -398,3 +398,98 @@ def test_plain_c_caller_of_the_cabi_compiles(tmp_path):
                         "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.exists(exe)
+
+
+# ---- round-2 advisor findings: every way the weights can change must reach every device object ----
+def test_state_loaded_through_a_parent_module_is_normalised_and_invalidates():
+    """``Brain.modules`` is an ``nn.ModuleDict`` and ``Checkpointer`` may load through it: nn.Module recursion never calls
+    the child's ``load_state_dict``, so the key normalisation (old weight-norm spelling, HF-only ``masked_spec_embed``) and
+    the invalidation of the uploaded copy live in load hooks of ``.model``."""
+    cfg = PRESETS["tiny-layer"]
+    enc = S.HuggingFaceWav2Vec2("tiny-layer", None, config=cfg, seed=1)
+    rep = enc.replica()
+    parent = torch.nn.ModuleDict({"wav2vec2": enc, "model": S.Linear(20, input_size=cfg.hidden_size)})
+    new = {"wav2vec2.model." + k: v for k, v in W.seeded_encoder_state_dict(cfg, seed=77, old_weight_norm_keys=True).items()}
+    new["wav2vec2.model.masked_spec_embed"] = torch.zeros(cfg.hidden_size)
+    new.update({"model." + k: v for k, v in parent["model"].state_dict().items()})
+    g0 = enc._gen[0]
+    res = parent.load_state_dict(new, strict=True)          # strict: the reference's checkpoint hook (utils/checkpoints.py:69-95)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert enc._gen[0] > g0 and rep._gen is enc._gen        # the replica sees the same generation counter
+    want = W.seeded_encoder_state_dict(cfg, seed=77)
+    for k, v in enc.model.state_dict().items():
+        assert torch.equal(v, want[k]), k
+    g1 = enc._gen[0]
+    enc.model.load_state_dict(want, strict=True)             # loading straight into .model invalidates too
+    assert enc._gen[0] > g1
+    g2 = enc._gen[0]
+    rep.load_state_dict({"model." + k: v for k, v in want.items()})   # ... and so does loading into a replica
+    assert enc._gen[0] > g2
+    g3 = enc._gen[0]
+    enc.refresh()
+    assert enc._gen[0] > g3
+
+
+def test_replica_and_data_parallel_replica_device_state():
+    """``replica()``: same parameters, OWN registry of device objects.  ``nn.DataParallel`` replicas (``replicate`` shallow-copies
+    ``__dict__``) SHARE the registry, so nothing is freed twice and each device keeps one C object across forwards."""
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg)
+    rep = enc.replica()
+    assert rep._dev is not enc._dev and rep.model is enc.model
+    dp = enc._replicate_for_data_parallel()
+    assert dp._dev is enc._dev and dp._gen is enc._gen and dp._dp_replica and not enc._dp_replica
+    for mod in (S.Linear(20, input_size=64), S.FusionRCA(d_model=64, nhead=8, d_ffn=128, max_length=50)):
+        r = mod._replicate_for_data_parallel()
+        assert r._dev is mod._dev
+    from svt_speechbrain_amd._device import DeviceObjects
+    d = DeviceObjects("svt_encoder_destroy")
+    a = d.slot(0, ("x",))
+    assert d.slot(0, ("x",)) is a and d.slot(1, ("x",)) is not a
+    assert d.slot(0, ("y",)) is not a        # other flags on the same device: the old slot is replaced
+    d.close()
+
+
+def test_local_directory_picks_the_weights_file_and_reads_shards(tmp_path):
+    """A Trainer output directory holds optimizer.bin / training_args.bin beside the weights, and large checkpoints come as
+    shards with an index: the wrapper must load pytorch_model.bin (or the shards), never the alphabetically first *.bin."""
+    import json
+    cfg = PRESETS["tiny-group"]
+    sd = W.seeded_encoder_state_dict(cfg, seed=5)
+    (tmp_path / "config.json").write_text(json.dumps({
+        "model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 4, "intermediate_size": 128,
+        "conv_dim": [32] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}))
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"do_normalize": False}))
+    torch.save({"state": torch.zeros(3)}, tmp_path / "optimizer.bin")
+    torch.save({"lr": 1.0}, tmp_path / "a_training_args.bin")
+    torch.save(sd, tmp_path / "pytorch_model.bin")
+    enc = S.HuggingFaceWav2Vec2(str(tmp_path), str(tmp_path))
+    assert enc.normalize_wav is False
+    for k, v in enc.model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # sharded form
+    (tmp_path / "pytorch_model.bin").unlink()
+    keys = list(sd.keys())
+    half = len(keys) // 2
+    torch.save({k: sd[k] for k in keys[:half]}, tmp_path / "pytorch_model-00001-of-00002.bin")
+    torch.save({k: sd[k] for k in keys[half:]}, tmp_path / "pytorch_model-00002-of-00002.bin")
+    wm = {k: ("pytorch_model-00001-of-00002.bin" if i < half else "pytorch_model-00002-of-00002.bin") for i, k in enumerate(keys)}
+    (tmp_path / "pytorch_model.bin.index.json").write_text(json.dumps({"weight_map": wm}))
+    enc2 = S.HuggingFaceWav2Vec2(str(tmp_path), str(tmp_path))
+    for k, v in enc2.model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_pretrain_without_weights_and_do_normalize_defaults(caplog):
+    from svt_speechbrain_amd.config import preset_do_normalize
+    with pytest.raises(FileNotFoundError, match="no local checkpoint"):
+        S.HuggingFaceWav2Vec2("facebook/wav2vec2-base", None, allow_random_init=False)
+    with caplog.at_level("WARNING"):
+        enc = S.HuggingFaceWav2Vec2("facebook/wav2vec2-base", None)     # the recipes' call: weights come from the Checkpointer later
+    assert "SEEDED RANDOM" in caplog.text
+    assert enc.normalize_wav is True
+    # the reference reads feature_extractor.do_normalize: False for the LibriSpeech-960 BASE models of HuBERT / WavLM
+    assert preset_do_normalize("facebook/hubert-base-ls960") is False and preset_do_normalize("microsoft/wavlm-base") is False
+    assert preset_do_normalize("facebook/hubert-large-ll60k") is True and preset_do_normalize("some/unknown-model") is None
+    assert S.HuggingFaceWav2Vec2("facebook/hubert-base-ls960", None, pretrain=False).normalize_wav is False
+    assert S.HuggingFaceWav2Vec2("facebook/hubert-base-ls960", None, pretrain=False, normalize_wav=True).normalize_wav is True
