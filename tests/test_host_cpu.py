@@ -289,6 +289,21 @@ def test_transcription_scores_hand_derived():
     with pytest.raises(ValueError):
         SC.score_song([[1.0, 1.0, 60]], refs)
     assert SC.midi_to_hz(69) == pytest.approx(440.0) and SC.midi_to_hz(57) == pytest.approx(220.0)
+    # COff (N20EMv2/audio_only/train_audio_ssl.py:148-150): offsets alone, tolerance max(0.2 * ref duration, 0.05)
+    #   est0 off 1.1 vs ref0 off 1.0 (tol 0.2) hit; est1 off 2.0 = ref1; est2 off 3.5 vs ref2 3.0 (tol 0.2) miss, but 3.5 is
+    #   within no other ref; est3 off 6.0 none  -> 2 matches
+    assert m["Offset_Precision"] == pytest.approx(2 / 4) and m["Offset_Recall"] == pytest.approx(2 / 3)
+    assert m["Offset_F-measure"] == pytest.approx(4 / 7)
+    # a long reference note widens its own offset window only: ref dur 2.0 -> tol 0.4
+    assert SC.score_song([[0.0, 2.39, 60]], [[0.0, 2.0, 60]])["Offset_F-measure"] == 1.0
+    assert SC.score_song([[0.0, 2.41, 60]], [[0.0, 2.0, 60]])["Offset_F-measure"] == 0.0
+    assert SC.score_song([[0.5, 1.04, 60]], [[0.0, 1.0, 60]])["Offset_F-measure"] == 1.0   # floor of 50 ms
+    # overlap ratio of the one fully matched pair: intersection [0.02, 1.0] / union [0.0, 1.1]
+    assert m["Average_Overlap_Ratio"] == pytest.approx(0.98 / 1.1)
+    assert m["Average_Overlap_Ratio_no_offset"] == pytest.approx((0.98 / 1.1 + 1.0 / 1.5) / 2)
+    assert set(m) == {"Precision", "Recall", "F-measure", "Average_Overlap_Ratio", "Precision_no_offset", "Recall_no_offset",
+                      "F-measure_no_offset", "Average_Overlap_Ratio_no_offset", "Onset_Precision", "Onset_Recall",
+                      "Onset_F-measure", "Offset_Precision", "Offset_Recall", "Offset_F-measure"}
 
 
 def test_config_from_source_family_heuristics():
