@@ -10,17 +10,29 @@ One step = encoder forward (incl. both whole-batch layer norms) -> 20-way head -
 decode kernel (+ one all-gather of the logits over RCCL when N > 1).  Weak scaling: the per-GPU batch is
 fixed, ranks own disjoint clips.  Prints ONE JSON line on rank 0.
 
-Successive steps are issued round-robin on two HIP streams (--streams, each with its own encoder object and
-workspace): every step still computes its whole batch, but the HBM-bound kernels of one step overlap the MFMA-bound
-kernels of the next.  The roofline leg (HIP events around every launch of the dominant kernel) replays the K steps on
-one stream after the timed region.
+The timed loop is ``svt_speechbrain_amd.distributed.run_sharded`` (the same function the 2-rank gloo test runs on CPU):
+W warm-up steps, barrier + device sync, EXACTLY K steps, device sync + barrier, MAX over ranks.  Successive steps are
+issued round-robin on two HIP streams (--streams, each with its own encoder object, workspace and preallocated gather
+buffers): every step still computes its whole batch, but the HBM-bound kernels of one step overlap the MFMA-bound
+kernels of the next.
+
+After the timed region (never part of `value`):
+  * roofline leg   -- the same K steps on ONE stream with a HIP-event pair around every dense-contraction launch;
+  * sustained leg  -- >= 3 s of back-to-back steps (`sustained_clips_per_s`) with shader-clock / wall-clock stamps
+                      (s_memtime / s_memrealtime) on either side: the clock the chip HELD under this load;
+  * notes-out leg  -- step + device-to-host copy of the decoded frames + `frames2note` of every clip
+                      (`notes_out_clips_per_s`: "greedy decode" all the way to note lists on the host);
+  * cpu_baseline   -- the oracle on the host cores, SURVEY.md §8(d) protocol (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -33,6 +45,7 @@ import torch  # noqa: E402
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 
 def synth_wav(B, L, seed=1986):
@@ -40,40 +53,67 @@ def synth_wav(B, L, seed=1986):
     return (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
 
 
-def cpu_baseline(cfg, sd, hd, seconds, budget_s=25.0):
-    """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the host cores.
-    ATen's intra-op threading stops scaling well before 128 cores on this workload (measured on the GPU box:
-    16 threads 3.95 clips/s, 64 threads 2.5, 128 threads 1.1), so a short sweep picks the best thread count
-    and `cores` reports the threads actually used for the quoted number."""
-    from oracle import svt_oracle as O
-    ncpu = os.cpu_count() or 1
-    B = 4
-    wav = synth_wav(B, int(16000 * seconds), seed=1986)
+def host_topology():
+    """(sockets, physical cores, logical CPUs, text) from lscpu; falls back to os.cpu_count()."""
+    logical = os.cpu_count() or 1
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        sockets = int(kv.get("Socket(s)", "1"))
+        cps = int(kv.get("Core(s) per socket", str(logical)))
+        tpc = int(kv.get("Thread(s) per core", "1"))
+        model = kv.get("Model name", "?")
+        return sockets, sockets * cps, logical, f"{sockets} socket(s) x {cps} cores x {tpc} thread(s), {model}"
+    except Exception:
+        return 1, logical, logical, f"{logical} logical CPUs (lscpu unavailable)"
 
-    def one():
+
+def cpu_baseline(cfg, sd, hd, budget_s=40.0):
+    """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the GPU box's host cores, protocol of
+    SURVEY.md §8(d): 2 warm-ups, then the MEDIAN of 5 timed passes, for C1 (one 5 s clip: latency and clips/s) and for the
+    throughput point B = 8 x 10 s, with torch.set_num_threads(N), N = the physical cores of the host (socket layout in
+    `sample`).  ATen's intra-op threading stops scaling well below the core count of a 2-socket host on this workload
+    (measured here: 16 threads 3.4-4.6 clips/s, 128 threads ~1.1), so the same protocol is repeated at 16 threads and the
+    better throughput is `value` -- the CPU gets its best configuration; both are listed.  A configuration whose passes
+    would exceed the time budget stops early (at least 3 timed passes) and says so."""
+    from oracle import svt_oracle as O
+    sockets, phys, logical, layout = host_topology()
+
+    def one(wav):
         with torch.no_grad():
             f = O.encoder_forward(sd, cfg, wav)
             lg = O.head_forward(f, hd["w.weight"], hd["w.bias"])
             O.decode_frames(lg)
 
-    t_start = time.perf_counter()
-    best = None
-    tried = []
-    for nt in [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]:
-        if time.perf_counter() - t_start > budget_s:
-            break
+    def protocol(wav, share_s):
+        t_cfg = time.perf_counter()
+        for _ in range(2):
+            one(wav)
+        ts = []
+        while len(ts) < 5 and (len(ts) < 3 or time.perf_counter() - t_cfg < share_s):
+            t = time.perf_counter()
+            one(wav)
+            ts.append(time.perf_counter() - t)
+        return statistics.median(ts), len(ts), (max(ts) - min(ts)) / statistics.median(ts)
+
+    wav_c1 = synth_wav(1, 80000, seed=1986)
+    wav_tp = synth_wav(8, 160000, seed=1986)
+    rows = []
+    t_all = time.perf_counter()
+    for nt in dict.fromkeys([min(phys, logical), min(16, logical)]):
         torch.set_num_threads(nt)
-        one()  # warm-up at this thread count
-        t = time.perf_counter()
-        one()
-        dt = time.perf_counter() - t
-        tried.append((nt, round(B / dt, 3)))
-        if best is None or dt < best[1]:
-            best = (nt, dt)
-    nt, dt = best
-    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": nt, "kind": "port",
-            "sample": f"oracle/svt_oracle.py fp32 (torch CPU), {B} x {seconds:g} s clips per pass, 1 warm-up + 1 timed pass "
-                      f"per thread count, best of {tried} (threads, clips/s); host has {ncpu} logical CPUs"}
+        left = budget_s - (time.perf_counter() - t_all)
+        lat, n1, _ = protocol(wav_c1, 0.15 * left)
+        med, n8, spread = protocol(wav_tp, 0.45 * left)
+        rows.append({"threads": nt, "c1_latency_ms": round(1e3 * lat, 1), "c1_clips_per_s": round(1.0 / lat, 3), "c1_passes": n1,
+                     "b8x10s_clips_per_s": round(8.0 / med, 4), "b8x10s_passes": n8, "b8x10s_spread": round(spread, 3)})
+    best = max(rows, key=lambda r: r["b8x10s_clips_per_s"])
+    return {"value": best["b8x10s_clips_per_s"], "unit": "clips/s", "cores": best["threads"], "kind": "port",
+            "physical_cores": phys, "sockets": sockets, "logical_cpus": logical, "host": layout,
+            "c1_latency_ms": best["c1_latency_ms"], "c1_clips_per_s": best["c1_clips_per_s"], "by_threads": rows,
+            "sample": "oracle/svt_oracle.py fp32 (torch CPU): 8 x 10 s clips per pass (throughput, `value`) and one 5 s clip "
+                      "(C1 latency); 2 warm-ups + median of up to 5 timed passes per thread count (N = physical cores and 16); "
+                      f"host: {layout}"}
 
 
 def main():
@@ -86,9 +126,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained and notes-out legs (profiling runs)")
+    ap.add_argument("--sustain-seconds", type=float, default=3.2)
+    ap.add_argument("--gather", default="logits", choices=["logits", "frames"],
+                    help="N > 1: all-gather the fp32 logits (80 B per frame, the north star's collective) or the compact decoded "
+                         "frames (16 B per frame, SURVEY.md §8e)")
     ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
                     "(the PCIe-inclusive rate; never the reported metric, whose inputs are resident in HBM)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured: no gain, the GPU is never idle)")
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
                     "object and workspace), so one step's HBM-bound kernels (LayerNorm, conv0, norms) run under the next step's MFMA-bound "
                     "ones: measured +5 %% with 2, less with 3.  The roofline leg always runs on one stream.")
@@ -97,6 +141,7 @@ def main():
     import svt_speechbrain_amd as S
     from svt_speechbrain_amd import _lib, distributed as D
     from svt_speechbrain_amd import weights as W
+    from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note
 
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # before the process group: RCCL binds to it
     rank, local, world = D.init_from_env()
@@ -123,79 +168,53 @@ def main():
         wav = synth_wav(B, L).to(dev)
 
     ns = max(1, args.streams)
-    enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, seed=1986).to(dev)
+    enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, normalize_wav=True, seed=1986).to(dev)
     encs = [enc] + [enc.replica() for _ in range(ns - 1)]  # same parameters, own device handle + workspace per stream
     head = S.Linear(20, input_size=cfg.hidden_size)
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=2986)
     head.load_state_dict(hd)
     head = head.to(dev)
-    frames_l = [torch.empty((B * T, 4), dtype=torch.int32, device=dev) for _ in range(ns)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    frames_l = [torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev) for _ in range(ns)]
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] + [torch.cuda.Stream() for _ in range(ns - 1)]
     wav_host = wav.cpu().pin_memory() if args.h2d else None
     wav_in = [torch.empty_like(wav) for _ in range(ns)] if args.h2d else None
-    counter = [0]
-    active = [ns]  # streams in use (the roofline leg sets this to 1)
+    gather_frames = args.gather == "frames"
+    gatherers = [D.RowGatherer(n_total, world, rank, (T, 4) if gather_frames else (T, 20),
+                               torch.int32 if gather_frames else torch.float32, dev) for _ in range(ns)]
 
-    import contextlib
-
-    def step():
-        i = counter[0] % active[0]
-        counter[0] += 1
-        # one stream: launch on whatever stream is current (during hipGraph capture that is the capture stream)
-        with (torch.cuda.stream(streams[i]) if ns > 1 else contextlib.nullcontext()):
+    def make_forward(i):
+        def fwd():
             if args.h2d:
                 wav_in[i].copy_(wav_host, non_blocking=True)
             feats = encs[i](wav_in[i] if args.h2d else wav)
             logits = head(feats)
-            _lib.check(lib.svt_decode_frames(_lib.ptr(logits), B * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
+            _lib.check(lib.svt_decode_frames(_lib.ptr(logits), (hi - lo) * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
                                              _lib.stream_ptr(dev)), "svt_decode_frames")
-            if world > 1:
-                return D.all_gather_rows(logits, n_total, world)
-        return logits
+            if i:
+                logits.record_stream(main_stream)  # allocated on a side stream, read by whoever consumes `out` on the main one
+            return frames_l[i] if gather_frames else logits
+        return fwd
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    # The step is ~110 dependent kernel launches with no host decisions in between: capture it once into a hipGraph
-    # (the C-ABI forward neither allocates nor synchronises) and replay it; every replay executes the full step.
-    graph = None
-    if args.graph and world == 1 and ns == 1:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as ex:  # capture is an optimisation, never a requirement
-            print(f"[bench] hipGraph capture unavailable ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+    fwds = [make_forward(i) for i in range(ns)]
+    lanes = [(lambda s=s: torch.cuda.stream(s)) for s in streams] if ns > 1 else [None]
+
+    def run(steps, warmup, n_lanes=ns):
+        return D.run_sharded(fwds[:n_lanes], n_total, rank, world, steps, warmup, dev, lanes=lanes[:n_lanes],
+                             gatherers=gatherers[:n_lanes], sync=torch.cuda.synchronize)
+
+    run(0, args.warmup)
     # HIP-event pairs around every SAMPLE-th dense-contraction launch of the timed region itself (on the launch stream): the
     # live measurement.  Sampling keeps the cost of the event records (~5 % of a step when every launch carries a pair) below 1 %.
     SAMPLE = 8
     lib.svt_prof_reset()
-    if graph is None:
-        lib.svt_prof_enable(SAMPLE)
-    D.barrier(world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            out = step()
-    torch.cuda.synchronize()
-    D.barrier(world)
-    elapsed = time.perf_counter() - t0
+    lib.svt_prof_enable(SAMPLE)
+    res = run(args.steps, 0)
     lib.svt_prof_enable(0)
-    elapsed = D.max_over_ranks(elapsed, world, dev)
+    elapsed = res["elapsed"]
+    out = res["out"]
     assert out.shape[0] == n_total
-    # a step is >= ~110 kernels: anything faster than this did not run the work (e.g. an empty captured graph)
+    # a step is >= ~110 kernels: anything faster than this did not run the work
     if 1e3 * elapsed / args.steps < 0.05:
         raise SystemExit("[bench] implausible step time: the timed region did not execute the step")
 
@@ -211,16 +230,70 @@ def main():
     # launch x ~70 launches per step add ~5 % of GPU idle time.
     # It runs on ONE stream: with two, kernels of consecutive steps share the chip and a launch lasts ~1.2x longer while the
     # job finishes sooner -- a per-launch duration under overlap says nothing about the kernel.
-    active[0] = 1
-    counter[0] = 0
     lib.svt_prof_reset()
     lib.svt_prof_enable(1)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+    run(args.steps, 0, n_lanes=1)
     lib.svt_prof_enable(0)
-
     k_dom, k_other, k_attn = prof(0), prof(1), prof(2)
+
+    # sustained leg: the chip needs ~2.5 s of load to settle to the clock it holds (profiles/r01_gemm_clock_trace.txt); the
+    # step count is derived from the max-over-ranks step time, so every rank issues the same number of collectives
+    sustained = None
+    if not args.no_extra_legs:
+        n_sus = max(args.steps, int(math.ceil(args.sustain_seconds / (elapsed / args.steps))))
+        stamps = torch.zeros((2, 16), dtype=torch.int64, device=dev)
+        _lib.check(lib.svt_debug_clock(_lib.ptr(stamps[0]), local, _lib.stream_ptr(dev)), "svt_debug_clock")
+        sres = run(n_sus, 0)
+        _lib.check(lib.svt_debug_clock(_lib.ptr(stamps[1]), local, _lib.stream_ptr(dev)), "svt_debug_clock")
+        torch.cuda.synchronize()
+        st = stamps.cpu().view(2, 8, 2)
+        ghz = []
+        for x in range(8):
+            if st[0, x, 1] > 0 and st[1, x, 1] > st[0, x, 1]:
+                ghz.append(float(st[1, x, 0] - st[0, x, 0]) / float(st[1, x, 1] - st[0, x, 1]) * 0.1)
+        ghz = [g for g in ghz if 0.3 < g < 3.0]
+        sustained = {"steps": n_sus, "seconds": round(sres["elapsed"], 3),
+                     "clips_per_s": round(n_total * n_sus / sres["elapsed"], 3),
+                     "ms_per_step": round(1e3 * sres["elapsed"] / n_sus, 4),
+                     "shader_clock_ghz": round(statistics.median(ghz), 4) if ghz else None,
+                     "shader_clock_ghz_per_xcd": [round(g, 4) for g in ghz],
+                     "clock_method": "d(s_memtime) / d(s_memrealtime) x 100 MHz between two stamp kernels around the leg, per XCD"}
+
+    # notes-out leg (local shard): step -> frames to the host -> note lists, i.e. "greedy decode" all the way out.  Two
+    # batches are in flight: while the host turns the frames of step i into notes, the GPU runs step i + 1 on the other lane
+    # (frames_l / pinned host buffers are per lane), which is how a caller that wants notes would drive the path.
+    notes_out = None
+    if not args.no_extra_legs:
+        fr_host = [torch.empty((hi - lo, T, 4), dtype=torch.int32).pin_memory() for _ in range(ns)]
+        done = [torch.cuda.Event() for _ in range(ns)]
+        n_it = 8
+        n_notes = 0
+        host_s = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for it in range(n_it + 1):
+            if it < n_it:
+                i = it % ns
+                with torch.cuda.stream(streams[i]):
+                    fwds[i]()
+                    fr_host[i].copy_(frames_l[i], non_blocking=True)
+                    done[i].record()
+            if pending is not None:
+                done[pending].synchronize()
+                th = time.perf_counter()
+                fr = fr_host[pending].numpy().view(FRAME_DTYPE).reshape(hi - lo, T)
+                n_notes = sum(len(frames2note(fr[b], 0.4, 0.5, 1 / 49.8)) for b in range(hi - lo))
+                host_s += time.perf_counter() - th
+            pending = (it % ns) if it < n_it else None
+            if ns == 1 and pending is not None:  # one lane: nothing to overlap with, finish this batch before the next step
+                done[0].synchronize()
+        dt = time.perf_counter() - t0
+        notes_out = {"clips_per_s": round((hi - lo) * n_it / dt, 3), "ms_per_step": round(1e3 * dt / n_it, 4), "iterations": n_it,
+                     "host_ms_per_step": round(1e3 * host_s / n_it, 4), "notes_in_last_batch": int(n_notes),
+                     "what": "per rank: step + D2H copy of the decoded frames (16 B per frame, pinned) + frames2note of every clip on the host "
+                             "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); the host work of step i overlaps the GPU "
+                             "work of step i + 1 (one batch per lane in flight); host_ms_per_step = the frames2note share"}
 
     if rank == 0:
         clips_per_s = n_total * args.steps / elapsed
@@ -232,16 +305,16 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 read correction applied: tools/pmc_summary.py);
         # null when that file is absent or the workload is not the default one
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc_file) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
+        if os.path.exists(PMC_TRAFFIC_FILE) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
             try:
-                pm = json.load(open(pmc_file))
-                fam = [v for k, v in pm.items() if k.startswith(("gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel"))]
+                pm = json.load(open(PMC_TRAFFIC_FILE))
+                fam = [v for k, v in pm.items() if k.startswith(("gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel", "ffn_fused_kernel"))]
                 tot_n = sum(v["launches"] for v in fam)
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
             except Exception:
                 traffic = None
-        res = {
+        split = args.precision in ("bf16x3", "fp16x3")
+        res_json = {
             "metric": "10s@16kHz clips/sec encoder+CTC forward, wav2vec2-base, 1/2/4/8 MI355X",
             "value": round(clips_per_s, 3),
             "unit": "clips/s",
@@ -258,15 +331,23 @@ def main():
                                    f"{B} x {args.seconds:g} s @16 kHz mono clips per GPU",
                        "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
-                       "launch": "hipGraph replay" if graph is not None else "eager",
-                       "streams": ns, "inputs": "pinned host memory, copied every step (diagnostic)" if args.h2d else "resident in HBM",
+                       "launch": "eager", "streams": ns,
+                       "inputs": "pinned host memory, copied every step (diagnostic)" if args.h2d else "resident in HBM",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
-            # dominant kernel = svt::gemm_pp8_kernel<BM> (conv1-6, projection, q/k/v/out, FFN): algorithmic flops of its
-            # launches / HIP-event time of those launches on their stream, over the timed region
-            "roofline": {"bound": "mfma", "kernel": "svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline: persistent, one tile per workgroup, or row-complete with fused LayerNorm)",
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates
+            "rccl_ranks": res["ranks"],
+            "collective": None if world == 1 else {"op": "all_gather_into_tensor", "payload": args.gather,
+                                                   "bytes_per_rank_per_step": gatherers[0].bytes_per_rank(),
+                                                   "backend": torch.distributed.get_backend()},
+            "per_rank_clips_per_s": [round(B * args.steps / t, 3) for t in res["elapsed_per_rank"]],
+            "roofline": {"bound": "mfma",
+                         "kernel": ("svt::gemm_kernel<float, 128, 128, SPLIT> (register-staged, fp32 operands cut into 16-bit (hi, lo) pieces on "
+                                    "their way into LDS, three MFMAs per 16x16x32 block)") if split else
+                                   ("svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline: "
+                                    "persistent, one tile per workgroup, or row-complete with fused LayerNorm)"),
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_unit": "GB of HBM traffic per launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
+                         "traffic_unit": f"GB of HBM traffic per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
                          "algorithmic_gb_per_launch": round(k_dom[3] / max(1, n_l) / 1e9, 4),
                          "launches": int(n_l), "avg_launch_ms": round(ms / max(1, n_l), 5),
                          "ms_per_step": round(ms / args.steps, 4),
@@ -282,10 +363,16 @@ def main():
                          "other_kernels_ms_per_step": {"small/fp32 gemm": round(k_other[1] / args.steps, 4),
                                                        "flash_attn": round(k_attn[1] / args.steps, 4)}},
         }
+        if sustained is not None:
+            res_json["sustained_clips_per_s"] = sustained["clips_per_s"]
+            res_json["sustained"] = sustained
+        if notes_out is not None:
+            res_json["notes_out_clips_per_s"] = notes_out["clips_per_s"]
+            res_json["notes_out"] = notes_out
         if world == 1 and not args.no_cpu_baseline:
             sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, hd, args.seconds)
-        print(json.dumps(res), flush=True)
+            res_json["cpu_baseline"] = cpu_baseline(cfg, sd, hd)
+        print(json.dumps(res_json), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -247,9 +247,15 @@ int svt_debug_set(int key, int value);
 /* on = 0: off; 1: a HIP-event pair around every dense-contraction / attention launch; n > 1: around every n-th one */
 int svt_prof_enable(int on);
 int svt_prof_reset(void);
-/* kind: 0 = svt::gemm_uring_kernel (the dominant kernel: every large bf16 dense contraction), 1 = the other dense
- * contraction kernels (fp32 / small-shape GEMM), 2 = fused attention */
+/* kind: 0 = the dominant kernel family (svt::gemm_pers_kernel / gemm_pp8_kernel / outproj_ln_kernel: every large bf16
+ * dense contraction; in the split-operand modes the split form of svt::gemm_kernel), 1 = the other dense contraction
+ * kernels (exact-fp32 / small-shape GEMM), 2 = fused attention */
 int svt_prof_read(int kind, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
+/* Clock stamps for a sustained-rate measurement (bench.py): enqueues a tiny kernel on `stream` that stores, per XCD x
+ * (0..7), out_dev[2x] = s_memtime (shader-clock ticks) and out_dev[2x + 1] = s_memrealtime (100 MHz ticks) as int64.
+ * Two calls around a region give the clock the chip HELD over it: d(memtime) / d(memrealtime) * 100 MHz, per XCD.
+ * out_dev: 16 x int64, zeroed by the caller (an XCD that ran no block of the kernel leaves its pair untouched). */
+int svt_debug_clock(int64_t* out_dev, int device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -350,6 +350,12 @@ int svt_debug_set(int key, int value) {
   return SVT_OK;
 }
 
+int svt_debug_clock(int64_t* out_dev, int device, void* stream) {
+  if (!out_dev) { set_error("svt_debug_clock: null argument"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(device));
+  return launch_clock_stamp((long long*)out_dev, (hipStream_t)stream) ? SVT_ERR_HIP : SVT_OK;
+}
+
 int svt_prof_enable(int on) { g_prof.on = on != 0; g_prof.every = on > 1 ? on : 1; g_prof.tick = 0; return SVT_OK; }
 int svt_prof_reset(void) {
   g_prof.used = 0;

@@ -266,6 +266,7 @@ int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct
 int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,
                       int32_t* out_lens, hipStream_t s);
 
+int launch_clock_stamp(long long* out16, hipStream_t s);
 // Fbank pieces
 int launch_fbank_frames(const float* wav, int B, int64_t L, int n_fft, int hop, int64_t nframes, const float* window,
                         float* frames /*B*nframes x n_fft*/, hipStream_t s);

@@ -1424,4 +1424,22 @@ int launch_fbank_db(float* fb, int B, int64_t per_seq, float top_db, hipStream_t
   return 0;
 }
 
+// ---- clock stamps (svt_debug_clock): one (shader clock, 100 MHz wall clock) pair per XCD ----
+__global__ void clock_stamp_kernel(long long* out) {
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const long long t = __builtin_amdgcn_s_memtime();
+    const long long r = __builtin_amdgcn_s_memrealtime();
+    out[2 * xcc] = t;
+    out[2 * xcc + 1] = r;
+  }
+}
+int launch_clock_stamp(long long* out16, hipStream_t s) {
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, s, out16);  // 64 blocks: round-robin over the 8 XCDs
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace svt
