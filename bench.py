@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--gather", default="logits", choices=["logits", "frames"],
                     help="N > 1: all-gather the fp32 logits (80 B per frame, the north star's collective) or the compact decoded "
                          "frames (16 B per frame, SURVEY.md §8e)")
+    ap.add_argument("--separate-tail", action="store_true", help="A/B: output norm, head and decode as separate kernels over the "
+                    "materialised features instead of the fused tail (svt_encoder_forward_head)")
     ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
                     "(the PCIe-inclusive rate; never the reported metric, whose inputs are resident in HBM)")
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
@@ -187,10 +189,13 @@ def main():
         def fwd():
             if args.h2d:
                 wav_in[i].copy_(wav_host, non_blocking=True)
-            feats = encs[i](wav_in[i] if args.h2d else wav)
-            logits = head(feats)
-            _lib.check(lib.svt_decode_frames(_lib.ptr(logits), (hi - lo) * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
-                                             _lib.stream_ptr(dev)), "svt_decode_frames")
+            x = wav_in[i] if args.h2d else wav
+            if args.separate_tail:  # encoder -> features -> head -> decode as three calls (the features are materialised)
+                logits = head(encs[i](x))
+                _lib.check(lib.svt_decode_frames(_lib.ptr(logits), (hi - lo) * T, 20, 4, 12, _lib.ptr(frames_l[i]), local,
+                                                 _lib.stream_ptr(dev)), "svt_decode_frames")
+            else:  # AMT.compute_forward + the per-frame decode in one C-ABI call (svt_encoder_forward_head): same logits, same frames
+                logits = encs[i].forward_head(x, head, frames=frames_l[i])
             if i:
                 logits.record_stream(main_stream)  # allocated on a side stream, read by whoever consumes `out` on the main one
             return frames_l[i] if gather_frames else logits

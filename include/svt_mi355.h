@@ -131,6 +131,18 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav_dev, int32_t batch, 
                            float* feats_dev, void* workspace_dev, size_t workspace_bytes, void* stream,
                            int32_t clips_per_norm_group);
 
+/* encoder + whole-batch output norm + frame head (+ per-frame decode) in one call, WITHOUT writing the (B, T, D) features:
+ * what AMT.compute_forward computes (MIR_ST500/train_audio_ssl.py:28-48: feats = wav2vec2(wavs); logits = model(feats))
+ * followed, when frames_out_dev is given, by the sigmoid / argmax of compute_objectives (:93-100).  The head is linear, so
+ * the raw dots x.w are taken in the single pass over the un-normalised encoder output that also sums the two moments of
+ * the output norm; a second pass over B*T*n_out values applies (dot - mean * sum(w)) * rstd + bias and decodes.
+ * head: an svt_linear with in_features = hidden_size (512 / 768 / 1024) and out_features <= 32 on the same device.
+ * logits_out_dev: (B, T, n_out) fp32.  frames_out_dev: B*T svt_frame or NULL (then n_octave / n_class are ignored). */
+int svt_encoder_forward_head(svt_encoder* enc, const svt_linear* head, const float* wav_dev, int32_t batch,
+                             int64_t n_samples, float* logits_out_dev, svt_frame* frames_out_dev, int32_t n_octave,
+                             int32_t n_class, void* workspace_dev, size_t workspace_bytes, void* stream,
+                             int32_t clips_per_norm_group);
+
 /* ---- frame head + per-frame decode: replaces speechbrain.nnet.linear.Linear (linear.py:41-76)
  *      and the sigmoid/argmax loop (train_audio_ssl.py:41-46,93-100) ---- */
 int svt_linear_create(int32_t in_features, int32_t out_features, int has_bias, int device, svt_linear** out);

@@ -67,6 +67,7 @@ SYMBOLS = {
     "svt_encoder_workspace_bytes": (C.c_int64, [_P, C.c_int32, C.c_int64]),
     "svt_encoder_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_size_t, _P]),
     "svt_encoder_forward_ex": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_size_t, _P, C.c_int32]),
+    "svt_encoder_forward_head": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_int32]),
     "svt_linear_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int, C.c_int, C.POINTER(_P)]),
     "svt_linear_destroy": (None, [_P]),
     "svt_linear_load": (C.c_int, [_P, _P, _P]),

@@ -22,6 +22,7 @@ class AMTForward:
         self.onset_threshold = onset_threshold
         self.offset_threshold = offset_threshold
         self.frame_rate = frame_rate
+        self.fuse_tail = True   # False: encoder and head as two module calls (the features are materialised)
         self.song_pred: list = []
 
     def _get(self, name):
@@ -32,9 +33,15 @@ class AMTForward:
         """-> (onset_logits, offset_logits, pitch_octave_logits, pitch_class_logits, wav_lens)."""
         if videos is not None:
             feats = self._get("fusion")(wavs, videos)
+            logits = self._get("model")(feats)
         else:
-            feats = self._get("wav2vec2")(wavs)
-        logits = self._get("model")(feats)
+            enc, head = self._get("wav2vec2"), self._get("model")
+            if self.fuse_tail and hasattr(enc, "forward_head") and enc.can_fuse_head(head) and wavs.is_cuda \
+                    and enc.config.hidden_size == head.w.in_features:
+                # the features are not an output of compute_forward: out-norm + head in one pass behind the encoder
+                logits = enc.forward_head(wavs, head)
+            else:
+                logits = head(enc(wavs))
         self.last_logits = logits
         o = self.pitch_octave_num
         pitch_out = logits[:, :, 2:]

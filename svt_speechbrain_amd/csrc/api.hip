@@ -243,6 +243,13 @@ struct svt_encoder {
   std::vector<EncLayerW> layers;
 };
 
+struct svt_linear {
+  int in_f = 0, out_f = 0, has_bias = 0, device = 0;
+  bool loaded = false;
+  DevBuf w, b;
+  DevBuf wsum;  // sum_k w[j][k] per output (fp64 on the host): the fused out-norm + head tail needs it
+};
+
 static int validate_cfg(const svt_encoder_config& c) {
   if (c.struct_size != (int32_t)sizeof(svt_encoder_config)) { set_error("svt_encoder_config: struct_size mismatch (ABI)"); return SVT_ERR_INVALID; }
   if (c.num_conv_layers < 0 || c.num_conv_layers > SVT_MAX_CONV_LAYERS) { set_error("num_conv_layers out of range"); return SVT_ERR_INVALID; }
@@ -655,6 +662,7 @@ struct EncWs {
   AttnBufs ab;
   void* attn_o;
   void* ffn;
+  float* dots;      // fused tail: raw head dots, rows x 32
   size_t total;
 };
 
@@ -705,6 +713,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.ffn = cv.take(rows * F * es);
   w.gate = c.rel_pos_buckets ? (float*)cv.take((size_t)B * H * T * 4) : nullptr;
   w.relpb = c.rel_pos_buckets ? (float*)cv.take((size_t)H * (2 * T - 1) * 4) : nullptr;
+  w.dots = (float*)cv.take(rows * 32 * 4);
   w.total = cv.off;
   return w;
 }
@@ -719,6 +728,22 @@ int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t
   return (int64_t)carve_encoder(e, batch, n_samples, nullptr).total;
 }
 
+}  // extern "C"
+
+// Tail of a forward call: either the features (the wrapper's output) or, with a head, logits (+ decoded frames) straight
+// from the un-normalised encoder output (fused out-norm + head + decode, kernels.hip head_dots_kernel).
+struct TailSpec {
+  float* feats = nullptr;
+  const svt_linear* head = nullptr;
+  float* logits = nullptr;
+  svt_frame* frames = nullptr;
+  int n_oct = 0, n_cls = 0;
+};
+static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int64_t L, const TailSpec& tail, void* workspace,
+                                size_t workspace_bytes, void* stream, int32_t clips_per_norm_group);
+
+extern "C" {
+
 int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, float* feats, void* workspace,
                         size_t workspace_bytes, void* stream) {
   return svt_encoder_forward_ex(e, wav, B, L, feats, workspace, workspace_bytes, stream, 0);
@@ -726,7 +751,34 @@ int svt_encoder_forward(svt_encoder* e, const float* wav, int32_t B, int64_t L, 
 
 int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t L, float* feats, void* workspace,
                            size_t workspace_bytes, void* stream, int32_t clips_per_norm_group) {
-  if (!e || !wav || !feats || !workspace) { set_error("encoder_forward: null argument"); return SVT_ERR_INVALID; }
+  if (!feats) { set_error("encoder_forward: null argument"); return SVT_ERR_INVALID; }
+  TailSpec t;
+  t.feats = feats;
+  return encoder_forward_impl(e, wav, B, L, t, workspace, workspace_bytes, stream, clips_per_norm_group);
+}
+
+int svt_encoder_forward_head(svt_encoder* e, const svt_linear* head, const float* wav, int32_t B, int64_t L, float* logits,
+                             svt_frame* frames, int32_t n_octave, int32_t n_class, void* workspace, size_t workspace_bytes,
+                             void* stream, int32_t clips_per_norm_group) {
+  if (!head || !logits) { set_error("encoder_forward_head: null argument"); return SVT_ERR_INVALID; }
+  if (!head->loaded) { set_error("encoder_forward_head: head weights not loaded"); return SVT_ERR_STATE; }
+  if (!e || head->in_f != e->cfg.hidden_size || head->device != e->device) {
+    set_error("encoder_forward_head: the head must take hidden_size inputs and live on the encoder's device"); return SVT_ERR_INVALID; }
+  if (!linear_head_eligible(head->in_f, head->out_f)) {
+    set_error("encoder_forward_head: the fused tail is built for hidden sizes 512 / 768 / 1024 and at most 32 outputs"); return SVT_ERR_INVALID; }
+  if (frames && head->out_f != 2 + n_octave + 1 + n_class + 1) {
+    set_error("encoder_forward_head: n_out != 2 + (n_octave+1) + (n_class+1)"); return SVT_ERR_INVALID; }
+  TailSpec t;
+  t.head = head; t.logits = logits; t.frames = frames; t.n_oct = n_octave; t.n_cls = n_class;
+  return encoder_forward_impl(e, wav, B, L, t, workspace, workspace_bytes, stream, clips_per_norm_group);
+}
+
+}  // extern "C"
+
+static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int64_t L, const TailSpec& tail, void* workspace,
+                                size_t workspace_bytes, void* stream, int32_t clips_per_norm_group) {
+  float* feats = tail.feats;
+  if (!e || !wav || !workspace) { set_error("encoder_forward: null argument"); return SVT_ERR_INVALID; }
   if (!e->finalized) { set_error("encoder_forward: parameters not finalized"); return SVT_ERR_STATE; }
   if (B < 1) { set_error("encoder_forward: batch < 1"); return SVT_ERR_INVALID; }
   const int64_t T = svt_encoder_num_frames(e, L);
@@ -997,8 +1049,16 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
     if (int r = ln_add(e->enc_g.as<float>(), e->enc_b.as<float>(), pending, nullptr, fin)) return r;
     final_x = fin;
   }
-  // ---- wrapper's whole-batch output LayerNorm ----
+  // ---- wrapper's whole-batch output LayerNorm (+ frame head + decode when a head was given) ----
   const int64_t n_out = rows * D;
+  if (tail.head) {
+    static_assert(sizeof(svt_frame) == sizeof(FrameOut), "frame layout");
+    if (launch_head_fused(final_x, rows, D, tail.head->w.as<float>(), tail.head->wsum.as<float>(),
+                          tail.head->has_bias ? tail.head->b.as<float>() : nullptr, tail.head->out_f, w.dots,
+                          c.output_norm ? out_mom : nullptr, rows / groups, 1e-5f, tail.logits, (FrameOut*)tail.frames, tail.n_oct,
+                          tail.n_cls, s)) return SVT_ERR_HIP;
+    return SVT_OK;
+  }
   if (c.output_norm) {
     if (int r = launch_moments(final_x, n_out / groups, out_mom, s, groups)) return r;
     if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups)) return r;
@@ -1011,13 +1071,6 @@ int svt_encoder_forward_ex(svt_encoder* e, const float* wav, int32_t B, int64_t 
 // =================================================================================================
 // frame head + decode
 // =================================================================================================
-}  // extern "C"
-
-struct svt_linear {
-  int in_f = 0, out_f = 0, has_bias = 0, device = 0;
-  bool loaded = false;
-  DevBuf w, b;
-};
 
 extern "C" {
 
@@ -1041,6 +1094,13 @@ int svt_linear_load(svt_linear* l, const float* weight_host, const float* bias_h
   if (int r = upload_f32(l->w, weight_host, (size_t)l->in_f * l->out_f)) return r;
   if (l->has_bias)
     if (int r = upload_f32(l->b, bias_host, (size_t)l->out_f)) return r;
+  std::vector<float> ws((size_t)l->out_f);
+  for (int j = 0; j < l->out_f; ++j) {
+    double a = 0.0;
+    for (int k = 0; k < l->in_f; ++k) a += (double)weight_host[(size_t)j * l->in_f + k];
+    ws[j] = (float)a;
+  }
+  if (int r = upload_f32(l->wsum, ws.data(), ws.size())) return r;
   l->loaded = true;
   return SVT_OK;
 }

@@ -261,6 +261,11 @@ int launch_softmax_small(const float* x, int64_t rows, int n, int apply_log, flo
 bool linear_head_eligible(int K, int N);
 int launch_linear_head(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y, hipStream_t s);
 struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };
+// fused tail: whole-batch output norm (moments taken in the same pass) + frame head + optional per-frame decode, from the
+// UN-normalised encoder output x (rows x K); dots = rows x N scratch; mom = 2 doubles per norm group (zeroed) or null
+int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
+                      double* mom, int64_t rows_per_group, float eps, float* logits, FrameOut* frames, int n_oct, int n_cls,
+                      hipStream_t s);
 int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
                          hipStream_t s);
 int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,

@@ -688,6 +688,140 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused tail of the audio recipes ("fuse with a2's out-LN and a9"): the wrapper's whole-batch output norm
+// (huggingface_interface.py:294-295), the 20-way frame head (speechbrain/nnet/linear.py:63-76) and the per-frame
+// sigmoid / argmax (train_audio_ssl.py:93-100) WITHOUT materialising the normalised features.  The head is linear, so
+//     logits[r][j] = ((x[r] - mu) * rs) . w[j] + b[j] = (x[r] . w[j] - mu * sum_k w[j][k]) * rs + b[j]
+// and the raw dots x[r] . w[j] can be taken in the same single pass over the un-normalised encoder output that sums the
+// two moments of the norm (per group of rows: clips_per_norm_group).  Pass 1 = head_dots_kernel (the frame-head kernel
+// plus fp64 row-sum accumulation); pass 2 = head_finish_kernel over rows x N values: affine fix-up, logits, decode.
+// Replaces moments + global_norm + linear_head + decode_frames (three reads and one write of the 49 MB feature tensor
+// at 32 x 10 s) by one read.
+template <int KC>
+__global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict__ x, int64_t rows, const float* __restrict__ w, int N,
+                                                        float* __restrict__ dots, double* __restrict__ mom, int64_t rows_per_group) {
+  constexpr int K = KC * 256;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  for (int i = threadIdx.x * 4; i < N * K; i += 1024) *(float4*)(wl + i) = *(const float4*)(w + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+  const int myrow = (hi32 ? 2 : 0) + (hi16 ? 1 : 0);
+  // running (sum, sum of squares) of the group this wave is in; flushed with two fp64 atomics when the group changes
+  int64_t cur_g = -1;
+  double gs = 0.0, gss = 0.0;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
+    float4 xv[4][KC];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t row = r0 + rr < rows ? r0 + rr : rows - 1;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) xv[rr][c] = *(const float4*)(x + row * K + c * 256 + lane * 4);
+    }
+    if (mom) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float4 v = xv[rr][c];
+          a += (v.x + v.y) + (v.z + v.w);
+          q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        a = wave_sum(a);
+        q = wave_sum(q);
+        if (r0 + rr < rows) {  // wave-uniform
+          const int64_t g = (r0 + rr) / rows_per_group;
+          if (g != cur_g) {
+            if (cur_g >= 0 && lane == 0) { atomicAdd(&mom[2 * cur_g], gs); atomicAdd(&mom[2 * cur_g + 1], gss); }
+            cur_g = g; gs = 0.0; gss = 0.0;
+          }
+          gs += (double)a;
+          gss += (double)q;
+        }
+      }
+    }
+    float out0 = 0.f, out1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+      float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float4 wv = *(const float4*)(wl + n * K + c * 256 + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          sacc[rr] = fmaf(xv[rr][c].x, wv.x, sacc[rr]);
+          sacc[rr] = fmaf(xv[rr][c].y, wv.y, sacc[rr]);
+          sacc[rr] = fmaf(xv[rr][c].z, wv.z, sacc[rr]);
+          sacc[rr] = fmaf(xv[rr][c].w, wv.w, sacc[rr]);
+        }
+      }
+      float k0 = hi32 ? sacc[2] : sacc[0], k1 = hi32 ? sacc[3] : sacc[1];
+      const float g0 = hi32 ? sacc[0] : sacc[2], g1 = hi32 ? sacc[1] : sacc[3];
+      k0 += __shfl_xor(g0, 32, 64);
+      k1 += __shfl_xor(g1, 32, 64);
+      float v = hi16 ? k1 : k0;
+      v += __shfl_xor(hi16 ? k0 : k1, 16, 64);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((lane & 15) == (n & 15)) { if (n < 16) out0 = v; else out1 = v; }
+    }
+    const int64_t row = r0 + myrow;
+    if (row < rows) {
+      const int n0 = lane & 15;
+      if (n0 < N) dots[row * N + n0] = out0;
+      if (n0 + 16 < N) dots[row * N + n0 + 16] = out1;
+    }
+  }
+  if (mom && cur_g >= 0 && lane == 0) { atomicAdd(&mom[2 * cur_g], gs); atomicAdd(&mom[2 * cur_g + 1], gss); }
+}
+
+// one thread per row: logits = (dots - mean * wsum) * rstd + bias; optional per-frame decode (same rule as decode_frames_kernel)
+__global__ void head_finish_kernel(const float* __restrict__ dots, int64_t rows, int N, const float* __restrict__ wsum,
+                                   const float* __restrict__ bias, const double* __restrict__ mom, int64_t rows_per_group,
+                                   double group_elems, float eps, float* __restrict__ logits, FrameOut* __restrict__ frames,
+                                   int n_oct, int n_cls) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float mu = 0.f, rs = 1.f;
+  if (mom) {
+    const int64_t g = r / rows_per_group;
+    const double mean = mom[2 * g] / group_elems;
+    const double var = mom[2 * g + 1] / group_elems - mean * mean;
+    mu = (float)mean;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  float l[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j)
+    if (j < N) {
+      l[j] = fmaf(dots[r * N + j] - mu * wsum[j], rs, bias ? bias[j] : 0.f);
+      logits[r * N + j] = l[j];
+    }
+  if (frames) {
+    FrameOut f;
+    f.p_on = 1.f / (1.f + expf(-l[0]));
+    f.p_off = 1.f / (1.f + expf(-l[1]));
+    int bo = 0;
+    float bv = l[2];
+#pragma unroll
+    for (int j = 3; j < 32; ++j)
+      if (j <= 2 + n_oct && l[j] > bv) { bv = l[j]; bo = j - 2; }
+    int bc = 0;
+    const int c0 = 2 + n_oct + 1;
+    bv = -3.4e38f;
+#pragma unroll
+    for (int j = 3; j < 32; ++j)
+      if (j >= c0 && j <= c0 + n_cls) {
+        if (j == c0) { bv = l[j]; bc = 0; }
+        else if (l[j] > bv) { bv = l[j]; bc = j - c0; }
+      }
+    f.octave = bo;
+    f.pitch_class = bc;
+    frames[r] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Validation losses of the recipes (speechbrain/nnet/losses.py:402-519 nll_loss / bce_loss over
 // compute_masked_loss :624-684).  One workgroup per batch item: per-frame loss x length mask, block-reduced in a
 // fixed order (deterministic) into double sums {sum loss*mask, sum mask, sum mean_c(logp)*mask}; a second tiny
@@ -1310,6 +1444,35 @@ int launch_linear_head(const float* x, int64_t rows, int K, const float* w, cons
   if (K == 1024) return launch_linear_head_kc<4>(x, rows, w, b, N, y, s);
   set_error("linear_head: unsupported K");
   return -1;
+}
+
+template <int KC>
+static int launch_head_dots_kc(const float* x, int64_t rows, const float* w, int N, float* dots, double* mom, int64_t rpg, hipStream_t s) {
+  const size_t lds = (size_t)N * KC * 256 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVT_HIP(hipFuncSetAttribute((const void*)head_dots_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * KC * 256 * 4));
+    attr_set = true;
+  }
+  const int64_t groups = (rows + 15) / 16;
+  const unsigned grid = (unsigned)(groups < 512 ? groups : 512);
+  hipLaunchKernelGGL((head_dots_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, N, dots, mom, rpg);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
+                      double* mom /*2 per group, zeroed; null = no output norm*/, int64_t rows_per_group, float eps, float* logits,
+                      FrameOut* frames, int n_oct, int n_cls, hipStream_t s) {
+  if (!linear_head_eligible(K, N)) { set_error("head_fused: unsupported head geometry"); return -1; }
+  if (frames && (N != 2 + n_oct + 1 + n_cls + 1 || N > 32)) { set_error("head_fused: n_out != 2 + (n_octave+1) + (n_class+1)"); return -1; }
+  int r = K == 512 ? launch_head_dots_kc<2>(x, rows, w, N, dots, mom, rows_per_group, s)
+        : K == 768 ? launch_head_dots_kc<3>(x, rows, w, N, dots, mom, rows_per_group, s)
+                   : launch_head_dots_kc<4>(x, rows, w, N, dots, mom, rows_per_group, s);
+  if (r) return r;
+  hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, dots, rows, N, wsum, b, mom,
+                     rows_per_group, (double)rows_per_group * (double)K, eps, logits, frames, n_oct, n_cls);
+  SVT_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y,

@@ -409,6 +409,46 @@ class HuggingFaceWav2Vec2(nn.Module):
         with torch.no_grad():
             return self.extract_features(wav, clips_per_norm_group).detach()
 
+    def forward_head(self, wav: torch.Tensor, head, clips_per_norm_group: int = 0, frames: Optional[torch.Tensor] = None,
+                     pitch_octave_num: int = 4, pitch_class_num: int = 12) -> torch.Tensor:
+        """``head(self(wav))`` -- the two module calls of ``AMT.compute_forward`` (train_audio_ssl.py:36-39) -- as ONE C-ABI call
+        that never writes the (B, T, D) features: the whole-batch output norm, the frame head (``svt_speechbrain_amd.Linear``
+        with <= 32 outputs) and, when ``frames`` (a ``(B*T, 4)`` int32 device tensor) is given, the per-frame sigmoid / argmax
+        are fused behind the encoder (``svt_encoder_forward_head``).  Returns the ``(B, T, n_out)`` logits."""
+        if wav.dim() != 2:
+            raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")
+        if not wav.is_cuda:
+            raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
+        lib = _lib.load()
+        slot = self._sync_device(wav.device)
+        hslot = head._sync(wav.device)
+        x = wav.detach().to(torch.float32).contiguous()
+        B, L = x.shape
+        T = self.config.frames(L)
+        if B < 1 or T < 1:
+            raise ValueError(f"waveform of {L} samples is shorter than the encoder's receptive field")
+        need = lib.svt_encoder_workspace_bytes(slot.handle, B, L)
+        if need < 0:
+            raise _lib.SvtError(_lib.last_error())
+        ws = slot.workspace(need, x.device)
+        n_out = head.w.out_features
+        logits = torch.empty((B, T, n_out), dtype=torch.float32, device=x.device)
+        if frames is not None and (frames.dtype != torch.int32 or frames.numel() != B * T * 4 or not frames.is_contiguous()):
+            raise ValueError("frames must be a contiguous int32 tensor of B*T*4 elements (16 bytes per frame)")
+        with torch.no_grad():
+            _lib.check(lib.svt_encoder_forward_head(slot.handle, hslot.handle, _lib.ptr(x), B, L, _lib.ptr(logits),
+                                                    _lib.ptr(frames) if frames is not None else None, int(pitch_octave_num),
+                                                    int(pitch_class_num), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device),
+                                                    int(clips_per_norm_group)), "svt_encoder_forward_head")
+        return logits
+
+    @staticmethod
+    def can_fuse_head(head) -> bool:
+        """True when ``head`` is this package's ``Linear`` with a geometry the fused tail serves."""
+        from .linear import Linear
+        return (isinstance(head, Linear) and not head.combine_dims and head.w.in_features in (512, 768, 1024)
+                and 1 <= head.w.out_features <= 32)
+
     def extract_features(self, wav: torch.Tensor, clips_per_norm_group: int = 0) -> torch.Tensor:
         if wav.dim() != 2:
             raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")

@@ -488,6 +488,9 @@ def main():
         "large_c1": lambda: make_encoder_case(hi, utils, "large_c1", "wav2vec2-large-lv60", 1, 80000, 23, full=False),
         "hubert_large_c1": lambda: make_encoder_case(hi, utils, "hubert_large_c1", "hubert-large-ll60k", 1, 48000, 24,
                                                       full=False),
+        # full-size 10 s goldens of the two LARGE BASELINE models (C3 / C5 geometry: 24 pre-LN layers, layer-norm conv stack)
+        "large_b2": lambda: make_encoder_case(hi, utils, "large_b2", "wav2vec2-large-lv60", 2, 160000, 27, full=False),
+        "hubert_large_b2": lambda: make_encoder_case(hi, utils, "hubert_large_b2", "hubert-large-ll60k", 2, 160000, 28, full=False),
         "tiny_hubert_bn": lambda: make_encoder_case(hi, utils, "tiny_hubert_bn", "tiny-hubert-bn", 2, 4000, 18),
         "tiny_wavlm": lambda: make_encoder_case(hi, utils, "tiny_wavlm", "tiny-wavlm", 2, 4000, 16),
         "tiny_wavlm_stable": lambda: make_encoder_case(hi, utils, "tiny_wavlm_stable", "tiny-wavlm-stable", 2, 4000, 17),

@@ -55,7 +55,7 @@ def test_oracle_tiny(golden, name):
         assert notes == d["notes"]
 
 
-@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1"])
+@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"])
 def test_oracle_full_size(golden, name):
     fx = golden(name)
     torch.set_num_threads(8)
@@ -64,10 +64,10 @@ def test_oracle_full_size(golden, name):
     assert (feats[:, ::25, ::16] - fx["feats_strided"]).abs().max() < 1e-4
     assert (logits - fx["logits"]).abs().max() < 2e-4
     p_on, p_off, octv, pc = O.decode_frames(logits)
-    d = fx["decode"][0]
     # argmax may legitimately differ only where the top-2 logits are within fp32 noise
-    mism = (octv[0] != d["oct"]) | (pc[0] != d["pc"])
-    assert int(mism.sum()) == 0
+    for b, d in enumerate(fx["decode"]):
+        mism = (octv[b] != d["oct"]) | (pc[b] != d["pc"])
+        assert int(mism.sum()) == 0
 
 
 def test_oracle_frame2note_golden(golden):
