@@ -250,7 +250,8 @@ int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const 
  * key 0 = kernel ablation variant, 1 = force the tile height (64/128/192/256), 2 = force the one-tile (2) / persistent (4)
  * scheduler, 3 = ablation variant while tracing, 5 = fused out-projection + LayerNorm on/off, 6 = small-problem kernel
  * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles, 8 = 8-wave fused-attention workgroups on/off,
- * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode.  Returns 0. */
+ * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode, 10 = whole-head fused
+ * attention kernel (K / V of a head resident in LDS; measured slower, off by default).  Returns 0. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

@@ -353,6 +353,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 7) g_gemm_skinny_max_tiles = value;
   else if (key == 8) g_flash_wide = value;
   else if (key == 9) g_conv_ln_bf16 = value;
+  else if (key == 10) g_flash_head = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }

@@ -158,6 +158,7 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
 // small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
 bool gemm_skinny_eligible(const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
+extern int g_flash_head;  // whole-head fused attention kernel (K / V resident in LDS): off (0, default: measured slower) / on (1), svt_debug_set key 10
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
