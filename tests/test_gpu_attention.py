@@ -61,7 +61,7 @@ def test_whole_head_kernel_variant(B, T, H):
     lib = _lib.load()
     lib.svt_debug_set(10, 1)
     try:
-        got, ref = run_attention(B * 64 if B * H < 128 else B, T, H, 64, seed=7)   # the dispatcher wants >= 128 heads
+        got, ref = run_attention(max(B, -(-128 // H)), T, H, 64, seed=7)   # the dispatcher wants >= 128 heads
     finally:
         lib.svt_debug_set(10, 0)
     assert torch.isfinite(got).all()
