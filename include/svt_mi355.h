@@ -184,15 +184,13 @@ int svt_fbank(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t sa
 
 /* ---- test / micro-benchmark hook: the dense contraction kernel on caller-supplied operands ----
  * C (M,N) = act(A W^T + bias) + resid with A (M,K) and W (N,K) in the operand type of `precision`
- * (fp32 or bf16 bits), C in the operand type unless out_f32.  a_rpb/a_bstride/a_rstride describe the
+ * (fp32, or bf16 bits for SVT_PREC_BF16; the split-operand precisions take fp32 operands), C in the operand type unless out_f32.  a_rpb/a_bstride/a_rstride describe the
  * implicit-conv row addressing (row m starts at (m / a_rpb) * a_bstride + (m % a_rpb) * a_rstride elements);
  * pass a_rpb = M, a_bstride = 0, a_rstride = K for a plain row-major A; ldw = W row pitch (>= K). */
 int svt_debug_gemm(int32_t precision, const void* a_dev, const void* w_dev, void* c_dev, const float* bias_dev,
                    const float* resid_dev, int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride,
                    int64_t a_rstride, int64_t ldw, int32_t act, int32_t out_f32, int device, void* stream);
 
-/* diagnostic knobs for tools/gemm_bench.py: key 0 = kernel variant (0 normal, 1 no DMA after prologue, 2 no MFMA),
- * key 1 = force the M tile (0 auto, 128/192/256).  Never set in the product path. */
 /* ---- AV-HuBERT lip front-end: replaces SubModel / ResEncoder of N20EMv2/video_only/resnet.py:134-187 (the
  * `feature_extractor_video` of the AV-HuBERT model, hubert.py:344-346): 3-D stem + ResNet-18 trunk (PReLU) + Linear(512,
  * embed_dim), eval mode.  Parameter keys are SubModel.state_dict() keys ("resnet.frontend3D.0.weight", "resnet.trunk.layer1.0.

@@ -169,7 +169,7 @@ extern int g_gemm_variant;  // diagnostics: replaces dbg inside the kernel while
 
 // ---- profiling of the dominant kernel (bench.py roofline leg) ----
 void prof_begin(hipStream_t s);
-// kind: 0 = gemm_uring_kernel (the dominant kernel), 1 = other dense contraction kernels, 2 = flash attention
+// kind: 0 = the dominant family (gemm_pers / gemm_pp8 / outproj_ln kernels; the split form of gemm_kernel), 1 = other dense contraction kernels, 2 = flash attention
 void prof_end(hipStream_t s, double flops, double bytes, int kind = 1);
 
 // ---- elementwise / reduction kernels (kernels.hip) ----
