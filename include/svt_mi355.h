@@ -249,7 +249,9 @@ int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const 
  * scheduler, 3 = ablation variant while tracing, 5 = fused out-projection + LayerNorm on/off, 6 = small-problem kernel
  * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles, 8 = 8-wave fused-attention workgroups on/off,
  * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode, 10 = whole-head fused
- * attention kernel (K / V of a head resident in LDS; measured slower, off by default).  Returns 0. */
+ * attention kernel (K / V of a head resident in LDS; measured slower, off by default), 11 = LDS-DMA split-operand GEMM
+ * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls.
+ * Returns 0. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

@@ -61,13 +61,14 @@ void prof_end(hipStream_t s, double flops, double bytes, int kind) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { release(); }
+  void release() { if (p) { split_weights_forget(p); (void)hipFree(p); p = nullptr; } }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
   int alloc(size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    release();
     bytes = n;
     SVT_HIP(hipMalloc(&p, n ? n : 16));
     return 0;
@@ -130,6 +131,17 @@ static int upload_operand(int prec, DevBuf& b, const float* h, size_t n) {
   return 0;
 }
 
+// weight matrix (rows x K, K contiguous): storage copy as upload_operand + in the split-operand modes the packed (hi, lo)
+// pieces the LDS-DMA split kernel reads (gemm_dma.hip); `precision` is the svt_precision of the object
+static int upload_weight(int precision, DevBuf& b, const float* h, size_t rows, size_t K) {
+  if (int r = upload_operand(precision >= 2 ? 0 : precision, b, h, rows * K)) return r;
+  if (precision >= 2) {
+    if (int r = split_weights_register(b.p, (long)rows, (int)K, precision, 0)) return r;
+    SVT_HIP(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int round_up_int(int x, int a) { return (x + a - 1) / a * a; }
 
@@ -149,6 +161,10 @@ struct AttnBufs {
   float* S;   // (B,H,T,Tp) fp32
   void* P;    // operand type
   void* Vt;   // (B,H,dh,Tp)
+  // split-operand modes: 16-bit (hi, lo) planes of the packed (rows, 3D) q/k/v projection, and of a separate (rows, D)
+  // query projection (RCA cross attention); null in the other modes
+  void* pl_qkv = nullptr;
+  void* pl_q = nullptr;
 };
 static size_t esize(int prec) { return prec ? 2 : 4; }
 // svt_precision -> storage type of activations / weights in HBM (0 = fp32, 1 = bf16).  The split-operand modes
@@ -173,6 +189,27 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
                                  long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr,
                                  int gp = -1) {
   if (gp < 0) gp = prec;
+  if (gp >= 2 && !gate && flash_attention_x3_ok(dh) && ab.pl_qkv && ldkv == 3L * H * dh &&
+      (const float*)V == (const float*)K + (long)H * dh) {
+    // split-operand fused attention: cut the fp32 projections into 16-bit planes once, then three MFMAs per product
+    // (attention.hip flash_attn_x3_kernel) -- no (B, H, T, T) score tensor
+    const long D = (long)H * dh, rows = (long)B * T;
+    const float* kv0 = (const float*)K - D;                     // start of the packed (rows, 3D) projection
+    const long pl3 = rows * 3 * D;
+    unsigned short* p3 = (unsigned short*)ab.pl_qkv;
+    if (!vt_ready)
+      if (int r = launch_split_planes(gp, kv0, 3 * D, rows, (int)(3 * D), p3, 3 * D, pl3, s)) return r;
+    const unsigned short* qp;
+    long qld, qpl;
+    if ((const float*)Q == kv0 && ldq == 3 * D) { qp = p3; qld = 3 * D; qpl = pl3; }
+    else {
+      if (!ab.pl_q) { set_error("attention: no workspace for the query planes"); return -1; }
+      if (int r = launch_split_planes(gp, (const float*)Q, ldq, rows, (int)D, ab.pl_q, D, rows * D, s)) return r;
+      qp = (const unsigned short*)ab.pl_q; qld = D; qpl = rows * D;
+    }
+    return launch_flash_attention_x3(gp, qp, qld, (long)T * qld, qpl, p3 + D, p3 + 2 * D, 3 * D, (long)T * 3 * D, pl3, (float*)out, ldo,
+                                     (long)T * ldo, B, T, H, dh, scale, s);
+  }
   if (use_flash(prec, dh, gate != nullptr, T)) {
     (void)vt_ready;
     return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
@@ -211,6 +248,7 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
 
 using namespace svt;
 
+static int g_debug_keep_split = 0;  // svt_debug_set(12, 1): svt_debug_gemm keeps the split copy of its weight operand between calls
 static int g_conv_ln_bf16 = 1;     // svt_debug_set(9, 0): fp32 conv output + LayerNorm (A/B)
 static int g_fuse_outproj_ln = 1;  // svt_debug_set(5, 0) falls back to GEMM + LayerNorm kernels (A/B measurements)
 
@@ -317,17 +355,46 @@ int svt_debug_gemm(int32_t precision, const void* a, const void* w, void* c, con
   g.A = a; g.W = w; g.C = c; g.bias = bias; g.resid = resid;
   g.M = m; g.N = n; g.K = k; g.a_rpb = a_rpb; g.a_bstride = a_bstride; g.a_rstride = a_rstride;
   g.ldw = ldw; g.ldc = n; g.act = act; g.out_f32 = out_f32;
-  return launch_gemm(precision, g, (hipStream_t)stream) ? SVT_ERR_INVALID : SVT_OK;
+  // split-operand modes: the product path cuts weight matrices into (hi, lo) pieces once, at finalize; the hook does it per
+  // call (or once per weight pointer with svt_debug_set(12, 1): micro-benchmarks)
+  static const void* s_kept = nullptr;
+  const bool split = precision >= 2 && ldw == k && k % 32 == 0;
+  if (split && !(g_debug_keep_split && s_kept == w)) {
+    if (split_weights_register(w, n, k, precision, (hipStream_t)stream)) return SVT_ERR_HIP;
+    s_kept = w;
+  }
+  const int rc = launch_gemm(precision, g, (hipStream_t)stream);
+  if (split && !g_debug_keep_split) {
+    SVT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    split_weights_forget(w);
+    s_kept = nullptr;
+  }
+  return rc ? SVT_ERR_INVALID : SVT_OK;
 }
 
 int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
                         int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
                         void* stream) {
   if (!q || !k || !v || !o) { set_error("svt_debug_attention: null argument"); return SVT_ERR_INVALID; }
-  if (precision != 1 || !(head_dim == 64 || head_dim == 128)) {
-    set_error("svt_debug_attention: only the fused bf16 kernel (head_dim 64 / 128) is exposed"); return SVT_ERR_INVALID; }
+  if (!(precision >= 1 && precision <= 3) || !(head_dim == 64 || head_dim == 128)) {
+    set_error("svt_debug_attention: only the fused kernels (bf16, or the split-operand modes on fp32 inputs; head_dim 64 / 128) are exposed"); return SVT_ERR_INVALID; }
   if (int r = check_device(device)) return r;
   SVT_HIP(hipSetDevice(device));
+  if (precision >= 2) {
+    // q / k / v: fp32 slices of ONE packed (batch * t, 3 * heads * head_dim) projection; o: fp32
+    const long D = (long)heads * head_dim, rows = (long)batch * t;
+    if ((const float*)k != (const float*)q + D || (const float*)v != (const float*)q + 2 * D || ldq != 3 * D || ldkv != 3 * D) {
+      set_error("svt_debug_attention: the split-operand kernel is exposed for a packed q|k|v projection"); return SVT_ERR_INVALID; }
+    void* planes = nullptr;
+    SVT_HIP(hipMalloc(&planes, (size_t)rows * 3 * D * 4));
+    AttnBufs ab{};
+    ab.pl_qkv = planes;
+    const int rc = attention_scores_path(0, q, ldq, k, v, ldkv, batch, t, heads, head_dim, scale, ab, false, o, ldo, (hipStream_t)stream,
+                                         nullptr, nullptr, precision);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(planes);
+    return rc ? SVT_ERR_INVALID : SVT_OK;
+  }
   if (launch_flash_attention(q, ldq, (long)t * ldq, k, v, ldkv, (long)t * ldkv, o, ldo, (long)t * ldo, batch, t, heads,
                              head_dim, scale, (hipStream_t)stream)) return SVT_ERR_INVALID;
   return SVT_OK;
@@ -354,6 +421,8 @@ int svt_debug_set(int key, int value) {
   else if (key == 8) g_flash_wide = value;
   else if (key == 9) g_conv_ln_bf16 = value;
   else if (key == 10) g_flash_head = value;
+  else if (key == 11) g_gemm_x3 = value;
+  else if (key == 12) g_debug_keep_split = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -446,7 +515,7 @@ int svt_encoder_finalize(svt_encoder* e) {
       for (int o = 0; o < co; ++o)
         for (int ci = 0; ci < cin; ++ci)
           for (int j = 0; j < k; ++j) wt[((size_t)o * k + j) * cin + ci] = p->v[((size_t)o * cin + ci) * k + j];
-      if (int r = upload_operand(prec, L.w, wt.data(), wt.size())) return r;
+      if (int r = upload_weight(c.precision, L.w, wt.data(), (size_t)co, (size_t)k * cin)) return r;
     }
     if (c.conv_bias) {
       if (int r = need(P, pre + "conv.bias", {co}, &p)) return r;
@@ -469,7 +538,7 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = upload_f32(e->fp_b, p->v.data(), p->v.size())) return r;
   }
   if (int r = need(P, "feature_projection.projection.weight", {D, cin}, &p)) return r;
-  if (int r = upload_operand(prec, e->proj_w, p->v.data(), p->v.size())) return r;
+  if (int r = upload_weight(c.precision, e->proj_w, p->v.data(), (size_t)D, (size_t)cin)) return r;
   if (int r = need(P, "feature_projection.projection.bias", {D}, &p)) return r;
   if (int r = upload_f32(e->proj_b, p->v.data(), p->v.size())) return r;
 
@@ -581,10 +650,10 @@ int svt_encoder_finalize(svt_encoder* e) {
       if (int r = need(P, pre + "attention." + names[i] + ".bias", {D}, &p)) return r;
       memcpy(bqkv.data() + (size_t)i * D, p->v.data(), (size_t)D * 4);
     }
-    if (int r = upload_operand(prec, L.wqkv, wqkv.data(), wqkv.size())) return r;
+    if (int r = upload_weight(c.precision, L.wqkv, wqkv.data(), (size_t)3 * D, (size_t)D)) return r;
     if (int r = upload_f32(L.bqkv, bqkv.data(), bqkv.size())) return r;
     if (int r = need(P, pre + "attention.out_proj.weight", {D, D}, &p)) return r;
-    if (int r = upload_operand(prec, L.wo, p->v.data(), p->v.size())) return r;
+    if (int r = upload_weight(c.precision, L.wo, p->v.data(), (size_t)D, (size_t)D)) return r;
     if (int r = need(P, pre + "attention.out_proj.bias", {D}, &p)) return r;
     if (int r = upload_f32(L.bo, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "layer_norm.weight", {D}, &p)) return r;
@@ -592,11 +661,11 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = need(P, pre + "layer_norm.bias", {D}, &p)) return r;
     if (int r = upload_f32(L.ln1b, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "feed_forward.intermediate_dense.weight", {F, D}, &p)) return r;
-    if (int r = upload_operand(prec, L.w1, p->v.data(), p->v.size())) return r;
+    if (int r = upload_weight(c.precision, L.w1, p->v.data(), (size_t)F, (size_t)D)) return r;
     if (int r = need(P, pre + "feed_forward.intermediate_dense.bias", {F}, &p)) return r;
     if (int r = upload_f32(L.b1, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "feed_forward.output_dense.weight", {D, F}, &p)) return r;
-    if (int r = upload_operand(prec, L.w2, p->v.data(), p->v.size())) return r;
+    if (int r = upload_weight(c.precision, L.w2, p->v.data(), (size_t)D, (size_t)F)) return r;
     if (int r = need(P, pre + "feed_forward.output_dense.bias", {D}, &p)) return r;
     if (int r = upload_f32(L.b2, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "final_layer_norm.weight", {D}, &p)) return r;
@@ -707,9 +776,11 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
     w.posy = Pf ? cv.take((size_t)B * Tq * Pf * D * 2) : nullptr;
   }
   w.qkv = cv.take(rows * 3 * D * es);
-  w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * H * T * Tp * 4);
-  w.ab.P = flash ? nullptr : cv.take((size_t)B * H * T * Tp * es);
+  const bool flash3 = c.precision >= 2 && flash_attention_x3_ok(dh) && !c.rel_pos_buckets;
+  w.ab.S = (flash || flash3) ? nullptr : (float*)cv.take((size_t)B * H * T * Tp * 4);
+  w.ab.P = (flash || flash3) ? nullptr : cv.take((size_t)B * H * T * Tp * es);
   w.ab.Vt = cv.take((size_t)B * H * dh * Tp * es);
+  w.ab.pl_qkv = (c.precision >= 2 && flash_attention_x3_ok(dh) && !c.rel_pos_buckets) ? cv.take(rows * 3 * D * 4) : nullptr;
   w.attn_o = cv.take(rows * D * es);
   w.ffn = cv.take(rows * F * es);
   w.gate = c.rel_pos_buckets ? (float*)cv.take((size_t)B * H * T * 4) : nullptr;
@@ -1179,6 +1250,10 @@ RcaWs carve_rca(const svt_rca* r, int B, int T, void* base) {
   w.ab.S = flash ? nullptr : (float*)cv.take((size_t)B * r->H * T * Tp * 4);
   w.ab.P = flash ? nullptr : cv.take((size_t)B * r->H * T * Tp * es);
   w.ab.Vt = cv.take((size_t)B * r->H * dh * Tp * es);
+  if (r->gp >= 2 && flash_attention_x3_ok(dh)) {
+    w.ab.pl_qkv = cv.take(rows * 3 * D * 4);
+    w.ab.pl_q = cv.take(rows * D * 4);
+  }
   w.att_s = cv.take(rows * D * es);
   w.att_c = cv.take(rows * D * es);
   w.blend = cv.take(rows * D * es);
@@ -1230,19 +1305,19 @@ int svt_rca_finalize(svt_rca* r) {
     const std::string pre = std::string("fusion.layer") + (l ? "2" : "1") + ".";
     RcaLayerW& L = r->L[l];
     if (int rc = need(P, pre + "self_att.att.in_proj_weight", {3 * D, D}, &p)) return rc;
-    if (int rc = upload_operand(r->prec, L.win, p->v.data(), p->v.size())) return rc;
+    if (int rc = upload_weight(r->gp, L.win, p->v.data(), (size_t)3 * D, (size_t)D)) return rc;
     if (int rc = need(P, pre + "self_att.att.in_proj_bias", {3 * D}, &p)) return rc;
     if (int rc = upload_f32(L.bin, p->v.data(), p->v.size())) return rc;
     if (int rc = need(P, pre + "self_att.att.out_proj.weight", {D, D}, &p)) return rc;
-    if (int rc = upload_operand(r->prec, L.wo, p->v.data(), p->v.size())) return rc;
+    if (int rc = upload_weight(r->gp, L.wo, p->v.data(), (size_t)D, (size_t)D)) return rc;
     if (int rc = need(P, pre + "self_att.att.out_proj.bias", {D}, &p)) return rc;
     if (int rc = upload_f32(L.bo, p->v.data(), p->v.size())) return rc;
     if (int rc = need(P, pre + "pos_ffn.ffn.0.weight", {F, D}, &p)) return rc;
-    if (int rc = upload_operand(r->prec, L.w1, p->v.data(), p->v.size())) return rc;
+    if (int rc = upload_weight(r->gp, L.w1, p->v.data(), (size_t)F, (size_t)D)) return rc;
     if (int rc = need(P, pre + "pos_ffn.ffn.0.bias", {F}, &p)) return rc;
     if (int rc = upload_f32(L.b1, p->v.data(), p->v.size())) return rc;
     if (int rc = need(P, pre + "pos_ffn.ffn.3.weight", {D, F}, &p)) return rc;
-    if (int rc = upload_operand(r->prec, L.w2, p->v.data(), p->v.size())) return rc;
+    if (int rc = upload_weight(r->gp, L.w2, p->v.data(), (size_t)D, (size_t)F)) return rc;
     if (int rc = need(P, pre + "pos_ffn.ffn.3.bias", {D}, &p)) return rc;
     if (int rc = upload_f32(L.b2, p->v.data(), p->v.size())) return rc;
     if (int rc = need(P, pre + "norm1.norm.weight", {D}, &p)) return rc;
@@ -1523,7 +1598,7 @@ int svt_video_finalize(svt_video* v) {
     cin = C;
   }
   if (int r = need(P, "proj.weight", {v->E, 512}, &p)) return r;
-  if (int r = upload_operand(v->prec, v->proj_w, p->v.data(), p->v.size())) return r;
+  if (int r = upload_weight(v->gp, v->proj_w, p->v.data(), (size_t)v->E, (size_t)512)) return r;
   if (int r = upload_vec(P, "proj.bias", v->E, &v->proj_b)) return r;
   v->finalized = true;
   return SVT_OK;

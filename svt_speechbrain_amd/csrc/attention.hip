@@ -259,6 +259,251 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
 #undef SVT_STAGE_DMA
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Split-operand fused attention (precision "bf16x3" / "fp16x3").  Q, K, V arrive as 16-bit (hi, lo) PLANES of the fp32
+// projections (split_planes_kernel below; plane = same (rows, ld) layout, lo plane `plane` elements after the hi plane);
+// every product is three MFMAs accumulated in fp32:
+//     S^T = Kh Qh^T + Kl Qh^T + Kh Ql^T,     O^T += Vh^T Ph^T + Vl^T Ph^T + Vh^T Pl^T   with P = (Ph, Pl) cut in registers
+// Everything else is flash_attn_kernel: keys on the MFMA rows, softmax state in fp32 registers, K / V tiles by LDS-DMA
+// into two stages (four tiles per stage: K hi, K lo, V hi, V lo), V read transposed out of its row-major tiles, deferred
+// rescale.  Output fp32.  Replaces, in the split modes, QK^T GEMM + softmax_rows + transpose_v + PV GEMM over a
+// materialised (B, H, T, T) score tensor: 8.2 of the 23.2 ms of a 32 x 10 s wav2vec2-base step went there.
+template <bool F16> struct X3T;
+template <> struct X3T<false> {
+  typedef bf16x8 v8;
+  static __device__ __forceinline__ f32x16 mma(const uint4& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mma(const s16x8& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void cut(float x, unsigned short& hi, unsigned short& lo) {
+    const bf16_t a = (bf16_t)x, b = (bf16_t)(x - (float)a);
+    hi = __builtin_bit_cast(unsigned short, a);
+    lo = __builtin_bit_cast(unsigned short, b);
+  }
+};
+template <> struct X3T<true> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mma(const uint4& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mma(const s16x8& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void cut(float x, unsigned short& hi, unsigned short& lo) {
+    const _Float16 a = (_Float16)x, b = (_Float16)(x - (float)a);
+    hi = __builtin_bit_cast(unsigned short, a);
+    lo = __builtin_bit_cast(unsigned short, b);
+  }
+};
+
+template <int DH, bool F16, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void flash_attn_x3_kernel(const unsigned short* __restrict__ Q, long ldq, long q_bstride, long q_plane,
+                                                            const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
+                                                            long ldk, long k_bstride, long k_plane, float* __restrict__ O, long ldo,
+                                                            long o_bstride, int T, int H, float c) {
+  typedef X3T<F16> X;
+  typedef typename X::v8 v8;
+  constexpr int KSD = DH / 16, DB = DH / 32, CPR = DH / 8, RB = 2 * DH;
+  constexpr int TILE16 = 64 * CPR;  // uint4 per tile
+  // two stages of { K hi, K lo, V hi, V lo }
+  __shared__ __attribute__((aligned(16))) uint4 KV[2][4 * TILE16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const unsigned short* Qb = Q + (long)b * q_bstride + (long)h * DH;
+  const unsigned short* Kb = K + (long)b * k_bstride + (long)h * DH;
+  const unsigned short* Vb = V + (long)b * k_bstride + (long)h * DH;
+  v8 qh[KSD], ql[KSD];
+  {
+    int q = q0 + (lane & 31);
+    if (q > T - 1) q = T - 1;
+    const unsigned short* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      qh[ks] = *(const v8*)(qp + ks * 16);
+      ql[ks] = *(const v8*)(qp + q_plane + ks * 16);
+    }
+  }
+  constexpr int ROWS_PER_DMA = 64 / CPR;
+  constexpr int DMA_PER_WAVE = 64 / ROWS_PER_DMA / NW;
+  static_assert(DMA_PER_WAVE >= 1, "too many waves for the tile's fill");
+  int dkey[DMA_PER_WAVE], kch[DMA_PER_WAVE], vch[DMA_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < DMA_PER_WAVE; ++i) {
+    const int kk = (wave * DMA_PER_WAVE + i) * ROWS_PER_DMA + lane / CPR;
+    const int slot = lane % CPR;
+    const int g = (DH == 64) ? ((kk >> 1) & 7) : (kk & 15);
+    const int sw = (DH == 64) ? (((kk >> 1) & 1) << 2) : ((kk & 3) << 2);
+    dkey[i] = kk;
+    kch[i] = (slot ^ g) * 8;
+    vch[i] = (slot ^ sw) * 8;
+  }
+  typedef const void __attribute__((address_space(1)))* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+#define SVT_STAGE_X3(TILE, STAGE)                                                                                  \
+  {                                                                                                                  \
+    const int key0_ = (TILE) * 64;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < DMA_PER_WAVE; ++i) {                                                       \
+      int key_ = key0_ + dkey[i];                                                                                    \
+      if (key_ > T - 1) key_ = T - 1;                                                                                \
+      const unsigned short* kp_ = Kb + (long)key_ * ldk;                                                             \
+      const unsigned short* vp_ = Vb + (long)key_ * ldk;                                                             \
+      uint4* dst_ = &KV[STAGE][(wave * DMA_PER_WAVE + i) * 64];                                                      \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kp_ + kch[i]), (lptr_t)(dst_), 16, 0, 0);                            \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kp_ + k_plane + kch[i]), (lptr_t)(dst_ + TILE16), 16, 0, 0);        \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vp_ + vch[i]), (lptr_t)(dst_ + 2 * TILE16), 16, 0, 0);               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vp_ + k_plane + vch[i]), (lptr_t)(dst_ + 3 * TILE16), 16, 0, 0);     \
+    }                                                                                                                \
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+  const int hh = lane >> 5, kl = lane & 31;
+  const int kg = (DH == 64) ? ((kl >> 1) & 7) : (kl & 15);
+  const int ntiles = (T + 63) / 64;
+  const char* vbase[DB];
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int key0 = 4 * (g >> 1) + q;
+    const int sw = (DH == 64) ? (((q >> 1) & 1) << 2) : (q << 2);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+      vbase[db] = (const char*)&KV[0][2 * TILE16] + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
+    }
+  }
+  constexpr long STAGE_BYTES = (long)4 * TILE16 * 16;
+  constexpr long PLANE_BYTES = (long)TILE16 * 16;
+  SVT_STAGE_X3(0, 0)
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int st = tile & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile + 1 < ntiles) {
+      if (st) SVT_STAGE_X3(tile + 1, 0) else SVT_STAGE_X3(tile + 1, 1)
+    }
+    const uint4* Kh = KV[st];
+    const uint4* Kl = KV[st] + TILE16;
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks) {
+        const int idx = (kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg);
+        const uint4 kh = Kh[idx], klo = Kl[idx];
+        s[kb] = X::mma(klo, qh[ks], s[kb]);
+        s[kb] = X::mma(kh, ql[ks], s[kb]);
+        s[kb] = X::mma(kh, qh[ks], s[kb]);
+      }
+    }
+    if (__builtin_expect(tile * 64 + 64 > T, 0)) {
+      const int kbase = tile * 64 + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+          asm volatile("" : "+v"(s[kb][r]));
+          if (key >= T) s[kb][r] = -3e38f;
+        }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    if (!__all(mx - m <= 8.0f)) {
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      l *= alpha;
+      m = mnew;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    float sum = 0.f;
+    // P = exp2(s c - m) cut into (hi, lo) pieces; the row sum is taken over the fp32 values
+    unsigned short ph[2][16], pl[2][16];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m));
+        sum += pv;
+        X::cut(pv, ph[kb][r], pl[kb][r]);
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l += sum;
+    v8 pfh[2][2], pfl[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        s16x8 th, tl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { th[j] = (short)ph[kb][ss * 8 + j]; tl[j] = (short)pl[kb][ss * 8 + j]; }
+        pfh[kb][ss] = __builtin_bit_cast(v8, th);
+        pfl[kb][ss] = __builtin_bit_cast(v8, tl);
+      }
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const char* vp = vbase[db] + st * STAGE_BYTES + (kb * 32 + ss * 16) * RB;
+          const s16x4 hlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
+          const s16x4 hhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
+          const s16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + PLANE_BYTES));
+          const s16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + PLANE_BYTES + 8 * RB));
+          const s16x8 vh = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 vl = __builtin_shufflevector(llo, lhi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = X::mma(vl, pfh[kb][ss], o[db]);
+          o[db] = X::mma(vh, pfl[kb][ss], o[db]);
+          o[db] = X::mma(vh, pfh[kb][ss], o[db]);
+        }
+  }
+  const int q = q0 + (lane & 31);
+  if (q >= T) return;
+  const float inv = 1.f / l;
+  float* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+      *(float4*)(op + db * 32 + 8 * g + 4 * hh) = v;
+    }
+}
+#undef SVT_STAGE_X3
+
+// fp32 (rows, cols) with row pitch ld_src -> 16-bit (hi, lo) planes (rows, cols) with row pitch ld_dst, lo plane `plane`
+// elements after the hi plane; cols % 4 == 0
+template <bool F16>
+__global__ void split_planes_kernel(const float* __restrict__ src, long ld_src, long rows, int cols, unsigned short* __restrict__ dst,
+                                    long ld_dst, long plane) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = cols / 4;
+  if (i >= rows * c4) return;
+  const long r = i / c4;
+  const int c = (int)(i % c4) * 4;
+  const float4 v = *(const float4*)(src + r * ld_src + c);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) X3T<F16>::cut(x[j], hi[j], lo[j]);
+  unsigned short* d = dst + r * ld_dst + c;
+  *(uint2*)d = uint2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+  *(uint2*)(d + plane) = uint2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Whole-head variant (head_dim 64, 256 < T <= 512: the encoder's 10 s clips, T = 499): ONE workgroup per (clip, head).
 // The head's entire K and V (512 keys x 128 B each = 2 x 64 KiB) are made resident in LDS by 16 LDS-DMA instructions per
 // wave issued up front in tile order, so K / V leave L2 exactly once per head (the 256-query workgroups above fetch them
@@ -448,6 +693,39 @@ __global__ __launch_bounds__(512) void flash_attn_head_kernel(const bf16_t* __re
   }
 }
 }  // namespace
+
+int launch_split_planes(int kind, const float* src, long ld_src, long rows, int cols, void* dst, long ld_dst, long plane, hipStream_t s) {
+  if (cols % 4 || ld_src % 4 || ld_dst % 4 || plane % 4) { set_error("split_planes: columns and pitches must be multiples of 4"); return -1; }
+  const long n = rows * (cols / 4);
+  if (kind == 3) hipLaunchKernelGGL((split_planes_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, rows, cols, (unsigned short*)dst, ld_dst, plane);
+  else hipLaunchKernelGGL((split_planes_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, rows, cols, (unsigned short*)dst, ld_dst, plane);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+bool flash_attention_x3_ok(int dh) { return dh == 64 || dh == 128; }
+// Q / K / V: 16-bit (hi, lo) planes (launch_split_planes); O fp32
+int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride, long q_plane, const void* K, const void* V, long ldk,
+                              long k_bstride, long k_plane, float* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale,
+                              hipStream_t s) {
+  if ((ldq | ldk | q_bstride | k_bstride | q_plane | k_plane) % 8 || (ldo | o_bstride) % 4) { set_error("flash_attention_x3: strides"); return -1; }
+  const float c = scale * 1.44269504088896340736f;
+  dim3 grid((T + 127) / 128, H, B);
+  const bool wide = dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512;
+  if (wide) grid.x = (T + 255) / 256;
+  const double flops = 4.0 * B * H * (double)T * T * dh;
+  const unsigned short *q = (const unsigned short*)Q, *k = (const unsigned short*)K, *v = (const unsigned short*)V;
+  prof_begin(s);
+#define SVT_X3_LAUNCH(DH_, F16_, NW_) hipLaunchKernelGGL((flash_attn_x3_kernel<DH_, F16_, NW_>), grid, dim3(64 * NW_), 0, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O, ldo, o_bstride, T, H, c)
+  if (dh == 64 && wide) { if (kind == 3) SVT_X3_LAUNCH(64, true, 8); else SVT_X3_LAUNCH(64, false, 8); }
+  else if (dh == 64) { if (kind == 3) SVT_X3_LAUNCH(64, true, 4); else SVT_X3_LAUNCH(64, false, 4); }
+  else if (dh == 128) { if (kind == 3) SVT_X3_LAUNCH(128, true, 4); else SVT_X3_LAUNCH(128, false, 4); }
+  else { set_error("flash_attention_x3: head_dim must be 64 or 128"); return -1; }
+#undef SVT_X3_LAUNCH
+  prof_end(s, flops, 0.0, 2);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
 
 int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones, 2 = also the whole-head kernel
 // whole-head kernel (K / V of a head resident in LDS, head_dim 64, 256 < T <= 512): OFF by default.  Measured on MI355X

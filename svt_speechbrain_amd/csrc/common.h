@@ -158,6 +158,12 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
 // small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
 bool gemm_skinny_eligible(const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
+// split-operand modes: weight matrices cut once into packed 16-bit (hi, lo) pieces for the LDS-DMA split kernel
+// (gemm_dma.hip gemm_x3_kernel).  kind = svt_precision (2 = bf16 pieces, 3 = fp16 pieces); other kinds are ignored.
+int split_weights_register(const void* w_f32_dev, long n_rows, int K, int kind, hipStream_t s);
+void split_weights_forget(const void* w_f32_dev);
+int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s);  // 0 = launched, 1 = not eligible (use the register-staged kernel), < 0 = error
+extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
 extern int g_flash_head;  // whole-head fused attention kernel (K / V resident in LDS): off (0, default: measured slower) / on (1), svt_debug_set key 10
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
@@ -218,6 +224,13 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
                            const float* gate = nullptr, const float* pb = nullptr);
 
+// split-operand fused attention (attention.hip): fp32 -> 16-bit (hi, lo) planes, then softmax(scale Q K^T) V with three MFMAs
+// per product; kind = svt_precision (2 = bf16 pieces, 3 = fp16 pieces)
+int launch_split_planes(int kind, const float* src, long ld_src, long rows, int cols, void* dst, long ld_dst, long plane, hipStream_t s);
+bool flash_attention_x3_ok(int dh);
+int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride, long q_plane, const void* K, const void* V, long ldk,
+                              long k_bstride, long k_plane, float* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale,
+                              hipStream_t s);
 // out = a*x + b*y (fp32 or operand type)
 int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s);
 // RCA: s = x + pe[t] (x f32 (B,T,D); x2 may be shorter in T: rows >= T2 read as zero) -> fp32 + operand type

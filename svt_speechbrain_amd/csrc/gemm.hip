@@ -479,6 +479,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_skinny = 1;
+int g_gemm_x3 = 1;
 // prec: 0 = fp32 operands, exact fp32 MFMA; 1 = bf16 operands; 2 / 3 = fp32 operands in memory, bf16x3 / fp16x3
 // split-operand products (every other argument as for prec 0)
 int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
@@ -517,6 +518,10 @@ int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
   if (prec && g_gemm_skinny && gemm_skinny_eligible(g)) return launch_gemm_skinny(g, s);
   if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
+  if (split && g_gemm_x3) {
+    const int r = launch_gemm_x3(prec_in, g, s);
+    if (r <= 0) return r;
+  }
   // split engine: two slabs in flight per workgroup, capped at 256 registers so that two workgroups share a CU (measured
   // on the encoder's shapes, tools/gemm_bench.py --prec 2: one set 185-212, two sets 186-212, three sets (one workgroup per
   // CU) 150-192 TFLOP/s: the kernel is bound by issue / barrier stalls of its four-wave lockstep, not by the loads)

@@ -19,6 +19,8 @@
 //     3x3 / 1x1 convolutions of the lip front-end's ResNet over zero-haloed channels-last tensors -- with bias +
 //     residual (operand type) + per-column PReLU in the epilogue; NBW = 2 gives a 128-column tile for 128-channel layers.
 #include "common.h"
+#include <map>
+#include <mutex>
 #include <utility>
 
 namespace svt {
@@ -709,6 +711,203 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-operand products (precision "bf16x3" / "fp16x3") on the LDS-DMA pipeline.  A stays fp32 in memory; the weight
+// matrix was cut ONCE (svt_*_finalize -> split_weights_register) into 16-bit (hi, lo) pieces stored per row and 32-deep
+// K slab as [hi k0..31 | lo k0..31] (128 bytes, the same bytes as the fp32 row).  Tile 256 x 256, K in 32-element slabs:
+// an A unit is 256 rows x 128 B of fp32, a W unit 256 rows x 128 B of pieces, both moved by full-line LDS-DMA into the
+// five-slot ring of the bf16 kernels (three units in flight across one raw barrier per slab, counted vmcnt).
+// Wave layout 8 (M) x 1 (N): a wave owns 32 rows x all 256 columns, so every A element is cut into its pieces by exactly
+// one wave (16 values per lane and slab: ~45 VALU instructions against 96 MFMAs), while the W pieces come out of LDS
+// ready-made.  Per 16 x 16 x 32 block: Wl*Xh + Wh*Xl + Wh*Xh accumulated in fp32 (three MFMAs of 16 cycles; the exact
+// fp32 form is eight of 32).  Epilogue: the LDS-transposed coalesced fp32 store of the bf16 kernels (bias, activation,
+// residual).  The register-staged split kernel of gemm.hip (which cuts BOTH operands in every workgroup, four waves in
+// lockstep around one barrier per slab) ran at 185-212 TFLOP/s on these shapes.
+// LDS-DMA issued from inline asm (M0 = LDS byte address of the wave's 1 KiB piece, saved and restored around it).  hipcc
+// tracks the LDS-DMA it emits itself for a builtin and puts an s_waitcnt vmcnt(0) in front of a later LDS read whose
+// address it cannot prove distinct from the DMA's destination -- here the W fragment reads of every slab, i.e. the ring
+// would be drained once per slab.  Through asm the compiler sees no LDS write; the counted vmcnt + barrier below order it.
+__device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* wsplit) {
+  constexpr int BM = 256, BN = 256, BK = 32, NSLOT = 5, SLOT = 2048, G = 4;  // G: DMA instructions per wave per unit
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* A = (const float*)p.A;
+  const unsigned short* W = (const unsigned short*)wsplit;  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
+  const float* asrc[G];
+  const unsigned short* wsrc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    int m = m0 + (wave + 8 * i) * 8 + r8;
+    if (m > p.M - 1) m = p.M - 1;
+    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 4;
+    const int rho = (wave + 8 * i) * 8 + r8;
+    const int i16 = rho & 15;
+    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+    if (n > p.N - 1) n = p.N - 1;
+    wsrc[i] = W + (long)n * (2 * p.K) + ch * 8;
+  }
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds);
+  auto issue_a = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      dma16_asm(asrc[i] + kt * BK, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u));
+  };
+  auto issue_w = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      dma16_asm(wsrc[i] + kt * 64, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u));
+  };
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
+  // 16-row block b of a unit starts at uint4 index b * 128; row r16 of it: group r16 >> 3, row rr8, chunk c at slot c ^ rr8
+  const int rowb = (r16 >> 3) * 64 + rr8 * 8;
+  const int fa0 = rowb + ((2 * cq) ^ rr8), fa1 = rowb + ((2 * cq + 1) ^ rr8);   // A: fp32 k = 8 cq .. 8 cq + 7 = chunks 2cq, 2cq+1
+  const int fwh = rowb + (cq ^ rr8), fwl = rowb + ((4 + cq) ^ rr8);             // W: hi pieces chunk cq, lo pieces chunk 4 + cq
+  const int nk = p.K / BK;
+  auto mma = [&](const uint4& a, const uint4& b, const f32x4& c) -> f32x4 {
+    if constexpr (F16) {
+      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+    } else {
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+  };
+  // 8 fp32 of one lane (two 16-byte chunks) -> (hi, lo) pieces
+  auto cut = [&](const uint4& r0, const uint4& r1, uint4& hi, uint4& lo) {
+    const f32x4 v0 = __builtin_bit_cast(f32x4, r0), v1 = __builtin_bit_cast(f32x4, r1);
+    if constexpr (F16) {
+      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+      f16x8v h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)v0[j]; l[j] = (_Float16)(v0[j] - (float)h[j]);
+        h[4 + j] = (_Float16)v1[j]; l[4 + j] = (_Float16)(v1[j] - (float)h[4 + j]);
+      }
+      hi = __builtin_bit_cast(uint4, h);
+      lo = __builtin_bit_cast(uint4, l);
+    } else {
+      bf16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (bf16_t)v0[j]; l[j] = (bf16_t)(v0[j] - (float)h[j]);
+        h[4 + j] = (bf16_t)v1[j]; l[4 + j] = (bf16_t)(v1[j] - (float)h[4 + j]);
+      }
+      hi = __builtin_bit_cast(uint4, h);
+      lo = __builtin_bit_cast(uint4, l);
+    }
+  };
+  // Software pipeline over slabs.  At the top of iteration kt every unit issued so far has landed (vmcnt(0) + barrier):
+  // W_kt, which this iteration multiplies, and A_{kt+1}, which it only cuts into pieces for the next one -- the A pieces of
+  // slab kt are already in registers.  The two units of the ring that nobody reads any more (those of slab kt - 1) are
+  // refilled with W_{kt+1} and A_{kt+2} right after the barrier, and the fp32 reads + cuts of A_{kt+1} sit in the middle of
+  // the 96 MFMAs, so the matrix pipe is never waiting for the wave's own DMA issue or conversion work.
+  issue_a(0, 0);
+  issue_w(0, 1);
+  if (nk > 1) issue_a(1, 2);
+  if (nk > 1) wait_vm<G>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  uint4 xh[2], xl[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) cut(lds[(wave * 2 + mb) * 128 + fa0], lds[(wave * 2 + mb) * 128 + fa1], xh[mb], xl[mb]);
+  int sw = 1;       // slot of W_kt; A_{kt+1} is in the next slot
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt > 0) {
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    } else if (nk > 1) {
+      wait_vm<0>();                  // A_1 (issued in the prologue): needed by this iteration's cut
+      __builtin_amdgcn_s_barrier();
+    }
+    if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
+    if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
+    const uint4* wa = lds + sw * SLOT;
+    const uint4* xn = lds + ((sw + 1) % NSLOT) * SLOT + (wave * 2) * 128;   // A_{kt+1}
+    uint4 raw[2][2], nh[2], nl[2];
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) { raw[mb][0] = xn[mb * 128 + fa0]; raw[mb][1] = xn[mb * 128 + fa1]; }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nb = 0; nb < 16; ++nb) {
+      const uint4 wh = wa[nb * 128 + fwh], wl = wa[nb * 128 + fwl];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wl, xh[mb], acc[nb][mb]);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wh, xl[mb], acc[nb][mb]);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wh, xh[mb], acc[nb][mb]);
+      if (nb == 5 && more) cut(raw[0][0], raw[0][1], nh[0], nl[0]);
+      if (nb == 10 && more) cut(raw[1][0], raw[1][1], nh[1], nl[1]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (more) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) { xh[mb] = nh[mb]; xl[mb] = nl[mb]; }
+    }
+    sw = (sw + 2) % NSLOT;
+  }
+  // ---- epilogue: LDS-transposed coalesced fp32 stores (epilogue_block reads its row / column base as
+  //      m0 + wm * (BM_/2) + mb * 16 and n0 + wn * 64: with BM_ = 64, wm = wave and wn = the 64-column group) ----
+  const float* bias = p.bias;
+  __syncthreads();
+  float* patch = (float*)lds + wave * (16 * 68);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, bias);
+    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, bias);
+  }
+}
+
+// fp32 (N, K) -> per row and 32-deep K slab [32 hi pieces | 32 lo pieces] (16-bit): one thread per 8 consecutive k
+template <bool F16>
+__global__ void split_pack_kernel(const float* __restrict__ w, long n_rows, int K, unsigned short* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index of an 8-element piece
+  const long per_row = K / 8;
+  if (i >= n_rows * per_row) return;
+  const long n = i / per_row;
+  const int k0 = (int)(i % per_row) * 8;
+  const float* src = w + n * K + k0;
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = src[j];
+    if constexpr (F16) {
+      const _Float16 a = (_Float16)x, b = (_Float16)(x - (float)a);
+      h[j] = __builtin_bit_cast(unsigned short, a);
+      l[j] = __builtin_bit_cast(unsigned short, b);
+    } else {
+      const bf16_t a = (bf16_t)x, b = (bf16_t)(x - (float)a);
+      h[j] = __builtin_bit_cast(unsigned short, a);
+      l[j] = __builtin_bit_cast(unsigned short, b);
+    }
+  }
+  unsigned short* dst = out + n * (2L * K) + (long)(k0 / 32) * 64 + (k0 % 32);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { dst[j] = h[j]; dst[32 + j] = l[j]; }
+}
+
 template <int BM>
 int launch_pers(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
@@ -751,6 +950,75 @@ int launch_pp8(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- registry of split weight matrices: fp32 device pointer -> packed (hi, lo) pieces (see gemm_x3_kernel) ----
+namespace {
+struct SplitW { void* packed; int N, K, kind; };
+std::map<const void*, SplitW> g_split_w;
+std::mutex g_split_mu;
+}  // namespace
+
+int split_weights_register(const void* w_f32, long n_rows, int K, int kind, hipStream_t s) {
+  if (kind != 2 && kind != 3) return 0;
+  if (K % 32 || n_rows < 1) return 0;   // K tails stay on the register-staged split kernel
+  void* packed = nullptr;
+  SVT_HIP(hipMalloc(&packed, (size_t)n_rows * K * 4));
+  const long pieces = n_rows * (K / 8);
+  if (kind == 3) hipLaunchKernelGGL((split_pack_kernel<true>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
+  else hipLaunchKernelGGL((split_pack_kernel<false>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
+  SVT_LAUNCH_CHECK();
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split_w.find(w_f32);
+  if (it != g_split_w.end()) (void)hipFree(it->second.packed);
+  g_split_w[w_f32] = SplitW{packed, (int)n_rows, K, kind};
+  return 0;
+}
+void split_weights_forget(const void* w_f32) {
+  std::lock_guard<std::mutex> lk(g_split_mu);
+  auto it = g_split_w.find(w_f32);
+  if (it == g_split_w.end()) return;
+  (void)hipFree(it->second.packed);
+  g_split_w.erase(it);
+}
+// launches the LDS-DMA split kernel when `a` is a plain (un-batched) product against a registered weight matrix; returns
+// 1 when the caller has to use the register-staged split kernel instead, 0 on success, < 0 on error
+int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
+  if (a.gen || a.nz != 1 || a.K % 32 || a.N < 128 || a.M < 128 || !a.c_vec || a.ldw != a.K || a.alpha != 1.f || a.w_z1 || a.w_z2 ||
+      a.a_z1 || a.a_z2 || a.c_z1 || a.c_z2 || (a.a_rstride & 3) || (a.a_bstride & 3) || ((uintptr_t)a.A & 15))
+    return 1;
+  const void* packed = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    // the weight pointer may point INTO a registered matrix (row offset): find the matrix that contains it
+    auto it = g_split_w.upper_bound(a.W);
+    if (it == g_split_w.begin()) return 1;
+    --it;
+    const char* base = (const char*)it->first;
+    const size_t off = (const char*)a.W - base;
+    if (it->second.kind != kind || it->second.K != a.K || off % ((size_t)a.K * 4) != 0) return 1;
+    const size_t row = off / ((size_t)a.K * 4);
+    if (row + a.N > (size_t)it->second.N) return 1;
+    packed = (const char*)it->second.packed + row * (size_t)a.K * 4;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const size_t lds_bytes = 5 * 32768;
+  GemmArgs g = a;
+  g.out_f32 = 1;
+  const double flops = 2.0 * a.M * (double)a.N * a.K;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
+  static bool attr_set[2] = {false, false};
+  prof_begin(s);
+  if (kind == 3) {
+    if (!attr_set[1]) { SVT_HIP(hipFuncSetAttribute((const void*)gemm_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set[1] = true; }
+    hipLaunchKernelGGL((gemm_x3_kernel<true>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+  } else {
+    if (!attr_set[0]) { SVT_HIP(hipFuncSetAttribute((const void*)gemm_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set[0] = true; }
+    hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+  }
+  prof_end(s, flops, bytes, 0);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
 
 bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 && a.M >= 128 && a.c_vec && a.N % 8 == 0; }
 

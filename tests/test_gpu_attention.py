@@ -66,3 +66,26 @@ def test_whole_head_kernel_variant(B, T, H):
         lib.svt_debug_set(10, 0)
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() < 4e-2 and (got - ref).abs().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 2e-5), (2, 4e-4)])
+@pytest.mark.parametrize("B,T,H,dh", [(2, 499, 12, 64), (1, 249, 3, 64), (2, 499, 8, 128), (2, 65, 2, 64), (1, 1, 2, 64), (3, 130, 2, 128)])
+def test_split_operand_attention_vs_torch(prec, tol, B, T, H, dh):
+    """The fused attention of the split-operand modes (fp32 q|k|v cut into 16-bit (hi, lo) planes, three MFMAs per product,
+    fp32 output) against fp64 softmax(q k^T) v on the same fp32 inputs: fp16 pieces to ~1e-6, bf16 pieces to ~1e-4."""
+    lib = _lib.load()
+    D = H * dh
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.5).to(DEV)
+    out = torch.full((B, T, D), float("nan"), device=DEV)
+    scale = dh ** -0.5
+    _lib.check(lib.svt_debug_attention(prec, qkv.data_ptr(), qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, out.data_ptr(), B, T, H, dh,
+                                       3 * D, 3 * D, D, scale, 0, torch.cuda.current_stream().cuda_stream), "svt_debug_attention")
+    torch.cuda.synchronize()
+    q, k, v = [x.double().cpu().view(B, T, H, dh).transpose(1, 2) for x in qkv.split(D, dim=-1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, T, D).float()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    print(f"split attention prec={prec} B={B} T={T} H={H} dh={dh}: max|err| {err:.3e}")
+    assert err < tol, err

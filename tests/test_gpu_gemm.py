@@ -71,6 +71,12 @@ CASES = [
     ("fp16x3_conv", 3, 2 * 999, 512, 1024, (1999, 999, 2, 512), 1, 0, False),
     ("fp16x3_ntail", 3, 777, 200, 3072, None, 2, 0, False),
     ("fp16x3_narrow_ktail", 3, 499, 20, 772, None, 0, 0, False),
+    # ... on the LDS-DMA split kernel (256 x 256 tiles, weight pieces cut once): M / N tails, conv rows, every epilogue
+    ("x3dma_bf16_conv", 2, 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, 0, False),
+    ("x3dma_fp16_qkv", 3, 15968, 2304, 768, None, 0, 0, False),
+    ("x3dma_fp16_mtail_ntail", 3, 777, 200, 3072, None, 2, 0, True),
+    ("x3dma_bf16_resid_k32", 2, 1000, 768, 32, None, 0, 0, True),
+    ("x3dma_fp16_one_tile", 3, 130, 136, 64, None, 1, 0, False),
 ]
 
 

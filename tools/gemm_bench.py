@@ -116,6 +116,7 @@ if __name__ == "__main__":
     ap.add_argument("--skinny-max-tiles", type=int, default=32)
     ap.add_argument("--variant", type=int, default=0, help="svt_debug_set key 3 (experimental kernel variants)")
     ap.add_argument("--nobias", action="store_true")
+    ap.add_argument("--no-x3-dma", action="store_true", help="split-operand modes: register-staged kernel instead of the LDS-DMA one (A/B)")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
@@ -124,6 +125,8 @@ if __name__ == "__main__":
     _lib.load().svt_debug_set(3, a.variant)
     _lib.load().svt_debug_set(6, 0 if a.no_skinny else 1)
     _lib.load().svt_debug_set(7, a.skinny_max_tiles)
+    _lib.load().svt_debug_set(11, 0 if a.no_x3_dma else 1)
+    _lib.load().svt_debug_set(12, 1)
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
