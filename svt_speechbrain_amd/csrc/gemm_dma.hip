@@ -45,10 +45,30 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // Instead each wave transposes its 16 x 64 block through a private LDS patch (row pitch 272 B: conflict-free both
 // ways) and stores row-contiguous: 16 (fp32) / 8 (bf16) consecutive lanes cover whole 128-byte lines.  Bias,
 // activation and the fp32 residual are applied on the read-back side with the same coalesced addressing.
+// this lane's bias values on the read-back side of epilogue_block (column base c4 = (lane & 15) * 4 for fp32 output,
+// c8 = (lane & 7) * 8 for bf16): loaded ONCE per wave and tile, not once per 16-row block (eight dependent L2 round trips)
+struct BiasRegs { float v[8]; };
+template <bool OUT32>
+__device__ __forceinline__ BiasRegs load_bias_regs(const GemmArgs& p, const float* bias, int lane, int wn, int n0) {
+  BiasRegs b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b.v[j] = 0.f;
+  const int n = n0 + wn * 64 + (OUT32 ? (lane & 15) * 4 : (lane & 7) * 8);
+  if (bias && n < p.N) {
+    const float4 b0 = *(const float4*)(bias + n);
+    b.v[0] = b0.x; b.v[1] = b0.y; b.v[2] = b0.z; b.v[3] = b0.w;
+    if (!OUT32) {
+      const float4 b1 = *(const float4*)(bias + n + 4);
+      b.v[4] = b1.x; b.v[5] = b1.y; b.v[6] = b1.z; b.v[7] = b1.w;
+    }
+  }
+  return b;
+}
+
 template <int MB, int BM, bool OUT32>
 __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a0, const f32x4& a1, const f32x4& a2,
                                                const f32x4& a3, int mb, float* patch, int lane, int wm, int wn, int m0,
-                                               int n0, long coff, const float* bias) {
+                                               int n0, long coff, const BiasRegs& br) {
   constexpr int PITCH = 68;  // floats
   const int m16 = lane & 15, q = lane >> 4;
   constexpr bool out32 = OUT32;
@@ -66,8 +86,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
     if (out32) {
       const int c4 = (lane & 15) * 4;
       const int n = n0 + wn * 64 + c4;
-      float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
-      if (bias && n < p.N) b4 = *(const float4*)(bias + n);
+      const float4 b4 = float4{br.v[0], br.v[1], br.v[2], br.v[3]};
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int r = pass * 4 + (lane >> 4);
@@ -89,11 +108,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
       const int n = n0 + wn * 64 + c8;
       float bb[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bb[j] = 0.f;
-      if (bias && n < p.N) {
-        const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-      }
+      for (int j = 0; j < 8; ++j) bb[j] = br.v[j];
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const int r = pass * 8 + (lane >> 3);
@@ -212,9 +227,10 @@ template <int MB, int BM, bool OUT32, int... I>
 __device__ __forceinline__ void epilogue_seq(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[4][MB],
                                              float* patch, int lane, int wm, int wn, int m0, int n0, long coff,
                                              const float* bias) {
+  const BiasRegs br = load_bias_regs<OUT32>(p, bias, lane, wn, n0);
   // fold over compile-time block indices: every acc[][] index is static (a runtime-indexed accumulator array
   // would be demoted to scratch)
-  (epilogue_block<MB, BM, OUT32>(p, acc[0][I], acc[1][I], acc[2][I], acc[3][I], I, patch, lane, wm, wn, m0, n0, coff, bias),
+  (epilogue_block<MB, BM, OUT32>(p, acc[0][I], acc[1][I], acc[2][I], acc[3][I], I, patch, lane, wm, wn, m0, n0, coff, br),
    ...);
 }
 
@@ -620,12 +636,17 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
       char* cbase = (char*)p.C + (long)m0 * p.ldc * esz;
       const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);
       const int nbase = n0 + wn * 64 + (lane >> 4) * 16;
+      // one branch around the four bias loads (hipcc waits vmcnt(0) at the first use of an ordinary load while LDS-DMA is in
+      // flight; a branch per load made that four serial waits per tile -- measured: no difference, the waits overlap the
+      // epilogue's own latency; kept because it is the simpler code)
       float bv[16];
 #pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *(const float4*)(p.bias + nbase + j4 * 4);
-        bv[j4 * 4 + 0] = b4.x; bv[j4 * 4 + 1] = b4.y; bv[j4 * 4 + 2] = b4.z; bv[j4 * 4 + 3] = b4.w;
+      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+      if (p.bias) {
+        const float4* bp = (const float4*)(p.bias + nbase);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        bv[8] = b2.x; bv[9] = b2.y; bv[10] = b2.z; bv[11] = b2.w; bv[12] = b3.x; bv[13] = b3.y; bv[14] = b3.z; bv[15] = b3.w;
       }
       if (p.out_f32) {
 #pragma unroll
@@ -875,8 +896,9 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* ws
   float* patch = (float*)lds + wave * (16 * 68);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, bias);
-    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, bias);
+    const BiasRegs br = load_bias_regs<true>(p, bias, lane, g, n0);
+    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, br);
+    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, br);
   }
 }
 
