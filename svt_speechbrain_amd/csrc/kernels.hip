@@ -707,9 +707,16 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
   const int myrow = (hi32 ? 2 : 0) + (hi16 ? 1 : 0);
-  // running (sum, sum of squares) of the group this wave is in; flushed with two fp64 atomics when the group changes
-  int64_t cur_g = -1;
-  double gs = 0.0, gss = 0.0;
+  // per-lane running (sum, sum of squares) of the norm group this wave is in: folded across the wave and flushed with two fp64
+  // atomics only when the wave's rows cross into another group (and at the end) -- no shuffles and no division per row
+  int64_t cur_g = -1, g_end = 0;
+  float la = 0.f, lq = 0.f;
+  auto flush = [&]() {
+    if (cur_g < 0) return;
+    const double sa = wave_sum((double)la), sq = wave_sum((double)lq);
+    if (lane == 0) { atomicAdd(&mom[2 * cur_g], sa); atomicAdd(&mom[2 * cur_g + 1], sq); }
+    la = 0.f; lq = 0.f;
+  };
   for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
     float4 xv[4][KC];
 #pragma unroll
@@ -721,6 +728,12 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
     if (mom) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
+        if (r0 + rr >= rows) break;  // wave-uniform
+        if (r0 + rr >= g_end || cur_g < 0) {  // rare: first row of the wave, or a group boundary
+          flush();
+          cur_g = (r0 + rr) / rows_per_group;
+          g_end = (cur_g + 1) * rows_per_group;
+        }
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
@@ -728,17 +741,8 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
           a += (v.x + v.y) + (v.z + v.w);
           q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
-        a = wave_sum(a);
-        q = wave_sum(q);
-        if (r0 + rr < rows) {  // wave-uniform
-          const int64_t g = (r0 + rr) / rows_per_group;
-          if (g != cur_g) {
-            if (cur_g >= 0 && lane == 0) { atomicAdd(&mom[2 * cur_g], gs); atomicAdd(&mom[2 * cur_g + 1], gss); }
-            cur_g = g; gs = 0.0; gss = 0.0;
-          }
-          gs += (double)a;
-          gss += (double)q;
-        }
+        la += a;
+        lq += q;
       }
     }
     float out0 = 0.f, out1 = 0.f;
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
       if (n0 + 16 < N) dots[row * N + n0 + 16] = out1;
     }
   }
-  if (mom && cur_g >= 0 && lane == 0) { atomicAdd(&mom[2 * cur_g], gs); atomicAdd(&mom[2 * cur_g + 1], gss); }
+  if (mom) flush();
 }
 
 // one thread per row: logits = (dots - mean * wsum) * rstd + bias; optional per-frame decode (same rule as decode_frames_kernel)
