@@ -250,7 +250,8 @@ int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const 
  * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles, 8 = 8-wave fused-attention workgroups on/off,
  * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode, 10 = whole-head fused
  * attention kernel (K / V of a head resident in LDS; measured slower, off by default), 11 = LDS-DMA split-operand GEMM
- * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls.
+ * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls,
+ * 13 = page-guarded device allocations (see svt_debug_alloc).
  * Returns 0. */
 int svt_debug_set(int key, int value);
 
@@ -269,6 +270,12 @@ int svt_prof_read(int kind, int64_t* launches, double* total_ms, double* total_f
  * Two calls around a region give the clock the chip HELD over it: d(memtime) / d(memrealtime) * 100 MHz, per XCD.
  * out_dev: 16 x int64, zeroed by the caller (an XCD that ran no block of the kernel leaves its pair untouched). */
 int svt_debug_clock(int64_t* out_dev, int device, void* stream);
+/* Diagnostics: a device buffer from the library's own allocator.  With svt_debug_set(13, 1 | 2) every allocation of the library
+ * (these included) is its own mapping between two unmapped granules of address space, flush against the end (1) or the start (2)
+ * of the mapping: an out-of-bounds access by a kernel on that side faults instead of landing in a neighbour
+ * (tests/test_gpu_guard.py runs the forward passes with weights, workspace and inputs placed this way). */
+int svt_debug_alloc(void** out, size_t bytes, int device);
+int svt_debug_free(void* p, int device);
 
 #ifdef __cplusplus
 }

@@ -58,11 +58,73 @@ void prof_end(hipStream_t s, double flops, double bytes, int kind) {
 }
 
 // ---------------------------------------------------------------- small helpers
+// ---- device allocations of the library (weights, packed pieces, scratch of the debug hooks) ----
+// g_guard_alloc (svt_debug_set key 13, diagnostics): 0 = hipMalloc.  1 / 2 = every allocation gets its own mapping between two
+// unmapped granules of reserved address space, the buffer flush against the END (1) or the START (2) of the mapping, so that a
+// kernel reading or writing past that edge takes a page fault instead of touching a neighbour (this pool has no GPU sanitizer).
+// 3 = hipMalloc with every byte set to 0xFF.
+int g_guard_alloc = 0;
+namespace {
+struct GuardRec { void* va; size_t va_bytes; void* map; size_t map_bytes; hipMemGenericAllocationHandle_t h; };
+std::map<void*, GuardRec> g_guard_recs;
+std::mutex g_guard_mu;
+}  // namespace
+int dev_alloc(void** out, size_t n) {
+  if (n == 0) n = 16;
+  if (!g_guard_alloc) { SVT_HIP(hipMalloc(out, n)); return 0; }
+  if (g_guard_alloc == 3) {   // plain allocation, every byte 0xFF (NaN in fp32 / bf16 / fp16): finds reads of bytes nobody wrote
+    SVT_HIP(hipMalloc(out, n));
+    SVT_HIP(hipMemset(*out, 0xFF, n));
+    return 0;
+  }
+  int dev = 0;
+  SVT_HIP(hipGetDevice(&dev));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  SVT_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  const size_t n16 = (n + 15) / 16 * 16, mapped = (n16 + gran - 1) / gran * gran;
+  GuardRec r{};
+  r.va_bytes = mapped + 2 * gran;
+  r.map_bytes = mapped;
+  SVT_HIP(hipMemAddressReserve(&r.va, r.va_bytes, gran, nullptr, 0));
+  r.map = (char*)r.va + gran;
+  SVT_HIP(hipMemCreate(&r.h, mapped, &prop, 0));
+  SVT_HIP(hipMemMap(r.map, mapped, 0, r.h, 0));
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  SVT_HIP(hipMemSetAccess(r.map, mapped, &acc, 1));
+  *out = g_guard_alloc == 2 ? r.map : (char*)r.map + (mapped - n16);
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard_recs[*out] = r;
+  return 0;
+}
+void dev_free(void* p) {
+  if (!p) return;
+  GuardRec r{};
+  {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    auto it = g_guard_recs.find(p);
+    if (it == g_guard_recs.end()) { (void)hipFree(p); return; }
+    r = it->second;
+    g_guard_recs.erase(it);
+  }
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(r.map, r.map_bytes);
+  (void)hipMemRelease(r.h);
+  // the reservation is deliberately NOT returned (hipMemAddressFree): on this stack a later reservation that lands on the same
+  // addresses is read through stale translations (measured: garbage weights after a free / allocate pair); address space is not
+  // a scarce resource for a diagnostic run
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   ~DevBuf() { release(); }
-  void release() { if (p) { split_weights_forget(p); (void)hipFree(p); p = nullptr; } }
+  void release() { if (p) { split_weights_forget(p); dev_free(p); p = nullptr; } }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -70,8 +132,7 @@ struct DevBuf {
   int alloc(size_t n) {
     release();
     bytes = n;
-    SVT_HIP(hipMalloc(&p, n ? n : 16));
-    return 0;
+    return dev_alloc(&p, n);
   }
   template <typename T> T* as() const { return (T*)p; }
 };
@@ -386,13 +447,13 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
     if ((const float*)k != (const float*)q + D || (const float*)v != (const float*)q + 2 * D || ldq != 3 * D || ldkv != 3 * D) {
       set_error("svt_debug_attention: the split-operand kernel is exposed for a packed q|k|v projection"); return SVT_ERR_INVALID; }
     void* planes = nullptr;
-    SVT_HIP(hipMalloc(&planes, (size_t)rows * 3 * D * 4));
+    if (int r = dev_alloc(&planes, (size_t)rows * 3 * D * 4)) return r;
     AttnBufs ab{};
     ab.pl_qkv = planes;
     const int rc = attention_scores_path(0, q, ldq, k, v, ldkv, batch, t, heads, head_dim, scale, ab, false, o, ldo, (hipStream_t)stream,
                                          nullptr, nullptr, precision);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(planes);
+    dev_free(planes);
     return rc ? SVT_ERR_INVALID : SVT_OK;
   }
   if (launch_flash_attention(q, ldq, (long)t * ldq, k, v, ldkv, (long)t * ldkv, o, ldo, (long)t * ldo, batch, t, heads,
@@ -423,7 +484,21 @@ int svt_debug_set(int key, int value) {
   else if (key == 10) g_flash_head = value;
   else if (key == 11) g_gemm_x3 = value;
   else if (key == 12) g_debug_keep_split = value;
+  else if (key == 13) g_guard_alloc = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
+  return SVT_OK;
+}
+
+int svt_debug_alloc(void** out, size_t bytes, int device) {
+  if (!out) { set_error("svt_debug_alloc: null argument"); return SVT_ERR_INVALID; }
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  return dev_alloc(out, bytes);
+}
+int svt_debug_free(void* p, int device) {
+  if (int r = check_device(device)) return r;
+  SVT_HIP(hipSetDevice(device));
+  dev_free(p);
   return SVT_OK;
 }
 

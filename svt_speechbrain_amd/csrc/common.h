@@ -173,6 +173,11 @@ extern int g_gemm_force_bm;
 extern int g_gemm_ring;
 extern int g_gemm_variant;  // diagnostics: replaces dbg inside the kernel while the trace pointer stays set
 
+// ---- device allocations of the library (api.hip): hipMalloc, or page-guarded mappings under svt_debug_set key 13 ----
+int dev_alloc(void** out, size_t bytes);
+void dev_free(void* p);
+extern int g_guard_alloc;
+
 // ---- profiling of the dominant kernel (bench.py roofline leg) ----
 void prof_begin(hipStream_t s);
 // kind: 0 = the dominant family (gemm_pers / gemm_pp8 / outproj_ln kernels; the split form of gemm_kernel), 1 = other dense contraction kernels, 2 = flash attention

@@ -179,13 +179,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmArgs p) {
     constexpr int S = decltype(set_c)::value;
     // The loads are unconditional: a "load or zero" select per piece makes hipcc branch around every load and drain
     // vmcnt(0) at the top of each iteration (nothing stays in flight across the MFMAs).  A piece past the end of K
-    // (last slab only) re-reads the piece of slab 0 -- valid memory -- and is zeroed when the slab is written to LDS.
+    // (last slab only) re-reads the FIRST piece of its row -- valid memory whatever K is (K < BK included: found with the
+    // page-guarded allocator, tests/test_gpu_guard.py) -- and is zeroed when the slab is written to LDS.
     int kbase = kt * BK;
-    if ((kbase + pc * EPP) >= p.K) kbase = 0;
     long ka = kbase;
     if constexpr (GEN) {
       if (p.kseg) ka = (long)(kbase / p.kseg) * p.kseg_stride + (kbase % p.kseg);
     }
+    if ((kbase + pc * EPP) >= p.K) { kbase = -pc * EPP; ka = kbase; }   // xsrc / wsrc already point at piece pc of the row
 #pragma unroll
     for (int i = 0; i < XP; ++i) xr[S][i] = *(const uint4*)(xsrc[i] + ka);
 #pragma unroll

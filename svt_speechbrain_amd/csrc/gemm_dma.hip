@@ -984,14 +984,14 @@ int split_weights_register(const void* w_f32, long n_rows, int K, int kind, hipS
   if (kind != 2 && kind != 3) return 0;
   if (K % 32 || n_rows < 1) return 0;   // K tails stay on the register-staged split kernel
   void* packed = nullptr;
-  SVT_HIP(hipMalloc(&packed, (size_t)n_rows * K * 4));
+  if (int r = dev_alloc(&packed, (size_t)n_rows * K * 4)) return r;
   const long pieces = n_rows * (K / 8);
   if (kind == 3) hipLaunchKernelGGL((split_pack_kernel<true>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
   else hipLaunchKernelGGL((split_pack_kernel<false>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
   SVT_LAUNCH_CHECK();
   std::lock_guard<std::mutex> lk(g_split_mu);
   auto it = g_split_w.find(w_f32);
-  if (it != g_split_w.end()) (void)hipFree(it->second.packed);
+  if (it != g_split_w.end()) dev_free(it->second.packed);
   g_split_w[w_f32] = SplitW{packed, (int)n_rows, K, kind};
   return 0;
 }
@@ -999,7 +999,7 @@ void split_weights_forget(const void* w_f32) {
   std::lock_guard<std::mutex> lk(g_split_mu);
   auto it = g_split_w.find(w_f32);
   if (it == g_split_w.end()) return;
-  (void)hipFree(it->second.packed);
+  dev_free(it->second.packed);
   g_split_w.erase(it);
 }
 // launches the LDS-DMA split kernel when `a` is a plain (un-batched) product against a registered weight matrix; returns
