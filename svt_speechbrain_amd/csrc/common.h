@@ -70,27 +70,28 @@ __device__ __forceinline__ f32x2_t gelu_bf16x2(f32x2_t x) {
 }
 // four pairs at once, Horner steps interleaved across the pairs: hipcc otherwise emits the four dependent chains one
 // after the other (a v_pk_fma every ~8 cycles behind an s_nop), i.e. latency-bound with ILP 1
-__device__ __forceinline__ void gelu_bf16x2_x4(f32x2_t (&x)[4]) {
-  f32x2_t z[4], u[4], q[4];
+template <int NP>
+__device__ __forceinline__ void gelu_bf16x2_xn(f32x2_t (&x)[NP]) {
+  f32x2_t z[NP], u[NP], q[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NP; ++i) {
     z[i] = x[i] * 0.70710678118654752440f;
     z[i].x = __builtin_amdgcn_fmed3f(z[i].x, -3.0f, 3.0f);
     z[i].y = __builtin_amdgcn_fmed3f(z[i].y, -3.0f, 3.0f);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = z[i] * z[i];
+  for (int i = 0; i < NP; ++i) u[i] = z[i] * z[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] = u[i] * 4.074456683e-08f + (-1.944940095e-06f);
+  for (int i = 0; i < NP; ++i) q[i] = u[i] * 4.074456683e-08f + (-1.944940095e-06f);
   constexpr float c[7] = {4.106299457e-05f, -5.110675702e-04f, 4.235681612e-03f, -2.510436811e-02f,
                           1.110860035e-01f, -3.753373921e-01f, 1.128336072e+00f};
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = q[i] * u[i] + c[k];
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * u[i] + c[k];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NP; ++i) {
     f32x2_t pe = z[i] * q[i];
     pe.x = __builtin_amdgcn_fmed3f(pe.x, -1.0f, 1.0f);
     pe.y = __builtin_amdgcn_fmed3f(pe.y, -1.0f, 1.0f);
@@ -98,6 +99,7 @@ __device__ __forceinline__ void gelu_bf16x2_x4(f32x2_t (&x)[4]) {
     x[i] = hx * pe + hx;
   }
 }
+__device__ __forceinline__ void gelu_bf16x2_x4(f32x2_t (&x)[4]) { gelu_bf16x2_xn<4>(x); }
 #endif
 
 void set_error(const std::string& msg);

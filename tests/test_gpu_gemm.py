@@ -92,6 +92,35 @@ def test_gemm_vs_torch(name, prec, M, N, K, conv, act, out_f32, resid):
     assert err < tol, (name, err)
 
 
+W4_CASES = [
+    # name, M, N, K, conv, act, out_f32, resid   (variant 40: one tile per workgroup; 41: persistent, needs K % 128 == 0, N % 256 == 0, no residual)
+    ("ffn1_gelu", 15968, 3072, 768, None, 1, 0, False),
+    ("conv_gelu_mtail", 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, 0, False),
+    ("f32out", 4999, 768, 768, None, 0, 1, False),
+    ("f32out_resid_ntail", 1000, 200, 128, None, 0, 1, True),
+    ("relu_two_slabs", 777, 256, 128, None, 2, 0, False),
+    ("one_slab", 300, 256, 64, None, 0, 0, False),
+    ("many_tiles_per_cu", 70000, 512, 256, None, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize("variant", [40, 41])
+@pytest.mark.parametrize("name,M,N,K,conv,act,out_f32,resid", W4_CASES, ids=[c[0] for c in W4_CASES])
+def test_four_wave_kernel_variants(variant, name, M, N, K, conv, act, out_f32, resid):
+    """The experimental four-wave kernels (gemm_w4_kernel / gemm_w4p_kernel: one wave per SIMD, 128 x 128 wave tiles, hand-ordered
+    slab body, register-direct epilogue; svt_debug_set key 3 = 40 / 41) against the same torch reference.  Shapes the persistent form
+    does not take fall through to the default dispatch, which must stay correct with the switch set."""
+    lib = _lib.load()
+    lib.svt_debug_set(3, variant)
+    try:
+        got, ref = run_gemm(1, M, N, K, conv, act, out_f32, resid)
+    finally:
+        lib.svt_debug_set(3, 0)
+    assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
+    err = (got - ref).abs().max().item()
+    assert err < (2e-4 if out_f32 else 3e-2), (name, variant, err)
+
+
 def test_gemm_rejects_unaligned():
     lib = _lib.load()
     A = torch.zeros(64, 36, device=DEV, dtype=torch.bfloat16)

@@ -130,13 +130,13 @@ def test_encoder_random_geometries_stay_in_bounds(seed):
 
 
 @pytest.mark.parametrize("cfg_name,prec,shapes", [
-    ("wav2vec2-base", "bf16", [(1, 16000), (2, 47000), (5, 80000), (9, 31000)]),
+    ("wav2vec2-base", "bf16", [(1, 16000), (5, 80000), (9, 31000)]),
     ("wav2vec2-base", "fp16x3", [(1, 16000), (3, 47000)]),
     ("wav2vec2-base", "bf16x3", [(2, 23000)]),
     ("wav2vec2-base", "fp32", [(2, 23000)]),
     ("wavlm-base", "bf16", [(2, 47000)]),
     ("wavlm-base", "fp16x3", [(1, 30000)]),
-    ("wav2vec2-large-lv60", "bf16", [(1, 16000), (3, 47000)]),
+    ("wav2vec2-large-lv60", "bf16", [(3, 47000)]),
     ("wav2vec2-large-lv60", "fp16x3", [(2, 20000)]),
     ("hubert-large-ll60k", "bf16", [(2, 33000)]),
     ("data2vec-audio-base", "bf16", [(2, 33000)]),
@@ -147,15 +147,17 @@ def test_full_width_models_stay_in_bounds(cfg_name, prec, shapes):
     if cfg_name not in PRESETS:
         pytest.skip(f"no preset {cfg_name}")
     cfg = PRESETS[cfg_name]
+    enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision=prec, seed=3).to(DEV)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict(W.seeded_head_state_dict(cfg.hidden_size, 20, seed=4))
+    head = head.to(DEV)
     for B, L in shapes:
         g = torch.Generator().manual_seed(B * 100 + L)
         wav = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
 
         def run(to_dev):
-            enc = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, precision=prec, seed=3).to(DEV)
-            head = S.Linear(20, input_size=cfg.hidden_size)
-            head.load_state_dict(W.seeded_head_state_dict(cfg.hidden_size, 20, seed=4))
-            head = head.to(DEV)
+            enc._dev.close()    # the device-side objects are rebuilt (weights uploaded again) under the allocator of this run
+            head._dev.close()
             x = to_dev(wav)
             feats = enc(x)
             logits = head(feats)
@@ -163,6 +165,8 @@ def test_full_width_models_stay_in_bounds(cfg_name, prec, shapes):
             fused = enc.forward_head(x, head, frames=frames)
             return feats.cpu(), logits.cpu(), S.decode_frames(logits), fused.cpu(), frames.cpu()
         check_guarded(run, (cfg_name, prec, B, L))
+    enc._dev.close()
+    head._dev.close()
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
