@@ -143,7 +143,7 @@ def main():
     import svt_speechbrain_amd as S
     from svt_speechbrain_amd import _lib, distributed as D
     from svt_speechbrain_amd import weights as W
-    from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note
+    from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note_batch
 
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # before the process group: RCCL binds to it
     rank, local, world = D.init_from_env()
@@ -288,7 +288,7 @@ def main():
                 done[pending].synchronize()
                 th = time.perf_counter()
                 fr = fr_host[pending].numpy().view(FRAME_DTYPE).reshape(hi - lo, T)
-                n_notes = sum(len(frames2note(fr[b], 0.4, 0.5, 1 / 49.8)) for b in range(hi - lo))
+                n_notes = sum(len(x) for x in frames2note_batch(fr, 0.4, 0.5, 1 / 49.8))
                 host_s += time.perf_counter() - th
             pending = (it % ns) if it < n_it else None
             if ns == 1 and pending is not None:  # one lane: nothing to overlap with, finish this batch before the next step
@@ -296,7 +296,7 @@ def main():
         dt = time.perf_counter() - t0
         notes_out = {"clips_per_s": round((hi - lo) * n_it / dt, 3), "ms_per_step": round(1e3 * dt / n_it, 4), "iterations": n_it,
                      "host_ms_per_step": round(1e3 * host_s / n_it, 4), "notes_in_last_batch": int(n_notes),
-                     "what": "per rank: step + D2H copy of the decoded frames (16 B per frame, pinned) + frames2note of every clip on the host "
+                     "what": "per rank: step + D2H copy of the decoded frames (16 B per frame, pinned) + frame2note of every clip on the host (svt_frames_to_notes, one call per batch) "
                              "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); the host work of step i overlaps the GPU "
                              "work of step i + 1 (one batch per lane in flight); host_ms_per_step = the frames2note share"}
 

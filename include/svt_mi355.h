@@ -153,6 +153,18 @@ int svt_linear_forward(svt_linear* l, const float* x_dev, int64_t rows, float* y
 /* logits (rows, 2+n_octave+1+n_class+1) -> frames; argmax = first maximum, sigmoid in fp32 */
 int svt_decode_frames(const float* logits_dev, int64_t rows, int32_t n_out, int32_t n_octave,
                       int32_t n_class, svt_frame* frames_dev, int device, void* stream);
+/* frame2note (reference MIR_ST500/utils.py:82-149; called per song at train_audio_ssl.py:104-108) over a batch of decoded frame
+ * sequences ON THE HOST: frames = batch x frames_per_clip records (host memory, as copied back from svt_decode_frames /
+ * svt_encoder_forward_head), n_frames = valid frames per clip (NULL: all).  Outputs, per clip b at [b * capacity_per_clip ...]:
+ * onset / offset times in seconds (frame_size * frame index, double like the reference's Python floats), pitch (MIDI number =
+ * mode of the note's frames + 36), the note's frame range [lo, hi), and n_notes[b].  Where the top pitch count is tied the
+ * reference's answer is CPython's max(set(bag), key=bag.count) -- set iteration order -- so pitch is -1 and the caller resolves it
+ * from the frames in [lo, hi) (svt_speechbrain_amd/decode.py does).  A one-frame sequence above the onset threshold is the
+ * reference's ValueError (max of an empty window): SVT_ERR_INVALID.  No device call is made. */
+int svt_frames_to_notes(const svt_frame* frames_host, int32_t batch, int64_t frames_per_clip, const int64_t* n_frames,
+                        float onset_thres, float offset_thres, double frame_size, int32_t n_octave, int32_t n_class,
+                        double* t_on, double* t_off, int32_t* pitch, int32_t* lo, int32_t* hi, int64_t capacity_per_clip,
+                        int64_t* n_notes);
 
 /* ---- RCA fusion: replaces FusionRCA (N20EMv2/audio_visual/fusion.py:186-209) ---- */
 int svt_rca_create(int32_t d_model, int32_t nhead, int32_t d_ffn, float alpha, int32_t max_len,

@@ -5,7 +5,7 @@ from .huggingface_interface import HuggingFaceWav2Vec2  # noqa: F401
 from .linear import Linear  # noqa: F401
 from .fusion import FusionRCA  # noqa: F401
 from .features import Fbank  # noqa: F401
-from .decode import decode_frames, frame2note, frames2note, frames_to_info, ctc_greedy_decode, filter_ctc_output  # noqa: F401
+from .decode import decode_frames, frame2note, frames2note, frames2note_batch, frames_to_info, ctc_greedy_decode, filter_ctc_output  # noqa: F401
 from .amt import AMTForward  # noqa: F401
 from . import losses  # noqa: F401
 from . import checkpoints  # noqa: F401
@@ -17,5 +17,5 @@ from .video import FairseqAVHubertPretrain  # noqa: F401
 from .song import SongTranscriber, utterance_bounds, save_song_features, feature_path  # noqa: F401
 
 __all__ = ["EncoderConfig", "PRESETS", "config_from_source", "HuggingFaceWav2Vec2", "Linear", "FusionRCA", "Fbank",
-           "decode_frames", "frame2note", "frames2note", "frames_to_info", "ctc_greedy_decode", "filter_ctc_output", "AMTForward",
+           "decode_frames", "frame2note", "frames2note", "frames2note_batch", "frames_to_info", "ctc_greedy_decode", "filter_ctc_output", "AMTForward",
            "SongTranscriber", "utterance_bounds", "save_song_features", "feature_path"]

@@ -105,6 +105,8 @@ SYMBOLS = {
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_debug_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "svt_frames_to_notes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "svt_debug_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
     "svt_debug_free": (C.c_int, [C.c_void_p, C.c_int]),
     "svt_prof_enable": (C.c_int, [C.c_int]),

@@ -10,7 +10,7 @@ from typing import List, Optional
 
 import torch
 
-from .decode import decode_frames, frame2note, frames_to_info, frames2note
+from .decode import decode_frames, frame2note, frames_to_info, frames2note, frames2note_batch
 
 
 class AMTForward:
@@ -63,5 +63,5 @@ class AMTForward:
     def transcribe_batch(self, logits: torch.Tensor) -> List[List[list]]:
         """Throughput path: every clip of a batch is its own song (one kernel + one D2H for the batch)."""
         frames = decode_frames(logits, self.pitch_octave_num, self.pitch_class_num)
-        return [frames2note(frames[b], self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
-                for b in range(frames.shape[0])]
+        return frames2note_batch(frames, self.onset_threshold, self.offset_threshold, 1 / self.frame_rate,
+                                 pitch_octave_num=self.pitch_octave_num, pitch_class_num=self.pitch_class_num)

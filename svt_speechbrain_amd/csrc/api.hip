@@ -1279,6 +1279,75 @@ int svt_decode_frames(const float* logits, int64_t rows, int32_t n_out, int32_t 
   return launch_decode_frames(logits, rows, n_out, n_octave, n_class, (FrameOut*)frames, (hipStream_t)stream);
 }
 
+// frame2note (reference MIR_ST500/utils.py:82-149) over a batch of decoded frame sequences, on the HOST (no device call).
+// Same scan as the reference's loop: float32 comparisons against the thresholds, onset = above threshold AND equal to the
+// maximum of onset[i-3 : min(i+4, N-1)] (the last frame is never inside a window), times = frame_size * i in double.
+// The pitch of a note is the mode of its bag; where the top count is tied the reference's answer depends on CPython's set
+// iteration order, so the note is returned with pitch = -1 and its frame range [lo, hi) and the caller resolves it.
+int svt_frames_to_notes(const svt_frame* frames, int32_t batch, int64_t frames_per_clip, const int64_t* n_frames,
+                        float onset_thres, float offset_thres, double frame_size, int32_t n_octave, int32_t n_class,
+                        double* t_on, double* t_off, int32_t* pitch, int32_t* lo, int32_t* hi, int64_t capacity_per_clip,
+                        int64_t* n_notes) {
+  if (!frames || !t_on || !t_off || !pitch || !lo || !hi || !n_notes || batch < 0 || frames_per_clip < 0) {
+    set_error("svt_frames_to_notes: bad argument"); return SVT_ERR_INVALID; }
+  if (n_octave < 1 || n_class < 1 || (long)n_octave * n_class + n_class > 4096) { set_error("svt_frames_to_notes: bad class counts"); return SVT_ERR_INVALID; }
+  std::vector<int> counts((size_t)n_octave * n_class + n_class + 1);
+  for (int32_t b = 0; b < batch; ++b) {
+    const svt_frame* f = frames + (int64_t)b * frames_per_clip;
+    const int64_t n = n_frames ? n_frames[b] : frames_per_clip;
+    if (n < 0 || n > frames_per_clip) { set_error("svt_frames_to_notes: n_frames out of range"); return SVT_ERR_INVALID; }
+    int64_t k = 0;
+    const int64_t base = (int64_t)b * capacity_per_clip;
+    bool open = false;
+    int64_t on_i = 0, bag_n = 0;
+    auto emit = [&](int64_t close_frame, int64_t hi_frame) -> int {   // the open note [on_i, hi_frame) closes at time frame_size * close_frame
+      if (k >= capacity_per_clip) { set_error("svt_frames_to_notes: more notes than capacity_per_clip"); return SVT_ERR_INVALID; }
+      int top = 0, arg = 0, ties = 0;
+      for (size_t v = 0; v < counts.size(); ++v) {
+        if (counts[v] > top) { top = counts[v]; arg = (int)v; ties = 1; }
+        else if (counts[v] == top && top > 0) ++ties;
+      }
+      t_on[base + k] = frame_size * (double)on_i;
+      t_off[base + k] = frame_size * (double)close_frame;
+      pitch[base + k] = ties > 1 ? -1 : arg + 36;
+      lo[base + k] = (int32_t)on_i;
+      hi[base + k] = (int32_t)hi_frame;
+      ++k;
+      return 0;
+    };
+    for (int64_t i = 0; i < n; ++i) {
+      const float p_on = f[i].p_on;
+      bool is_on = false;
+      if (p_on >= onset_thres) {
+        const int64_t w0 = i - 3 > 0 ? i - 3 : 0, w1 = i + 4 < n - 1 ? i + 4 : n - 1;
+        if (w1 <= w0) { set_error("frame2note: max() of an empty onset window (a one-frame sequence above the onset threshold), as in the reference"); return SVT_ERR_INVALID; }
+        float m = f[w0].p_on;
+        for (int64_t j = w0 + 1; j < w1; ++j) m = f[j].p_on > m ? f[j].p_on : m;
+        is_on = p_on == m;
+      }
+      if (is_on) {
+        if (open && bag_n) { if (int r = emit(i, i)) return r; }
+        open = true; on_i = i; bag_n = 0;
+        std::fill(counts.begin(), counts.end(), 0);
+      } else if (f[i].p_off >= offset_thres) {
+        if (open) {
+          if (bag_n) { if (int r = emit(i, i)) return r; }
+          open = false; bag_n = 0;
+        }
+      }
+      if (open && f[i].octave != n_octave && f[i].pitch_class != n_class) {
+        const long v = (long)f[i].octave * n_class + f[i].pitch_class;
+        if (v < 0 || v >= (long)counts.size()) { set_error("svt_frames_to_notes: frame class out of range"); return SVT_ERR_INVALID; }
+        ++counts[v];
+        ++bag_n;
+      }
+    }
+    if (open && bag_n) { if (int r = emit(n - 1, n)) return r; }
+    n_notes[b] = k;
+  }
+  return SVT_OK;
+}
+
 }  // extern "C"
 
 // =================================================================================================

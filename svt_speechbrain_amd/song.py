@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from .decode import decode_frames, frame2note, frames2note, frames_to_info
+from .decode import decode_frames, frame2note, frames2note, frames2note_batch, frames_to_info
 
 
 def utterance_bounds(n_samples: int, sample_rate: int = 16000, dur_threshold: float = 5.0) -> List[Tuple[int, int]]:
@@ -104,7 +104,8 @@ class SongTranscriber:
         for st in lanes[1:]:
             main.wait_stream(st)
         frames = decode_frames(torch.cat(logits_all, dim=0), self.pitch_octave_num, self.pitch_class_num)
-        notes = frames2note(frames, self.onset_threshold, self.offset_threshold, 1 / self.frame_rate)
+        notes = frames2note_batch(frames, self.onset_threshold, self.offset_threshold, 1 / self.frame_rate,
+                                  pitch_octave_num=self.pitch_octave_num, pitch_class_num=self.pitch_class_num)[0]
         if return_feats:
             return notes, torch.cat(feats_all, dim=0)
         return notes

@@ -117,7 +117,7 @@ def check_guarded(run, what):
 PRECISIONS = ("fp32", "fp16x3", "bf16x3", "bf16")
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SVT_GUARD_CASES", "24")))))
 def test_encoder_random_geometries_stay_in_bounds(seed):
     cfg, B, L = random_case(1000 + seed)
     g = torch.Generator().manual_seed(seed)

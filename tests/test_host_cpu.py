@@ -1,6 +1,7 @@
 """CPU tests (-m "not gpu"): host logic, state-dict schema, C-ABI symbol export, loud failure without a GPU."""
 import ctypes
 import os
+import time
 import re
 
 import numpy as np
@@ -401,6 +402,63 @@ def test_frames2note_equals_the_frame_loop(golden):
         frames2note(one, 0.4, 0.5)
     assert frames2note(pack(np.float32([0.1]), np.float32([0.1]), [1], [1]), 0.4, 0.5) == []
     assert frames2note(pack([], [], [], []), 0.4, 0.5) == []
+
+
+def test_frames2note_batch_c_routine_equals_the_frame_loop(golden):
+    """svt_frames_to_notes (the library's host routine, one call per batch) against the literal frame loop: the reference's golden
+    cases, random batches with plateaus / exact-threshold values / pitch ties (resolved by the reference's own expression), ragged
+    lengths, and the reference's ValueError for a one-frame sequence above the onset threshold."""
+    from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note_batch
+
+    def pack(p_on, p_off, octv, pc):
+        fr = np.zeros(len(p_on), dtype=FRAME_DTYPE)
+        fr["p_on"], fr["p_off"], fr["octave"], fr["pitch_class"] = p_on, p_off, octv, pc
+        return fr
+
+    for k, c in golden("frame2note").items():
+        fr = pack(c["p_on"].numpy(), c["p_off"].numpy(), c["oct"].numpy(), c["pc"].numpy())
+        assert frames2note_batch(fr, 0.4, 0.5, 1 / 49.8) == [c["notes"]], k
+    rng = np.random.default_rng(11)
+    grid = np.array([0.0, 0.1, 0.4, 0.5, 0.7, 0.7, 0.9, 1.0], dtype=np.float32)
+    ties = 0
+    for trial in range(40):
+        B, T = int(rng.integers(1, 9)), int(rng.integers(2, 600))
+        fr = np.zeros((B, T), dtype=FRAME_DTYPE)
+        fr["p_on"] = grid[rng.integers(0, len(grid), (B, T))] * (rng.random((B, T)) < 0.3)
+        fr["p_off"] = grid[rng.integers(0, len(grid), (B, T))] * (rng.random((B, T)) < 0.2)
+        if trial % 2:
+            fr["octave"] = np.repeat(rng.integers(0, 5, (B, T // 7 + 1)), 7, axis=1)[:, :T]
+            fr["pitch_class"] = np.repeat(rng.integers(0, 13, (B, T // 3 + 1)), 3, axis=1)[:, :T]
+        else:
+            fr["octave"] = rng.integers(0, 5, (B, T))
+            fr["pitch_class"] = rng.integers(0, 13, (B, T))
+        lengths = rng.integers(2, T + 1, B) if trial % 3 == 0 else None
+        got = frames2note_batch(fr, 0.4, 0.5, 1 / 49.8, lengths=lengths)
+        for b in range(B):
+            n = T if lengths is None else int(lengths[b])
+            want = S.frame2note(S.frames_to_info(fr[b, :n]), 0.4, 0.5, 1 / 49.8)
+            assert got[b] == want, (trial, b)
+            for note in want:
+                lo_f, hi_f = round(note[0] * 49.8), round(note[1] * 49.8)
+                seg = fr[b, lo_f:max(hi_f, lo_f + 1)]
+                bag = [int(o) * 12 + int(p) for o, p in zip(seg["octave"], seg["pitch_class"]) if o != 4 and p != 12]
+                ties += len(bag) > 0 and sorted(bag.count(v) for v in set(bag))[-2:].count(max(bag.count(v) for v in set(bag))) > 1
+    assert ties > 20, "the random cases must exercise tied pitch histograms"
+    one = pack(np.float32([0.9]), np.float32([0.1]), [1], [1])
+    with pytest.raises(ValueError):
+        frames2note_batch(one, 0.4, 0.5)
+    assert frames2note_batch(pack(np.float32([0.1]), np.float32([0.1]), [1], [1]), 0.4, 0.5) == [[]]
+    assert frames2note_batch(np.zeros((3, 0), dtype=FRAME_DTYPE), 0.4, 0.5) == [[], [], []]
+    assert frames2note_batch(np.zeros((0, 5), dtype=FRAME_DTYPE), 0.4, 0.5) == []
+    t0 = time.time()
+    big = np.zeros((32, 499), dtype=FRAME_DTYPE)
+    big["p_on"] = rng.random((32, 499)).astype(np.float32)
+    big["p_off"] = rng.random((32, 499)).astype(np.float32)
+    big["octave"] = rng.integers(0, 5, (32, 499))
+    big["pitch_class"] = rng.integers(0, 13, (32, 499))
+    for _ in range(10):
+        frames2note_batch(big, 0.4, 0.5, 1 / 49.8)
+    print(f"32 x 499 frames: {1e2 * (time.time() - t0):.2f} ms per batch")
 
 
 def test_plain_c_caller_of_the_cabi_compiles(tmp_path):
