@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--gather", default="logits", choices=["logits", "frames"],
                     help="N > 1: all-gather the fp32 logits (80 B per frame, the north star's collective) or the compact decoded "
                          "frames (16 B per frame, SURVEY.md §8e)")
+    ap.add_argument("--global-norm", action="store_true", help="N > 1: the wrapper's two whole-batch layer norms over the GLOBAL batch (two "
+                    "16-byte all-reduces per step, svt_encoder_set_norm_reduce) instead of per rank; default off = what the reference's "
+                    "DataParallel / DDP runs compute")
     ap.add_argument("--separate-tail", action="store_true", help="A/B: output norm, head and decode as separate kernels over the "
                     "materialised features instead of the fused tail (svt_encoder_forward_head)")
     ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
@@ -172,6 +175,9 @@ def main():
     ns = max(1, args.streams)
     enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, normalize_wav=True, seed=1986).to(dev)
     encs = [enc] + [enc.replica() for _ in range(ns - 1)]  # same parameters, own device handle + workspace per stream
+    if args.global_norm and world > 1:
+        for e_ in encs:
+            e_.set_global_batch_norm(n_total)
     head = S.Linear(20, input_size=cfg.hidden_size)
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=2986)
     head.load_state_dict(hd)
@@ -343,7 +349,8 @@ def main():
             "rccl_ranks": res["ranks"],
             "collective": None if world == 1 else {"op": "all_gather_into_tensor", "payload": args.gather,
                                                    "bytes_per_rank_per_step": gatherers[0].bytes_per_rank(),
-                                                   "backend": torch.distributed.get_backend()},
+                                                   "backend": torch.distributed.get_backend(),
+                                                   "norm_all_reduce": "2 x 16 B per step (global-batch norms)" if args.global_norm else None},
             "per_rank_clips_per_s": [round(B * args.steps / t, 3) for t in res["elapsed_per_rank"]],
             "roofline": {"bound": "mfma",
                          "kernel": ("svt::gemm_kernel<float, 128, 128, SPLIT> (register-staged, fp32 operands cut into 16-bit (hi, lo) pieces on "

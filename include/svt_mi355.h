@@ -108,6 +108,17 @@ int svt_device_count(void);
 /* ---- encoder: replaces HuggingFaceWav2Vec2 (huggingface_interface.py:47-297) + the HF model it wraps ---- */
 int svt_encoder_create(const svt_encoder_config* cfg, int device, svt_encoder** out);
 void svt_encoder_destroy(svt_encoder* e);
+
+/* Optional "global-batch-equivalent" norms for a batch that is ONE SHARD of a larger one (the reference's
+ * wrapper normalises over every element of the batch it is given: huggingface_interface.py:289-295).  With a function set, every
+ * forward of this encoder calls it twice, in stream order on the forward's stream -- after the waveform moments and after the
+ * moments of the encoder output -- with a DEVICE pointer to the (sum, sum of squares) pair in double precision; the function must
+ * replace the pair by its sum over all ranks (an all-reduce of 16 bytes: dist.all_reduce on a tensor wrapping the pointer, or
+ * ncclAllReduce on `stream`) and return 0.  The statistics are then taken over global_clips clips (the clip count of the whole
+ * global batch, equal lengths), and N shards return what one device returns for the whole batch.  Whole-batch norms only
+ * (clips_per_norm_group = 0).  fn = NULL restores the per-shard norms, which is what the reference's DataParallel / DDP runs do. */
+typedef int (*svt_norm_reduce_fn)(double* sums_dev, int32_t n_doubles, void* stream, void* user);
+int svt_encoder_set_norm_reduce(svt_encoder* enc, svt_norm_reduce_fn fn, void* user, int64_t global_clips);
 /* copy one parameter by its HF state-dict key (without the wrapper's "model." prefix); both weight-norm
  * spellings of the positional conv are accepted (…conv.weight_g/_v and …parametrizations.weight.original0/1).
  * replaces: Module.load_state_dict (speechbrain/utils/checkpoints.py:69-95, train_audio_ssl.py:232-234) */

@@ -54,6 +54,9 @@ class FrameC(C.Structure):
 # every symbol include/svt_mi355.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I64P = C.POINTER(C.c_int64)
+# svt_norm_reduce_fn (include/svt_mi355.h): int fn(double* sums_dev, int32_t n_doubles, void* stream, void* user)
+NORM_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+
 SYMBOLS = {
     "svt_last_error": (C.c_char_p, []),
     "svt_abi_version": (C.c_int, []),
@@ -105,6 +108,7 @@ SYMBOLS = {
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_debug_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "svt_encoder_set_norm_reduce": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int64]),
     "svt_frames_to_notes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "svt_debug_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),

@@ -340,6 +340,10 @@ struct svt_encoder {
   DevBuf rel_embed;                     // WavLM: (buckets, H) relative position embedding of layer 0
   DevBuf ones, zeros;                   // LayerNorm without affine parameters
   std::vector<EncLayerW> layers;
+  // optional cross-rank reduction of the wrapper's two whole-batch norm statistics (svt_encoder_set_norm_reduce)
+  svt_norm_reduce_fn reduce_fn = nullptr;
+  void* reduce_user = nullptr;
+  int64_t reduce_global_clips = 0;
 };
 
 struct svt_linear {
@@ -548,6 +552,15 @@ void svt_encoder_destroy(svt_encoder* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   delete e;
+}
+
+int svt_encoder_set_norm_reduce(svt_encoder* e, svt_norm_reduce_fn fn, void* user, int64_t global_clips) {
+  if (!e) { set_error("svt_encoder_set_norm_reduce: null encoder"); return SVT_ERR_INVALID; }
+  if (fn && global_clips < 1) { set_error("svt_encoder_set_norm_reduce: global_clips must be the clip count of the whole global batch"); return SVT_ERR_INVALID; }
+  e->reduce_fn = fn;
+  e->reduce_user = user;
+  e->reduce_global_clips = fn ? global_clips : 0;
+  return SVT_OK;
 }
 
 int svt_encoder_load_param(svt_encoder* e, const char* key, const void* data_host, int dtype, const int64_t* shape,
@@ -955,9 +968,27 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   double* wav_mom = c.normalize_wav ? w.mom : nullptr;
   double* out_mom = w.mom + 2 * (size_t)B;
   double* wm = w.mom + 4 * (size_t)B;
-  const int64_t n_wav = (int64_t)cpg * L;
+  int64_t n_wav = (int64_t)cpg * L;
   if (c.normalize_wav)
     if (int r = launch_moments(wav, n_wav, wav_mom, s, groups)) return r;
+  // "global-batch-equivalent" norms (optional): the batch is a shard of a larger one; the caller's function sums the
+  // (sum, sum of squares) pair over the ranks -- 16 bytes per norm -- and the statistics are then those of the whole global batch
+  struct ReduceCtx { svt_encoder* e; double* mom; hipStream_t s; } rctx{e, nullptr, s};
+  auto reduce_now = [](void* a) -> int {
+    ReduceCtx* rc = (ReduceCtx*)a;
+    if (rc->e->reduce_fn(rc->mom, 2, (void*)rc->s, rc->e->reduce_user)) { set_error("encoder_forward: the norm-reduce callback reported an error"); return SVT_ERR_INVALID; }
+    return 0;
+  };
+  const bool global_norm = e->reduce_fn != nullptr;
+  if (global_norm) {
+    if (groups != 1) { set_error("encoder_forward: the cross-rank norm reduction applies to whole-batch norms (clips_per_norm_group = 0)"); return SVT_ERR_INVALID; }
+    if (e->reduce_global_clips < B) { set_error("encoder_forward: global_clips of the norm reduction is smaller than this batch"); return SVT_ERR_INVALID; }
+    if (c.normalize_wav) {
+      rctx.mom = wav_mom;
+      if (int r = reduce_now(&rctx)) return r;
+      n_wav = e->reduce_global_clips * L;
+    }
+  }
 
   // ---- conv feature extractor (channels-last activations) ----
   int64_t tin = L;
@@ -1198,17 +1229,20 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   }
   // ---- wrapper's whole-batch output LayerNorm (+ frame head + decode when a head was given) ----
   const int64_t n_out = rows * D;
+  const double n_out_stat = global_norm ? (double)e->reduce_global_clips * (double)(rows / B) * (double)D : 0.0;
+  rctx.mom = out_mom;
   if (tail.head) {
     static_assert(sizeof(svt_frame) == sizeof(FrameOut), "frame layout");
     if (launch_head_fused(final_x, rows, D, tail.head->w.as<float>(), tail.head->wsum.as<float>(),
                           tail.head->has_bias ? tail.head->b.as<float>() : nullptr, tail.head->out_f, w.dots,
                           c.output_norm ? out_mom : nullptr, rows / groups, 1e-5f, tail.logits, (FrameOut*)tail.frames, tail.n_oct,
-                          tail.n_cls, s)) return SVT_ERR_HIP;
+                          tail.n_cls, s, n_out_stat, global_norm && c.output_norm ? +reduce_now : nullptr, &rctx)) return SVT_ERR_HIP;
     return SVT_OK;
   }
   if (c.output_norm) {
     if (int r = launch_moments(final_x, n_out / groups, out_mom, s, groups)) return r;
-    if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups)) return r;
+    if (global_norm) { if (int r = reduce_now(&rctx)) return r; }
+    if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups, n_out_stat)) return r;
   } else {
     SVT_HIP(hipMemcpyAsync(feats, final_x, (size_t)n_out * 4, hipMemcpyDeviceToDevice, s));
   }

@@ -190,7 +190,8 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // moments[0] += sum(x), moments[1] += sum(x^2) over n fp32 values (fp64 accumulation); caller zeroes moments
 int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
 // y = (x - mean) * rsqrt(var + eps) from global moments over n elements (no affine)
-int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups = 1);
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups = 1,
+                       double n_stat = 0);  // n_stat > 0: the moments were summed over n_stat elements (cross-rank reduction), not n
 
 // row LayerNorm over D: in fp32 or operand type; outputs: yT (operand type, may be null) and yF (fp32, may be null)
 // optional `add` (fp32, same shape) is summed into x before the statistics (residual add fused into the norm);
@@ -286,7 +287,8 @@ struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };
 // UN-normalised encoder output x (rows x K); dots = rows x N scratch; mom = 2 doubles per norm group (zeroed) or null
 int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
                       double* mom, int64_t rows_per_group, float eps, float* logits, FrameOut* frames, int n_oct, int n_cls,
-                      hipStream_t s);
+                      hipStream_t s,
+                      double n_stat = 0, int (*between)(void*) = nullptr, void* between_arg = nullptr);
 int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
                          hipStream_t s);
 int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,

@@ -67,12 +67,12 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n,
   }
 }
 
-__global__ void global_norm_kernel(const float* x, float* y, int64_t n, const double* mom, float eps) {
+__global__ void global_norm_kernel(const float* x, float* y, int64_t n, const double* mom, float eps, double n_stat) {
   x += (int64_t)blockIdx.y * n;
   y += (int64_t)blockIdx.y * n;
   mom += 2 * blockIdx.y;
-  const double mean = mom[0] / (double)n;
-  const double var = mom[1] / (double)n - mean * mean;
+  const double mean = mom[0] / n_stat;   // n_stat: the elements the moments were summed over (= n, or the global count when
+  const double var = mom[1] / n_stat - mean * mean;   // the sums were reduced over ranks: svt_encoder_set_norm_reduce)
   const float mu = (float)mean;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
   const int64_t n4 = n >> 2;
@@ -1223,9 +1223,10 @@ int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, in
   return 0;
 }
 
-int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups) {
+int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups, double n_stat) {
   if (groups > 1 && (n & 3)) { set_error("global_norm: per-group length must be a multiple of 4 elements"); return -1; }
-  hipLaunchKernelGGL(global_norm_kernel, dim3(grid_for(n / 4 + 1), groups), dim3(256), 0, s, x, y, n, moments, eps);
+  hipLaunchKernelGGL(global_norm_kernel, dim3(grid_for(n / 4 + 1), groups), dim3(256), 0, s, x, y, n, moments, eps,
+                     n_stat > 0 ? n_stat : (double)n);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -1486,15 +1487,16 @@ static int launch_head_dots_kc(const float* x, int64_t rows, const float* w, int
 }
 int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
                       double* mom /*2 per group, zeroed; null = no output norm*/, int64_t rows_per_group, float eps, float* logits,
-                      FrameOut* frames, int n_oct, int n_cls, hipStream_t s) {
+                      FrameOut* frames, int n_oct, int n_cls, hipStream_t s, double n_stat, int (*between)(void*), void* between_arg) {
   if (!linear_head_eligible(K, N)) { set_error("head_fused: unsupported head geometry"); return -1; }
   if (frames && (N != 2 + n_oct + 1 + n_cls + 1 || N > 32)) { set_error("head_fused: n_out != 2 + (n_octave+1) + (n_class+1)"); return -1; }
   int r = K == 512 ? launch_head_dots_kc<2>(x, rows, w, N, dots, mom, rows_per_group, s)
         : K == 768 ? launch_head_dots_kc<3>(x, rows, w, N, dots, mom, rows_per_group, s)
                    : launch_head_dots_kc<4>(x, rows, w, N, dots, mom, rows_per_group, s);
   if (r) return r;
+  if (between) { if (int rb = between(between_arg)) return rb; }   // the moments are complete here: cross-rank reduction hook
   hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, dots, rows, N, wsum, b, mom,
-                     rows_per_group, (double)rows_per_group * (double)K, eps, logits, frames, n_oct, n_cls);
+                     rows_per_group, n_stat > 0 ? n_stat : (double)rows_per_group * (double)K, eps, logits, frames, n_oct, n_cls);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -115,6 +115,13 @@ def _config_from_dir(path: str) -> Optional[EncoderConfig]:
         conv_pos_batch_norm=bool(j.get("conv_pos_batch_norm", False)) and fam == "hubert", **kw)
 
 
+class _DevF64:
+    """A device pointer to ``n`` doubles as a ``__cuda_array_interface__`` object (``torch.as_tensor`` wraps it without a copy)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class HuggingFaceWav2Vec2(nn.Module):
     """wav2vec 2.0 / HuBERT encoder on MI355X with the reference wrapper's surface.
 
@@ -397,6 +404,45 @@ class HuggingFaceWav2Vec2(nn.Module):
     def num_frames(self, n_samples: int) -> int:
         return self.config.frames(n_samples)
 
+    # ------------------------------------------------------------------ "global-batch-equivalent" norms
+    def set_norm_reduce(self, fn, global_clips: int = 0) -> None:
+        """Make the wrapper's two whole-batch layer norms (reference ``huggingface_interface.py:289-295``) those of a LARGER batch
+        this object only sees a shard of.  ``fn(sums)`` receives a 2-element float64 CUDA tensor -- (sum, sum of squares) of the
+        local shard, first of the waveform, then of the encoder output -- and must add the other shards' pairs in place
+        (``torch.distributed.all_reduce``); it runs inside the forward, in stream order on the current stream.  ``global_clips`` is
+        the clip count of the whole batch (equal lengths).  ``fn=None`` restores per-shard norms, which is what the reference's own
+        multi-GPU modes compute.  ``set_global_batch_norm`` is the ``torch.distributed`` form."""
+        if fn is None:
+            self._norm_reduce = None
+            return
+        if int(global_clips) < 1:
+            raise ValueError("set_norm_reduce: global_clips = the number of clips of the whole global batch")
+
+        def cb(ptr, n, stream, user):
+            try:
+                t = torch.as_tensor(_DevF64(ptr, n), device=torch.device("cuda", torch.cuda.current_device()))
+                fn(t)
+                return 0
+            except Exception:   # the C side turns a non-zero return into an error of the forward call
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._norm_reduce = (_lib.NORM_REDUCE_FN(cb), int(global_clips))
+
+    def set_global_batch_norm(self, global_clips: int, group=None) -> None:
+        """``set_norm_reduce`` with ``torch.distributed.all_reduce`` (RCCL: two 16-byte all-reduces per forward): N ranks holding
+        contiguous shards of one global batch return what a single device returns for the whole batch."""
+        import torch.distributed as dist
+        self.set_norm_reduce(lambda t: dist.all_reduce(t, group=group), global_clips)
+
+    def _apply_norm_reduce(self, lib, handle) -> None:
+        nr = getattr(self, "_norm_reduce", None)
+        if nr is None:
+            _lib.check(lib.svt_encoder_set_norm_reduce(handle, None, None, 0), "svt_encoder_set_norm_reduce")
+        else:
+            _lib.check(lib.svt_encoder_set_norm_reduce(handle, C.cast(nr[0], C.c_void_p), None, nr[1]), "svt_encoder_set_norm_reduce")
+
     # ------------------------------------------------------------------ forward (reference :263-297)
     def forward(self, wav: torch.Tensor, clips_per_norm_group: int = 0) -> torch.Tensor:
         """``clips_per_norm_group`` (extension; 0 = the reference: both whole-tensor layer norms over the entire batch):
@@ -435,6 +481,7 @@ class HuggingFaceWav2Vec2(nn.Module):
         logits = torch.empty((B, T, n_out), dtype=torch.float32, device=x.device)
         if frames is not None and (frames.dtype != torch.int32 or frames.numel() != B * T * 4 or not frames.is_contiguous()):
             raise ValueError("frames must be a contiguous int32 tensor of B*T*4 elements (16 bytes per frame)")
+        self._apply_norm_reduce(lib, slot.handle)
         with torch.no_grad():
             _lib.check(lib.svt_encoder_forward_head(slot.handle, hslot.handle, _lib.ptr(x), B, L, _lib.ptr(logits),
                                                     _lib.ptr(frames) if frames is not None else None, int(pitch_octave_num),
@@ -466,6 +513,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise _lib.SvtError(_lib.last_error())
         ws = slot.workspace(need, x.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=x.device)
+        self._apply_norm_reduce(lib, slot.handle)
         _lib.check(lib.svt_encoder_forward_ex(slot.handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(ws),
                                               ws.numel(), _lib.stream_ptr(x.device), int(clips_per_norm_group)),
                    "svt_encoder_forward")

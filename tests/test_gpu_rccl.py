@@ -42,6 +42,18 @@ assert g.tolist() == [1.25]
 dist.barrier()
 # the package's helpers at world 1 (no collective) still agree
 assert D.gather_floats(2.5, 1, dev) == [2.5] and D.max_over_ranks(3.0, 1, dev) == 3.0
+# the optional global-batch norms through RCCL: with one rank the two 16-byte all-reduces are identities
+import svt_speechbrain_amd as S
+cfg = S.PRESETS["tiny-group"]
+enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, normalize_wav=True, precision="fp32", seed=1).to(dev)
+wav = 0.1 * torch.randn(3, 4000, device=dev)
+want = enc(wav)
+enc.set_global_batch_norm(3)
+with torch.cuda.stream(side):
+    side.wait_stream(torch.cuda.current_stream())
+    got = enc(wav)
+torch.cuda.synchronize()
+assert torch.equal(got, want)
 dist.destroy_process_group()
 print("RCCL_OK")
 """
