@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--global-norm", action="store_true", help="N > 1: the wrapper's two whole-batch layer norms over the GLOBAL batch (two "
                     "16-byte all-reduces per step, svt_encoder_set_norm_reduce) instead of per rank; default off = what the reference's "
                     "DataParallel / DDP runs compute")
+    ap.add_argument("--verify", action="store_true", help="after the timed region every rank recomputes ALL shards locally (the clips are "
+                    "seeded by their global index) and compares them with what the last step gathered: \"verified\" in the JSON line")
     ap.add_argument("--separate-tail", action="store_true", help="A/B: output norm, head and decode as separate kernels over the "
                     "materialised features instead of the fused tail (svt_encoder_forward_head)")
     ap.add_argument("--h2d", action="store_true", help="diagnostic: every step first copies its batch from pinned host memory "
@@ -148,8 +150,12 @@ def main():
     from svt_speechbrain_amd import weights as W
     from svt_speechbrain_amd.decode import FRAME_DTYPE, frames2note_batch
 
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))  # before the process group: RCCL binds to it
+    # SVT_SHARE_GPU=1 (test mode, with SVT_DIST_BACKEND=gloo): every rank uses device 0 -- the N > 1 control flow on a one-GPU box
+    share_gpu = os.environ.get("SVT_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0")))  # before the process group: RCCL binds to it
     rank, local, world = D.init_from_env()
+    if share_gpu:
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{local}")
@@ -228,6 +234,38 @@ def main():
     # a step is >= ~110 kernels: anything faster than this did not run the work
     if 1e3 * elapsed / args.steps < 0.05:
         raise SystemExit("[bench] implausible step time: the timed region did not execute the step")
+
+    verified = None
+    if args.verify:
+        # every rank rebuilds the whole global batch from the per-clip seeds and computes it shard by shard with the norms the run
+        # used (per shard, or -- with --global-norm -- over the whole batch in ONE forward), then compares with the gathered rows
+        torch.cuda.synchronize()
+        gathered = out.clone()
+        for e_ in encs:
+            e_.set_norm_reduce(None)
+        full = torch.cat([synth_wav(1, L, seed=1986 + i) for i in range(n_total)]).to(dev) if world > 1 else wav
+        fr_all = torch.empty((n_total, T, 4), dtype=torch.int32, device=dev)
+        if args.global_norm or world == 1:
+            lg_all = enc.forward_head(full, head, frames=fr_all)
+        else:
+            parts = []
+            for r_ in range(world):
+                a_, b_ = D.shard_bounds(n_total, r_, world)
+                parts.append(enc.forward_head(full[a_:b_], head, frames=fr_all[a_:b_].view(-1, 4)))
+            lg_all = torch.cat(parts)
+        ref_rows = fr_all if gather_frames else lg_all
+        if gather_frames:
+            verified = bool(torch.equal(gathered.view(torch.int32).reshape(ref_rows.shape), ref_rows))
+        else:
+            # per-shard norms: the same kernels on the same shard -> identical; global norms: one forward of the whole batch against
+            # shards with reduced statistics -> identical in the exact modes (tests/test_gpu_global_norm.py), bf16 rounds differently
+            tol = 0.0 if not (args.global_norm and world > 1) else (1e-5 if args.precision != "bf16" else 0.5)
+            verified = bool((gathered - ref_rows).abs().max().item() <= tol)
+        flags = D.gather_floats(1.0 if verified else 0.0, world, dev)
+        verified = all(f == 1.0 for f in flags)
+        if args.global_norm and world > 1:
+            for e_ in encs:
+                e_.set_global_batch_norm(n_total)
 
     def prof(kind):
         n, ms_, fl_, by_ = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
@@ -347,6 +385,7 @@ def main():
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates
             "rccl_ranks": res["ranks"],
+            "verified": verified,
             "collective": None if world == 1 else {"op": "all_gather_into_tensor", "payload": args.gather,
                                                    "bytes_per_rank_per_step": gatherers[0].bytes_per_rank(),
                                                    "backend": torch.distributed.get_backend(),

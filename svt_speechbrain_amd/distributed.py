@@ -27,8 +27,8 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # SVT_DIST_BACKEND=gloo: test mode for one-GPU boxes (collectives staged through the host, see _gather_into)
+            backend = os.environ.get("SVT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -38,6 +38,21 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _host_staged() -> bool:
+    """gloo has no all-gather for device tensors: with it (CPU tests, or several ranks sharing ONE GPU in the GPU test of the
+    N > 1 control flow) device tensors go through the host.  RCCL (`nccl`) takes the device tensors as they are."""
+    return dist.get_backend() == "gloo"
+
+
+def _gather_into(out: torch.Tensor, inp: torch.Tensor) -> None:
+    if inp.is_cuda and _host_staged():
+        tmp = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(tmp, inp.cpu())
+        out.copy_(tmp)
+    else:
+        dist.all_gather_into_tensor(out, inp)
 
 
 class RowGatherer:
@@ -77,10 +92,10 @@ class RowGatherer:
         if tuple(local.shape) != (self.hi - self.lo,) + self.row_shape:
             raise ValueError(f"rank {self.rank}: expected a {(self.hi - self.lo,) + self.row_shape} shard, got {tuple(local.shape)}")
         if self.even:
-            dist.all_gather_into_tensor(self.out, local.contiguous())
+            _gather_into(self.out, local.contiguous())
             return self.out
         self.pad[: local.shape[0]].copy_(local)
-        dist.all_gather_into_tensor(self.raw, self.pad)
+        _gather_into(self.raw, self.pad)
         torch.index_select(self.raw, 0, self.idx, out=self.out)
         return self.out
 
@@ -96,7 +111,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int) -> torch.Tens
 def max_over_ranks(value: float, world: int, device) -> float:
     if world == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -105,8 +120,9 @@ def gather_floats(value: float, world: int, device) -> List[float]:
     """value of every rank, in rank order, on every rank."""
     if world == 1:
         return [float(value)]
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    out = torch.empty(world, dtype=torch.float64, device=device)
+    dev = "cpu" if _host_staged() else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = torch.empty(world, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(out, t)
     return [float(v) for v in out.tolist()]
 

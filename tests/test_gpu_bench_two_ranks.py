@@ -1,0 +1,47 @@
+"""bench.py's own N > 1 control flow on a one-GPU box: two ranks launched exactly like the driver launches them
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2`), both on device 0
+(SVT_SHARE_GPU=1) with the collectives on gloo, staged through the host (SVT_DIST_BACKEND=gloo; RCCL refuses two ranks on one
+device).  Everything else is the real path: per-rank clip seeding, shard bounds, the lanes / streams, one gather per step from the
+step's stream, max over ranks, per-rank rates, the JSON line -- and `--verify`: every rank recomputes all shards locally and
+compares them with the rows the last step gathered.  Second case: compact-frames gather + the optional global-batch norms, whose
+two 16-byte all-reduces then really cross a process boundary, verified against ONE forward of the whole global batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(port, *extra):
+    env = dict(os.environ, SVT_SHARE_GPU="1", SVT_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3",
+           "--seconds", "2", "--no-cpu-baseline", "--no-extra-legs", "--verify", *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_two_ranks_logits_gather():
+    j = launch(29541)
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == "weak" and j["verified"] is True
+    assert len(j["per_rank_clips_per_s"]) == 2 and j["config"]["global_batch"] == 6 and j["config"]["per_gpu_batch"] == 3
+    c = j["collective"]
+    assert c["op"] == "all_gather_into_tensor" and c["payload"] == "logits" and c["backend"] == "gloo"
+    assert c["bytes_per_rank_per_step"] == 3 * 99 * 20 * 4          # 3 clips x 99 frames (2 s) x 20 logits, fp32
+    assert j["value"] > 0 and j["steps"] == 3 and j["warmup"] == 1
+
+
+def test_two_ranks_frames_gather_with_global_norms():
+    j = launch(29542, "--gather", "frames", "--global-norm", "--precision", "fp32")
+    assert j["verified"] is True and j["rccl_ranks"] == 2
+    c = j["collective"]
+    assert c["payload"] == "frames" and c["bytes_per_rank_per_step"] == 3 * 99 * 16 and c["norm_all_reduce"]
