@@ -44,7 +44,7 @@ import torch  # noqa: E402
 
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 
@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--model", default="wav2vec2-base")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained and notes-out legs (profiling runs)")
     ap.add_argument("--sustain-seconds", type=float, default=3.2)
@@ -159,7 +159,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{local}")
-    lib = _lib.load()
+    lib = _lib.load("f16" if args.precision == "fp16" else None)   # the build the encoder lives in: its profiling hooks are per library
     _lib.require_gpu()
     for kv in os.environ.get("SVT_DEBUG_SET", "").split(","):  # diagnostics: "key=value,..." -> svt_debug_set (A/B of kernel variants)
         if "=" in kv:

@@ -102,6 +102,10 @@ typedef struct svt_frame {
 
 const char* svt_last_error(void);
 int svt_abi_version(void);
+/* The 16-bit operand type of precision code SVT_PREC_BF16 in THIS build of the library: 0 = bf16 (libsvt_mi355.so), 1 = IEEE half
+ * (libsvt_mi355_f16.so: the same sources compiled with -DSVT_OPERAND_F16 -- same MFMA rate, three more mantissa bits; serves
+ * precision codes 0 and 1 only). */
+int svt_operand_type(void);
 /* number of visible HIP devices whose arch is gfx950 (0 => the product path must fail loudly) */
 int svt_device_count(void);
 

@@ -39,8 +39,9 @@ class DeviceSlot:
 
 
 class DeviceObjects:
-    def __init__(self, destroy_symbol: str):
+    def __init__(self, destroy_symbol: str, lib_variant: str = None):
         self._destroy = destroy_symbol
+        self._variant = lib_variant   # which build of the library created the handles (None: libsvt_mi355.so)
         self._slots: Dict[int, DeviceSlot] = {}
 
     def slot(self, dev_index: int, key) -> DeviceSlot:
@@ -57,7 +58,7 @@ class DeviceObjects:
     def _free(self, s: DeviceSlot) -> None:
         if s.handle is not None:
             try:
-                getattr(_lib.load(), self._destroy)(s.handle)
+                getattr(_lib.load(getattr(self, "_variant", None)), self._destroy)(s.handle)
             except Exception:
                 pass
             s.handle = None

@@ -108,6 +108,7 @@ SYMBOLS = {
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_debug_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "svt_operand_type": (C.c_int, []),
     "svt_encoder_set_norm_reduce": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int64]),
     "svt_frames_to_notes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -119,35 +120,43 @@ SYMBOLS = {
 }
 
 _lib: Optional[C.CDLL] = None
+_libs: dict = {}   # one handle per build of the library ("" = bf16 operands, "f16" = IEEE-half operands)
 
 
-def load() -> C.CDLL:
-    """dlopen the in-tree library and bind every declared symbol; raises SvtError if it is missing."""
+def load(variant: str = None) -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol; raises SvtError if it is missing.
+    ``variant="f16"``: the IEEE-half build of the same sources (``libsvt_mi355_f16.so``, precision="fp16" of the modules)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    key = variant or ""
+    if key in _libs:
+        return _libs[key]
+    path = LIB_PATH if not variant else LIB_PATH.replace(".so", f"_{variant}.so")
+    if not os.path.exists(path):
         raise SvtError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C svt_speechbrain_amd/csrc`). The MI355X path has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     if lib.svt_abi_version() != 1:
-        raise SvtError("libsvt_mi355.so ABI version mismatch")
-    _lib = lib
+        raise SvtError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.svt_operand_type() != (1 if variant == "f16" else 0):
+        raise SvtError(f"{os.path.basename(path)} was built for another operand type")
+    _libs[key] = lib
+    if not variant:
+        _lib = lib
     return lib
 
 
-def last_error() -> str:
-    return (load().svt_last_error() or b"").decode("utf-8", "replace")
+def last_error(lib: C.CDLL = None) -> str:
+    return ((lib or load()).svt_last_error() or b"").decode("utf-8", "replace")
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", lib: C.CDLL = None) -> None:
     if rc != 0:
-        raise SvtError(f"{what}: {last_error()} (status {rc})")
+        raise SvtError(f"{what}: {last_error(lib)} (status {rc})")
 
 
 def require_gpu() -> None:

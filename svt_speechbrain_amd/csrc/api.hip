@@ -232,7 +232,12 @@ static size_t esize(int prec) { return prec ? 2 : 4; }
 // (SVT_PREC_BF16X3 / SVT_PREC_FP16X3) keep the fp32 parity pipeline and change only the engine of the dense products:
 // launch_gemm(gp = precision) cuts the fp32 operands into 16-bit pieces on their way into LDS (gemm.hip).
 static inline int storage_prec(int precision) { return precision >= 2 ? 0 : precision; }
+#ifdef SVT_OPERAND_F16
+// the IEEE-half build serves the exact fp32 mode and the 16-bit throughput mode; the split-operand engines live in the bf16 build
+static inline bool valid_precision(int p) { return p == SVT_PREC_FP32 || p == SVT_PREC_BF16; }
+#else
 static inline bool valid_precision(int p) { return p >= SVT_PREC_FP32 && p <= SVT_PREC_FP16X3; }
+#endif
 
 // out[b,t,h*dh+d] = softmax(scale * q k^T) v ; q rows at Q + (b*T+t)*ldq + h*dh, likewise K (ldkv), V (ldkv)
 // fused attention: bf16, head_dim 64 / 128; its relative-position-bias variant (WavLM) exists for head_dim 64 with the
@@ -400,6 +405,13 @@ extern "C" {
 
 const char* svt_last_error(void) { return g_err.c_str(); }
 int svt_abi_version(void) { return SVT_ABI_VERSION; }
+int svt_operand_type(void) {
+#ifdef SVT_OPERAND_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
 int svt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

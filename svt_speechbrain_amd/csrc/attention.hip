@@ -152,8 +152,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KSD; ++ks)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb], 0, 0, 0);
+        s[kb] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb]);
     }
     // softmax in the scaled log2 domain: p = exp2(s*c - m).  The scale is folded into the exponent FMA, the row max is
     // taken on the raw scores, and the running max is only raised (O and l rescaled) when some row of the wave grew
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
           const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[db], 0, 0, 0);
+          o[db] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[db]);
         }
   }
 
@@ -269,15 +268,15 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
 // materialised (B, H, T, T) score tensor: 8.2 of the 23.2 ms of a 32 x 10 s wav2vec2-base step went there.
 template <bool F16> struct X3T;
 template <> struct X3T<false> {
-  typedef bf16x8 v8;
+  typedef real_bf16x8 v8;
   static __device__ __forceinline__ f32x16 mma(const uint4& a, const v8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(real_bf16x8, a), b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ f32x16 mma(const s16x8& a, const v8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(real_bf16x8, a), b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ void cut(float x, unsigned short& hi, unsigned short& lo) {
-    const bf16_t a = (bf16_t)x, b = (bf16_t)(x - (float)a);
+    const __bf16 a = (__bf16)x, b = (__bf16)(x - (float)a);
     hi = __builtin_bit_cast(unsigned short, a);
     lo = __builtin_bit_cast(unsigned short, b);
   }
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(512) void flash_attn_head_kernel(const bf16_t* __re
         for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KSD; ++ks)
-          s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb][ks]), qf[qb][ks], s[qb][kb], 0, 0, 0);
+          s[qb][kb] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, kf[kb][ks]), qf[qb][ks], s[qb][kb]);
       }
     const bool last = tile * 64 + 64 > T;
 #pragma unroll
@@ -671,7 +670,7 @@ __global__ __launch_bounds__(512) void flash_attn_head_kernel(const bf16_t* __re
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
             const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[qb][db], 0, 0, 0);
+            o[qb][db] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[qb][db]);
           }
     }
   }

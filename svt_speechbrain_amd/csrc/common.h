@@ -4,7 +4,21 @@
 #include <stdint.h>
 #include <string>
 
+// The 16-bit operand type of the throughput mode (precision code 1).  The library is built twice from the same sources:
+// libsvt_mi355.so with bf16 operands (`bf16_t` = __bf16: the mode BASELINE names) and libsvt_mi355_f16.so with IEEE half operands
+// (-DSVT_OPERAND_F16: same MFMA rate, three more mantissa bits; the Python layer loads it for precision="fp16").  Everything in
+// the kernels is written against `bf16_t` and SVT_MFMA_*; the split-operand engines (precision codes 2 / 3) name their piece types
+// explicitly (`real_bf16x8`, `_Float16`) and exist in the bf16 build only.
+typedef __bf16 real_bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef SVT_OPERAND_F16
+typedef _Float16 bf16_t;
+#define SVT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define SVT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
 typedef __bf16 bf16_t;
+#define SVT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define SVT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

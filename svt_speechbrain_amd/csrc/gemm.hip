@@ -70,7 +70,7 @@ template <int SPLIT> __device__ __forceinline__ f32x4 mfma16(const uint4& a, con
   if constexpr (SPLIT == 2)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(real_bf16x8, a), __builtin_bit_cast(real_bf16x8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
           if constexpr (sizeof(T) == 2) {
-            acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, wf[nb][0]), __builtin_bit_cast(bf16x8, xf[mb][0]), acc[nb][mb], 0, 0, 0);
+            acc[nb][mb] = SVT_MFMA_16x16x32(__builtin_bit_cast(bf16x8, wf[nb][0]), __builtin_bit_cast(bf16x8, xf[mb][0]), acc[nb][mb]);
           } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512) void gemm_pp8_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int jj = 0; jj < HM; ++jj)                                                            \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                         \
-        acc[nb][half_ * HM + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nb], xfr[jj], acc[nb][half_ * HM + jj], 0, 0, 0); \
+        acc[nb][half_ * HM + jj] = SVT_MFMA_16x16x32(wfr[nb], xfr[jj], acc[nb][half_ * HM + jj]); \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
   }
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
         for (int j = 0; j < HM; ++j)
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb)
-            acc[nb][half * HM + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[ks][nb], xfr[half][j], acc[nb][half * HM + j], 0, 0, 0);
+            acc[nb][half * HM + j] = SVT_MFMA_16x16x32(wfr[ks][nb], xfr[half][j], acc[nb][half * HM + j]);
       }
     }
     sa = (sa + 2) % NSLOT;
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* ws
       typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
       return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
     } else {
-      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(real_bf16x8, a), __builtin_bit_cast(real_bf16x8, b), c, 0, 0, 0);
     }
   };
   // 8 fp32 of one lane (two 16-byte chunks) -> (hi, lo) pieces
@@ -1474,8 +1474,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     return launch_pp8<128, true>(a, s);
   }
   const bool w4_ok = a.nz == 1 && a.c_z1 == 0 && a.c_z2 == 0 && a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
+  (void)w4_ok;
+#ifndef SVT_OPERAND_F16   // the four-wave kernels' instruction stream names the bf16 MFMA
   if (g_gemm_variant == 40 && w4_ok) return launch_w4(a, s);
   if (g_gemm_variant == 41 && w4_ok && a.K % 128 == 0 && a.N % 256 == 0 && !a.resid) return launch_w4p(a, s);
+#endif
   const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
                        a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;

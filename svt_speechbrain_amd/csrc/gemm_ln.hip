@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void outproj_ln_kernel(OutLnArgs p) {
       _Pragma("unroll") for (int nbh = 0; nbh < 6; ++nbh) {                                                      \
         const bf16x8 wf = __builtin_bit_cast(bf16x8, ws_[nbh * 128 + (ks ? frag1 : frag0)]);                     \
         _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
-          acc[(HALF) * 6 + nbh][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mb], acc[(HALF) * 6 + nbh][mb], 0, 0, 0); \
+          acc[(HALF) * 6 + nbh][mb] = SVT_MFMA_16x16x32(wf, xf[mb], acc[(HALF) * 6 + nbh][mb]); \
       }                                                                                                          \
     }                                                                                                            \
   }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[ks][nb], f.x[ks][mb], acc[nb][mb], 0, 0, 0);
+          acc[nb][mb] = SVT_MFMA_16x16x32(f.w[ks][nb], f.x[ks][mb], acc[nb][mb]);
   };
 
   // Three slabs in flight.  The steady-state loop has no branch: a conditional load would make the compiler's vmcnt

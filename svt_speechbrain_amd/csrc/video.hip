@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void conv3d_front_bf16_kernel(const bf16_t* vp
       const u32x4v xv = {q[0], q[1], q[2], q[3]};
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ks][nb], __builtin_bit_cast(bf16x8, xv), acc[nb], 0, 0, 0);
+        acc[nb] = SVT_MFMA_16x16x32(wr[ks][nb], __builtin_bit_cast(bf16x8, xv), acc[nb]);
     }
     if (live) {
       bf16_t* o = out + ((long)f * npix + pix) * 64 + (lane >> 4) * 16;

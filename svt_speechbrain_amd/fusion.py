@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _lib
 from ._device import DeviceObjects
-from .huggingface_interface import ParamTree, PRECISIONS
+from .huggingface_interface import ParamTree, PRECISIONS, LIB_VARIANT
 from .weights import seeded_fusion_state_dict
 
 
@@ -43,7 +43,7 @@ class FusionRCA(nn.Module):
         for name in ("positional_encoding", "layer1", "layer2"):
             ordered.add_module(name, tree._modules[name])
         self.fusion = ordered
-        self._dev = DeviceObjects("svt_rca_destroy")  # one C object per device, shared with DataParallel replicas
+        self._dev = DeviceObjects("svt_rca_destroy", LIB_VARIANT.get(self.precision))  # one C object per device, shared with DataParallel replicas
 
     def _tensors(self):
         for n, p in self.fusion.named_parameters():
@@ -52,7 +52,7 @@ class FusionRCA(nn.Module):
             yield "fusion." + n, b
 
     def _sync(self, device):
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision, float(self.alpha)))
@@ -62,14 +62,14 @@ class FusionRCA(nn.Module):
         if slot.handle is None:
             h = C.c_void_p()
             _lib.check(lib.svt_rca_create(self.d_model, self.nhead, self.d_ffn, float(self.alpha), self.max_length,
-                                          PRECISIONS[self.precision], idx, C.byref(h)), "svt_rca_create")
+                                          PRECISIONS[self.precision], idx, C.byref(h)), "svt_rca_create", lib)
             slot.handle = h
         for name, t in self._tensors():
             c = t.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * c.dim())(*c.shape)
             _lib.check(lib.svt_rca_load_param(slot.handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
-                       f"svt_rca_load_param({name})")
-        _lib.check(lib.svt_rca_finalize(slot.handle), "svt_rca_finalize")
+                       f"svt_rca_load_param({name})", lib)
+        _lib.check(lib.svt_rca_finalize(slot.handle), "svt_rca_finalize", lib)
         slot.sig = sig
         return slot
 
@@ -83,16 +83,16 @@ class FusionRCA(nn.Module):
                              f"and {tuple(video_feats.shape)}")
         if abs(T1 - T2) > 15:
             print("Alignment is wrong")  # the reference's diagnostic (fusion.py:204-205)
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         slot = self._sync(audio_feats.device)
         a = audio_feats.detach().to(torch.float32).contiguous()
         v = video_feats.detach().to(torch.float32).contiguous()
         need = lib.svt_rca_workspace_bytes(slot.handle, B, T1)
         if need < 0:
-            raise _lib.SvtError(_lib.last_error())
+            raise _lib.SvtError(_lib.last_error(lib))
         ws = slot.workspace(need, a.device)
         out = torch.empty((B, T1, D), dtype=torch.float32, device=a.device)
         _lib.check(lib.svt_rca_forward(slot.handle, _lib.ptr(a), T1, _lib.ptr(v), T2, B, _lib.ptr(out),
                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(a.device)),
-                   "svt_rca_forward")
+                   "svt_rca_forward", lib)
         return out

@@ -29,7 +29,10 @@ from .weights import encoder_param_shapes, seeded_encoder_state_dict
 
 logger = logging.getLogger(__name__)
 
-PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x3": 3}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x3": 3, "fp16": 1}
+# "fp16": the 16-bit throughput mode with IEEE-half operands instead of bf16 -- precision code 1 of the OTHER build of the library
+# (libsvt_mi355_f16.so, the same sources compiled with -DSVT_OPERAND_F16): same MFMA rate, three more mantissa bits
+LIB_VARIANT = {"fp16": "f16"}
 
 
 class ParamTree(nn.Module):
@@ -212,7 +215,7 @@ class HuggingFaceWav2Vec2(nn.Module):
         # device side: one C object per device (shared with nn.DataParallel replicas, see _device.py) and ONE generation
         # counter of the parameter values, shared BY REFERENCE with every replica(): whoever changes the weights bumps it,
         # every device object compares it before a forward
-        self._dev = DeviceObjects("svt_encoder_destroy")
+        self._dev = DeviceObjects("svt_encoder_destroy", LIB_VARIANT.get(self.precision))
         self._gen = [0]
         self._dp_replica = False
         self._warned_grad = False
@@ -344,12 +347,16 @@ class HuggingFaceWav2Vec2(nn.Module):
         return r
 
     # ------------------------------------------------------------------ device-side object
+    def _lib(self):
+        """The build of the library this object's precision lives in (``libsvt_mi355_f16.so`` for "fp16")."""
+        return _lib.load(LIB_VARIANT.get(self.precision))
+
     def _params_signature(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.model.parameters()) + list(self.model.buffers()))
 
     def _sync_device(self, device: torch.device):
         """Make the C object of ``device`` current with the parameters; returns its slot (handle + workspace)."""
-        lib = _lib.load()
+        lib = self._lib()
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.normalize_wav, self.output_norm, self.precision))
@@ -369,7 +376,7 @@ class HuggingFaceWav2Vec2(nn.Module):
         if slot.handle is None:
             h = C.c_void_p()
             cc = _config_to_c(self.config, self.normalize_wav, self.output_norm, self.precision)
-            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
+            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create", lib)
             slot.handle = h
         for name, p in self.model.state_dict().items():
             if not p.is_floating_point():
@@ -377,8 +384,8 @@ class HuggingFaceWav2Vec2(nn.Module):
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(lib.svt_encoder_load_param(slot.handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
-                                                  t.dim()), f"svt_encoder_load_param({name})")
-        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize")
+                                                  t.dim()), f"svt_encoder_load_param({name})", lib)
+        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize", lib)
         slot.sig = (None if self.freeze else self._params_signature(), self._sentinel())
         slot.gen = gen
         return slot
@@ -397,7 +404,7 @@ class HuggingFaceWav2Vec2(nn.Module):
         counter with this object: ``load_state_dict`` / ``refresh`` / ``.to()`` on either one re-uploads both."""
         import copy
         c = copy.copy(self)
-        c._dev = DeviceObjects("svt_encoder_destroy")
+        c._dev = DeviceObjects("svt_encoder_destroy", LIB_VARIANT.get(self.precision))
         # copy.copy shares _parameters / _modules dicts and the _gen list; the load hooks of self.model fire for both
         return c
 
@@ -447,9 +454,9 @@ class HuggingFaceWav2Vec2(nn.Module):
     def _apply_norm_reduce(self, lib, handle) -> None:
         nr = getattr(self, "_norm_reduce", None)
         if nr is None:
-            _lib.check(lib.svt_encoder_set_norm_reduce(handle, None, None, 0), "svt_encoder_set_norm_reduce")
+            _lib.check(lib.svt_encoder_set_norm_reduce(handle, None, None, 0), "svt_encoder_set_norm_reduce", lib)
         else:
-            _lib.check(lib.svt_encoder_set_norm_reduce(handle, C.cast(nr[0], C.c_void_p), None, nr[1]), "svt_encoder_set_norm_reduce")
+            _lib.check(lib.svt_encoder_set_norm_reduce(handle, C.cast(nr[0], C.c_void_p), None, nr[1]), "svt_encoder_set_norm_reduce", lib)
 
     # ------------------------------------------------------------------ forward (reference :263-297)
     def forward(self, wav: torch.Tensor, clips_per_norm_group: int = 0) -> torch.Tensor:
@@ -473,7 +480,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")
         if not wav.is_cuda:
             raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
-        lib = _lib.load()
+        lib = self._lib()
         slot = self._sync_device(wav.device)
         hslot = head._sync(wav.device)
         x = wav.detach().to(torch.float32).contiguous()
@@ -483,7 +490,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise ValueError(f"waveform of {L} samples is shorter than the encoder's receptive field")
         need = lib.svt_encoder_workspace_bytes(slot.handle, B, L)
         if need < 0:
-            raise _lib.SvtError(_lib.last_error())
+            raise _lib.SvtError(_lib.last_error(lib))
         ws = slot.workspace(need, x.device)
         n_out = head.w.out_features
         logits = torch.empty((B, T, n_out), dtype=torch.float32, device=x.device)
@@ -494,7 +501,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             _lib.check(lib.svt_encoder_forward_head(slot.handle, hslot.handle, _lib.ptr(x), B, L, _lib.ptr(logits),
                                                     _lib.ptr(frames) if frames is not None else None, int(pitch_octave_num),
                                                     int(pitch_class_num), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device),
-                                                    int(clips_per_norm_group)), "svt_encoder_forward_head")
+                                                    int(clips_per_norm_group)), "svt_encoder_forward_head", lib)
         return logits
 
     @staticmethod
@@ -509,7 +516,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise ValueError(f"expected a (batch, samples) waveform, got shape {tuple(wav.shape)}")
         if not wav.is_cuda:
             raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
-        lib = _lib.load()
+        lib = self._lib()
         slot = self._sync_device(wav.device)
         x = wav.detach().to(torch.float32).contiguous()
         B, L = x.shape
@@ -518,11 +525,11 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise ValueError(f"waveform of {L} samples is shorter than the encoder's receptive field")
         need = lib.svt_encoder_workspace_bytes(slot.handle, B, L)
         if need < 0:
-            raise _lib.SvtError(_lib.last_error())
+            raise _lib.SvtError(_lib.last_error(lib))
         ws = slot.workspace(need, x.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=x.device)
         self._apply_norm_reduce(lib, slot.handle)
         _lib.check(lib.svt_encoder_forward_ex(slot.handle, _lib.ptr(x), B, L, _lib.ptr(out), _lib.ptr(ws),
                                               ws.numel(), _lib.stream_ptr(x.device), int(clips_per_norm_group)),
-                   "svt_encoder_forward")
+                   "svt_encoder_forward", lib)
         return out

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import _lib
 from ._device import DeviceObjects
-from .huggingface_interface import ParamTree, PRECISIONS
+from .huggingface_interface import ParamTree, PRECISIONS, LIB_VARIANT
 from .weights import seeded_video_frontend_state_dict
 
 
@@ -53,7 +53,7 @@ class SubModel(nn.Module):
                 if ("frontend3D" in key or "trunk" in key) and new_key in own:
                     own[new_key] = val
             self.load_state_dict(own)
-        self._dev = DeviceObjects("svt_video_destroy")  # one C object per device, shared with DataParallel replicas
+        self._dev = DeviceObjects("svt_video_destroy", LIB_VARIANT.get(self.precision))  # one C object per device, shared with DataParallel replicas
 
     def _tensors(self):
         for n, p in self.named_parameters():
@@ -62,7 +62,7 @@ class SubModel(nn.Module):
             yield n, b
 
     def _sync(self, device):
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision,))
@@ -71,7 +71,7 @@ class SubModel(nn.Module):
             return slot
         if slot.handle is None:
             h = C.c_void_p()
-            _lib.check(lib.svt_video_create(self.embed_dim, PRECISIONS[self.precision], idx, C.byref(h)), "svt_video_create")
+            _lib.check(lib.svt_video_create(self.embed_dim, PRECISIONS[self.precision], idx, C.byref(h)), "svt_video_create", lib)
             slot.handle = h
         for name, t in self._tensors():
             if name.endswith("num_batches_tracked"):
@@ -79,8 +79,8 @@ class SubModel(nn.Module):
             c = t.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * c.dim())(*c.shape)
             _lib.check(lib.svt_video_load_param(slot.handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),
-                       f"svt_video_load_param({name})")
-        _lib.check(lib.svt_video_finalize(slot.handle), "svt_video_finalize")
+                       f"svt_video_load_param({name})", lib)
+        _lib.check(lib.svt_video_finalize(slot.handle), "svt_video_finalize", lib)
         slot.sig = sig
         return slot
 
@@ -90,7 +90,7 @@ class SubModel(nn.Module):
         if x.dim() != 5 or x.shape[1] != 1:
             raise ValueError(f"expected a (B, 1, T, H, W) lip ROI tensor, got {tuple(x.shape)}")
         B, _, T, H, W = x.shape
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         slot = self._sync(x.device)
         v = x.detach().to(torch.float32).contiguous()
         need = lib.svt_video_workspace_bytes(slot.handle, B, T, H, W)
@@ -99,7 +99,7 @@ class SubModel(nn.Module):
         ws = slot.workspace(need, v.device)
         out = torch.empty((B, T, self.embed_dim), dtype=torch.float32, device=v.device)
         _lib.check(lib.svt_video_forward(slot.handle, _lib.ptr(v), B, T, H, W, _lib.ptr(out), _lib.ptr(ws),
-                                         ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward")
+                                         ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward", lib)
         return out.transpose(1, 2)  # (B, embed_dim, T), the reference's layout
 
 
@@ -164,7 +164,7 @@ class FairseqAVHubertPretrain(nn.Module):
             self.eval()
             for p in self.parameters():
                 p.requires_grad = False
-        self._dev = DeviceObjects("svt_encoder_destroy")  # one C object per device, shared with DataParallel replicas
+        self._dev = DeviceObjects("svt_encoder_destroy", LIB_VARIANT.get(self.precision))  # one C object per device, shared with DataParallel replicas
 
     @staticmethod
     def _read_fairseq_checkpoint(path):
@@ -197,7 +197,7 @@ class FairseqAVHubertPretrain(nn.Module):
                 yield n, p
 
     def _sync(self, device):
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision, bool(self.output_norm)))
@@ -207,7 +207,7 @@ class FairseqAVHubertPretrain(nn.Module):
         if slot.handle is None:
             h = C.c_void_p()
             cc = _config_to_c(self.config, False, bool(self.output_norm), self.precision)
-            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create")
+            _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create", lib)
             slot.handle = h
         for name, p in self._transformer_tensors():
             hf = fairseq_to_hf_key(name)
@@ -216,8 +216,8 @@ class FairseqAVHubertPretrain(nn.Module):
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(lib.svt_encoder_load_param(slot.handle, hf.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()),
-                       f"svt_encoder_load_param({hf})")
-        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize")
+                       f"svt_encoder_load_param({hf})", lib)
+        _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize", lib)
         slot.sig = sig
         return slot
 
@@ -237,14 +237,14 @@ class FairseqAVHubertPretrain(nn.Module):
         B, E, T = fv.shape
         feats = torch.zeros((B, T, 2 * E), dtype=torch.float32, device=fv.device)
         feats[:, :, E:] = fv.transpose(1, 2)                       # audio half = zeros (hubert.py:700-702)
-        lib = _lib.load()
+        lib = _lib.load(LIB_VARIANT.get(self.precision))
         slot = self._sync(feats.device)
         need = lib.svt_encoder_workspace_bytes(slot.handle, B, T)
         if need < 0:
-            raise _lib.SvtError(_lib.last_error())
+            raise _lib.SvtError(_lib.last_error(lib))
         ws = slot.workspace(need, feats.device)
         out = torch.empty((B, T, self.config.hidden_size), dtype=torch.float32, device=feats.device)
         _lib.check(lib.svt_encoder_forward_ex(slot.handle, _lib.ptr(feats), B, T, _lib.ptr(out), _lib.ptr(ws),
                                               ws.numel(), _lib.stream_ptr(feats.device), int(clips_per_norm_group)),
-                   "svt_encoder_forward")
+                   "svt_encoder_forward", lib)
         return out

@@ -55,7 +55,7 @@ def test_random_geometry_vs_oracle(seed):
             f"g={cfg.num_conv_pos_embedding_groups} B={B} L={L}")
     # random geometries hit every dispatch of the split-operand modes too: LDS-DMA kernel (K % 32 == 0, N >= 128, M >= 128),
     # register-staged split kernel (narrow / batched / K tails), fused split attention (head_dim 64 / 128) or the score path
-    for prec, bound in (("fp32", 1e-3), ("fp16x3", 1e-3), ("bf16x3", 1.5e-3), ("bf16", None)):
+    for prec, bound in (("fp32", 1e-3), ("fp16x3", 1e-3), ("bf16x3", 1.5e-3), ("bf16", None), ("fp16", 0.35)):
         enc = S.HuggingFaceWav2Vec2(cfg.name, None, config=cfg, normalize_wav=True, precision=prec, seed=seed).to(DEV)
         got = enc(wav.to(DEV)).cpu()
         assert got.shape == want.shape, desc
@@ -88,7 +88,7 @@ def test_random_fusion_ctc_fbank_losses_vs_oracle(seed):
     a = torch.randn(B, T1, d_model, generator=g)
     v = torch.randn(B, T2, d_model, generator=g)
     want = O.fusion_forward(sd, a, v, alpha=0.5, nhead=nhead)
-    for prec, tol in (("fp32", 1e-3), ("fp16x3", 1e-3), ("bf16x3", 1e-3), ("bf16", 0.25)):
+    for prec, tol in (("fp32", 1e-3), ("fp16x3", 1e-3), ("bf16x3", 1e-3), ("bf16", 0.25), ("fp16", 0.04)):
         fus = S.FusionRCA(nhead=nhead, d_ffn=d_ffn, d_model=d_model, precision=prec, max_length=300, seed=seed).to(DEV)
         fus.load_state_dict(sd)
         got = fus(a.to(DEV), v.to(DEV)).cpu()

@@ -78,7 +78,8 @@ class Guard:
         self.mp = pytest.MonkeyPatch()
 
     def __enter__(self):
-        _lib.load().svt_debug_set(13, self.mode)
+        for lib in (_lib.load(), _lib.load("f16")):   # both builds of the library keep their own allocator switch
+            lib.svt_debug_set(13, self.mode)
         self.mp.setattr(_device.DeviceSlot, "workspace", _guarded_workspace)
         self.mp.setattr(torch, "empty", guarded_empty)
         return self
@@ -86,7 +87,8 @@ class Guard:
     def __exit__(self, *exc):
         torch.cuda.synchronize()
         self.mp.undo()
-        _lib.load().svt_debug_set(13, 0)
+        for lib in (_lib.load(), _lib.load("f16")):
+            lib.svt_debug_set(13, 0)
 
 
 def same(a, b):
@@ -114,7 +116,7 @@ def check_guarded(run, what):
             del got
 
 
-PRECISIONS = ("fp32", "fp16x3", "bf16x3", "bf16")
+PRECISIONS = ("fp32", "fp16x3", "bf16x3", "bf16", "fp16")
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SVT_GUARD_CASES", "24")))))
@@ -132,6 +134,7 @@ def test_encoder_random_geometries_stay_in_bounds(seed):
 @pytest.mark.parametrize("cfg_name,prec,shapes", [
     ("wav2vec2-base", "bf16", [(1, 16000), (5, 80000), (9, 31000)]),
     ("wav2vec2-base", "fp16x3", [(1, 16000), (3, 47000)]),
+    ("wav2vec2-base", "fp16", [(1, 16000), (5, 47000)]),
     ("wav2vec2-base", "bf16x3", [(2, 23000)]),
     ("wav2vec2-base", "fp32", [(2, 23000)]),
     ("wavlm-base", "bf16", [(2, 47000)]),

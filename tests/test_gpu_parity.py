@@ -126,6 +126,35 @@ def test_bf16_mode_error_bound(golden, name):
     assert mism <= max(2, int(1.2 * mm + 0.999)), (mism, mm, total)
 
 
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1",
+                                  "large_b2", "hubert_large_b2"])
+def test_fp16_mode_error_bound(golden, name):
+    """`precision="fp16"`: the 16-bit throughput mode with IEEE-half operands (the second build of the library,
+    libsvt_mi355_f16.so: same kernels, same MFMA rate, three more mantissa bits than bf16).  Limits = measured on MI355X in round 2
+    plus 20 %: about one eighth of the bf16 mode's error on every golden (base_c1: max |dlogit| 0.055 vs 0.44, mean 0.0099 vs 0.081,
+    4 vs 18 of 249 frames with a different octave / pitch-class argmax) at 98 % of its clips/s."""
+    measured = {  # name: (max, mean, mismatching frames)
+        "tiny_group": (0.0073, 0.0018, 0), "tiny_layer": (0.0116, 0.0024, 0), "base_c1": (0.0547, 0.0099, 4),
+        "base_b2": (0.0576, 0.0109, 11), "large_c1": (0.0237, 0.0046, 2), "data2vec_base_c1": (0.0511, 0.0098, 1),
+        "wavlm_base_c1": (0.0404, 0.0078, 2), "large_b2": (0.0290, 0.0053, 3), "hubert_large_b2": (0.0235, 0.0045, 0)}
+    fx = golden(name)
+    cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "fp16")
+    wav = golden_wav(fx).to(DEV)
+    logits = head(enc(wav))
+    assert torch.isfinite(logits).all()
+    err = (logits.cpu() - fx["logits"]).abs()
+    mism = check_decode(logits, fx, exact=False)
+    total = fx["logits"].shape[0] * fx["logits"].shape[1]
+    print(f"fp16[{name}]: max|dlogit| {err.max():.4f} mean {err.mean():.4f}; frames with a different octave/pitch-class argmax: {mism}/{total}")
+    mx, mn, mm = measured[name]
+    assert err.max() < 1.2 * mx, (err.max(), mx)
+    assert err.mean() < 1.2 * mn, (err.mean(), mn)
+    assert mism <= max(2, int(1.2 * mm + 0.999)), (mism, mm, total)
+    # the fused tail serves this build too, and agrees with encoder -> head
+    fused = enc.forward_head(wav, head) if S.HuggingFaceWav2Vec2.can_fuse_head(head) else logits
+    assert (fused - logits).abs().max().item() < 2e-4
+
+
 def test_encoder_flags_and_batch_coupling():
     """normalize_wav / output_norm off, and the whole-batch norms couple clips."""
     cfg = PRESETS["tiny-group"]

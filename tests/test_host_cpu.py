@@ -461,6 +461,19 @@ def test_frames2note_batch_c_routine_equals_the_frame_loop(golden):
     print(f"32 x 499 frames: {1e2 * (time.time() - t0):.2f} ms per batch")
 
 
+def test_both_builds_of_the_library_export_the_cabi():
+    """libsvt_mi355.so (bf16 operands) and libsvt_mi355_f16.so (IEEE-half operands, precision="fp16") export every symbol the header
+    declares and say which one they are; the f16 build refuses the split-operand precision codes (they live in the bf16 build)."""
+    a, b = _lib.load(), _lib.load("f16")
+    assert a.svt_operand_type() == 0 and b.svt_operand_type() == 1 and a.svt_abi_version() == b.svt_abi_version() == 1
+    for name in _lib.SYMBOLS:
+        assert hasattr(a, name) and hasattr(b, name), name
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=PRESETS["tiny-group"], precision="fp16", seed=1)
+    assert enc._lib() is b
+    with pytest.raises(ValueError):
+        S.HuggingFaceWav2Vec2("tiny-group", None, config=PRESETS["tiny-group"], precision="fp8", seed=1)
+
+
 def test_plain_c_caller_of_the_cabi_compiles(tmp_path):
     """tests/cabi/cabi_driver.c (C11, no torch, no Python) builds against include/svt_mi355.h with gcc; it runs in the GPU suite."""
     import subprocess
