@@ -1135,6 +1135,9 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   const float scale = 1.0f / std::sqrt((float)dh);
   if (c.rel_pos_buckets)
     if (int r = launch_relpos_table(e->rel_embed.as<float>(), H, (int)T, c.rel_pos_buckets, c.rel_pos_max_distance, w.relpb, s)) return r;
+  // split-operand modes with the fused attention: the QKV projection's epilogue writes the planes the attention reads
+  const bool qkv_planes = gp >= 2 && !c.rel_pos_buckets && flash_attention_x3_ok(dh) && w.ab.pl_qkv != nullptr;
+  unsigned short* const qkv_pl = qkv_planes ? (unsigned short*)w.ab.pl_qkv : nullptr;
   int cur_layer = 0;
   auto attention = [&](void) -> int {
     const float* gate = nullptr;
@@ -1148,16 +1151,19 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     ++cur_layer;
     return attention_scores_path(prec, w.qkv, 3L * D, (const char*)w.qkv + (size_t)D * esize(prec),
                                  (const char*)w.qkv + (size_t)2 * D * esize(prec), 3L * D, B, (int)T, H, dh, scale, w.ab,
-                                 false, w.attn_o, D, s, gate, w.relpb, gp);
+                                 qkv_planes, w.attn_o, D, s, gate, w.relpb, gp);
   };
+  // planes: the product additionally / instead leaves as 16-bit (hi, lo) planes for the fused split attention (QKV projection)
   auto gemm_rows = [&](const void* A, int K, const DevBuf& W, const DevBuf& bias, int N, void* Cout, int out_f32, int act,
-                       const float* resid) -> int {
+                       const float* resid, unsigned short* planes = nullptr) -> int {
     GemmArgs g;
     g.A = A; g.W = W.p; g.C = Cout; g.bias = bias.as<float>(); g.resid = resid;
     g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N;
     g.out_f32 = out_f32; g.act = act;
+    g.planes = planes; g.plane_stride = (long)rows * N;
     return launch_gemm(gp, g, s);
   };
+
   float* final_x = nullptr;
   // The residual add lives in the LayerNorm kernel (LN(x + branch)), not in the GEMM epilogue: the GEMM epilogue
   // is then store-only (fire-and-forget under the next tile's MFMAs in the persistent kernel).  tmp = w.hF is free
@@ -1177,7 +1183,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
       const bool last = l + 1 == c.num_layers;
-      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
       // (64 rows per workgroup: below ~190 workgroups the fused kernel leaves CUs idle and the two-kernel form is faster)
       if (outproj_ln_eligible(D, D) && g_fuse_outproj_ln && rows >= 12288) {
@@ -1200,7 +1206,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
                                  prec ? w.xF : nullptr, s)) return r;
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
-      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
       if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
       if (int r = launch_layernorm(prec, tmp, tmp_f32, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, w.xb,
@@ -1226,7 +1232,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
       if (int r = ln_add(Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), pending, w.xb, nullptr)) return r;
-      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
       if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
       if (int r = ln_add(Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), tmp, w.xb, nullptr)) return r;

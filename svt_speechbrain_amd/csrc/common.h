@@ -162,6 +162,12 @@ struct GemmArgs {
   const float* slope = nullptr;      // ACT_PRELU: per-column negative slope
   int resid_first = 0;               // act(acc + bias + resid) instead of act(acc + bias) + resid
   int resid_op_type = 0;             // resid is stored in the operand type (bf16 in bf16 mode), not fp32
+  // split-operand modes: instead of the fp32 C, the epilogue writes C cut into 16-bit (hi, lo) PLANES -- same (row, ldc) layout,
+  // the lo plane plane_stride elements after the hi plane -- which is what the fused split attention reads (the QKV projection).
+  // Served by the LDS-DMA split kernel; for any other kernel launch_gemm writes C and cuts it afterwards.
+  unsigned short* planes = nullptr;
+  long plane_stride = 0;
+  int planes_f16 = 0;          // piece type: 1 = IEEE half, 0 = bf16
   long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
 };
 

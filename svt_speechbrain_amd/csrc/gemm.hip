@@ -484,6 +484,22 @@ int g_gemm_x3 = 1;
 // split-operand products (every other argument as for prec 0)
 int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
+  if (a.planes) {
+    // C as (hi, lo) planes (split-operand modes only): written by the LDS-DMA split kernel's epilogue; any other kernel writes the
+    // fp32 C and the planes are cut from it afterwards
+    if (prec_in < 2 || a.nz != 1 || a.gen) { set_error("gemm: (hi, lo) plane output is served for plain split-operand products"); return -1; }
+    if (g_gemm_x3) {
+      GemmArgs gp = a;
+      gp.c_vec = !(a.ldc & 3) && !((uintptr_t)a.C & 15) && !((uintptr_t)a.resid & 15) && !((uintptr_t)a.bias & 15) && !(a.plane_stride & 3) &&
+                 !((uintptr_t)a.planes & 7);
+      const int r = launch_gemm_x3(prec_in, gp, s);
+      if (r <= 0) return r;
+    }
+    GemmArgs g2 = a;
+    g2.planes = nullptr;
+    if (int r = launch_gemm(prec_in, g2, s)) return r;
+    return launch_split_planes(prec_in, (const float*)a.C, a.ldc, a.M, a.N, a.planes, a.ldc, a.plane_stride, s);
+  }
   const int split = prec_in >= 2 ? prec_in - 1 : 0;
   const int prec = prec_in >= 2 ? 0 : prec_in;
   const int epp = prec ? 8 : 4;

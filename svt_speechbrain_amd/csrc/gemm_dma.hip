@@ -102,7 +102,24 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
             const float4 r4 = *(const float4*)(p.resid + idx);
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
           }
-          *(float4*)((float*)p.C + idx) = v;
+          if (p.planes) {   // (hi, lo) planes instead of fp32 (GemmArgs::planes): 8 + 8 bytes per lane, whole 128-byte lines per row
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (p.planes_f16) {
+                const _Float16 a = (_Float16)x[j], b = (_Float16)(x[j] - (float)a);
+                hi[j] = __builtin_bit_cast(unsigned short, a); lo[j] = __builtin_bit_cast(unsigned short, b);
+              } else {
+                const __bf16 a = (__bf16)x[j], b = (__bf16)(x[j] - (float)a);
+                hi[j] = __builtin_bit_cast(unsigned short, a); lo[j] = __builtin_bit_cast(unsigned short, b);
+              }
+            }
+            *(uint2*)(p.planes + idx) = uint2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+            *(uint2*)(p.planes + p.plane_stride + idx) = uint2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+          } else {
+            *(float4*)((float*)p.C + idx) = v;
+          }
         }
       }
     } else {
@@ -1416,6 +1433,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   const size_t lds_bytes = 5 * 32768;
   GemmArgs g = a;
   g.out_f32 = 1;
+  g.planes_f16 = kind == 3;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
   static bool attr_set[2] = {false, false};
