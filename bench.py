@@ -313,36 +313,43 @@ def main():
     # (frames_l / pinned host buffers are per lane), which is how a caller that wants notes would drive the path.
     notes_out = None
     if not args.no_extra_legs:
-        fr_host = [torch.empty((hi - lo, T, 4), dtype=torch.int32).pin_memory() for _ in range(ns)]
-        done = [torch.cuda.Event() for _ in range(ns)]
-        n_it = 8
+        # ns steps stay in flight while the host assembles notes: the lane a finished step frees is refilled BEFORE its notes are
+        # assembled (ns + 1 pinned host buffers, so the refill's copy never lands in the buffer being read)
+        fr_host = [torch.empty((hi - lo, T, 4), dtype=torch.int32).pin_memory() for _ in range(ns + 1)]
+        done = [torch.cuda.Event() for _ in range(ns + 1)]
+        n_it = 16
         n_notes = 0
         host_s = 0.0
+
+        def issue(k):
+            lane, hb = k % ns, k % (ns + 1)
+            with torch.cuda.stream(streams[lane]):
+                fwds[lane]()
+                fr_host[hb].copy_(frames_l[lane], non_blocking=True)
+                done[hb].record()
+
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pending = None
-        for it in range(n_it + 1):
-            if it < n_it:
-                i = it % ns
-                with torch.cuda.stream(streams[i]):
-                    fwds[i]()
-                    fr_host[i].copy_(frames_l[i], non_blocking=True)
-                    done[i].record()
-            if pending is not None:
-                done[pending].synchronize()
-                th = time.perf_counter()
-                fr = fr_host[pending].numpy().view(FRAME_DTYPE).reshape(hi - lo, T)
-                n_notes = sum(len(x) for x in frames2note_batch(fr, 0.4, 0.5, 1 / 49.8))
-                host_s += time.perf_counter() - th
-            pending = (it % ns) if it < n_it else None
-            if ns == 1 and pending is not None:  # one lane: nothing to overlap with, finish this batch before the next step
-                done[0].synchronize()
+        issued = 0
+        while issued < min(ns, n_it):
+            issue(issued)
+            issued += 1
+        for k in range(n_it):
+            hb = k % (ns + 1)
+            done[hb].synchronize()
+            if issued < n_it:
+                issue(issued)
+                issued += 1
+            th = time.perf_counter()
+            fr = fr_host[hb].numpy().view(FRAME_DTYPE).reshape(hi - lo, T)
+            n_notes = sum(len(x) for x in frames2note_batch(fr, 0.4, 0.5, 1 / 49.8))
+            host_s += time.perf_counter() - th
         dt = time.perf_counter() - t0
         notes_out = {"clips_per_s": round((hi - lo) * n_it / dt, 3), "ms_per_step": round(1e3 * dt / n_it, 4), "iterations": n_it,
                      "host_ms_per_step": round(1e3 * host_s / n_it, 4), "notes_in_last_batch": int(n_notes),
                      "what": "per rank: step + D2H copy of the decoded frames (16 B per frame, pinned) + frame2note of every clip on the host (svt_frames_to_notes, one call per batch) "
-                             "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); the host work of step i overlaps the GPU "
-                             "work of step i + 1 (one batch per lane in flight); host_ms_per_step = the frames2note share"}
+                             "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); one step per lane stays in flight "
+                             "while the host assembles the notes of the step that just finished; host_ms_per_step = the frame2note share"}
 
     if rank == 0:
         clips_per_s = n_total * args.steps / elapsed
