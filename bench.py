@@ -68,7 +68,7 @@ def host_topology():
         return 1, logical, logical, f"{logical} logical CPUs (lscpu unavailable)"
 
 
-def cpu_baseline(cfg, sd, hd, budget_s=40.0):
+def cpu_baseline(cfg, sd, hd, budget_s=40.0, model=None):
     """The oracle (CPU fp32 restatement of the reference forward, kind="port") on the GPU box's host cores, protocol of
     SURVEY.md §8(d): 2 warm-ups, then the MEDIAN of 5 timed passes, for C1 (one 5 s clip: latency and clips/s) and for the
     throughput point B = 8 x 10 s, with torch.set_num_threads(N), N = the physical cores of the host (socket layout in
@@ -108,12 +108,113 @@ def cpu_baseline(cfg, sd, hd, budget_s=40.0):
         rows.append({"threads": nt, "c1_latency_ms": round(1e3 * lat, 1), "c1_clips_per_s": round(1.0 / lat, 3), "c1_passes": n1,
                      "b8x10s_clips_per_s": round(8.0 / med, 4), "b8x10s_passes": n8, "b8x10s_spread": round(spread, 3)})
     best = max(rows, key=lambda r: r["b8x10s_clips_per_s"])
-    return {"value": best["b8x10s_clips_per_s"], "unit": "clips/s", "cores": best["threads"], "kind": "port",
+    by_procs = None
+    if model is not None:
+        try:
+            by_procs = cpu_by_procs(model, sd, hd, phys, sockets, logical)
+        except Exception as e:   # the single-process figure stays the reported baseline
+            by_procs = {"error": repr(e)}
+    return {"value": best["b8x10s_clips_per_s"], "unit": "clips/s", "cores": best["threads"], "kind": "port", "by_procs": by_procs,
             "physical_cores": phys, "sockets": sockets, "logical_cpus": logical, "host": layout,
             "c1_latency_ms": best["c1_latency_ms"], "c1_clips_per_s": best["c1_clips_per_s"], "by_threads": rows,
             "sample": "oracle/svt_oracle.py fp32 (torch CPU): 8 x 10 s clips per pass (throughput, `value`) and one 5 s clip "
                       "(C1 latency); 2 warm-ups + median of up to 5 timed passes per thread count (N = physical cores and 16); "
                       f"host: {layout}"}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a child, pass its stdout (rank 0's JSON line) and stderr through, return its exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc:
+        raise SystemExit(rc)
+    return 0
+
+
+def cpu_worker(spec):
+    """One process of cpu_baseline.by_procs: `spec` = JSON {state, model, cpus, threads, go, passes}.  CPU only (the oracle)."""
+    sp = json.loads(spec)
+    if sp.get("cpus"):
+        try:
+            os.sched_setaffinity(0, set(sp["cpus"]))
+        except OSError:
+            pass
+    torch.set_num_threads(int(sp["threads"]))
+    import svt_speechbrain_amd.config as CFG
+    from oracle import svt_oracle as O
+    cfg = CFG.PRESETS[sp["model"]]
+    st = torch.load(sp["state"], map_location="cpu")
+    sd, hd = st["sd"], st["hd"]
+    wav = synth_wav(8, 160000, seed=1986)
+
+    def one():
+        with torch.no_grad():
+            f = O.encoder_forward(sd, cfg, wav)
+            O.decode_frames(O.head_forward(f, hd["w.weight"], hd["w.bias"]))
+
+    one()
+    one()
+    while time.time() < sp["go"]:   # all processes start their timed passes together
+        time.sleep(0.005)
+    ts = []
+    for _ in range(int(sp["passes"])):
+        t = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t)
+    print(json.dumps({"median_s": statistics.median(ts), "passes": len(ts), "t_end": time.time()}), flush=True)
+    return 0
+
+
+def cpu_by_procs(model, sd, hd, phys, sockets, logical, threads=16, passes=3):
+    """The host's throughput rather than one process's: floor(physical cores / 16) oracle processes side by side, 16 intra-op
+    threads each, every process pinned to its own 16 physical cores (a contiguous range, so a process stays on one socket),
+    same 8 x 10 s batch and 2 warm-ups, then `passes` timed passes started together; value = sum over processes of 8 / median."""
+    import tempfile
+    nproc = max(1, phys // threads)
+    if nproc < 2:
+        return None
+    path = os.path.join(tempfile.gettempdir(), f"svt_cpu_baseline_{os.getpid()}.pt")
+    torch.save({"sd": sd, "hd": hd}, path)
+    try:
+        go = time.time() + 25.0   # load + two warm-ups of the slowest process
+        procs = []
+        for i in range(nproc):
+            cpus = list(range(i * threads, (i + 1) * threads)) if logical >= phys else []
+            spec = json.dumps({"state": path, "model": model, "cpus": cpus, "threads": threads, "go": go, "passes": passes})
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], stdout=subprocess.PIPE,
+                                          stderr=subprocess.DEVNULL, text=True, env=env))
+        outs = []
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=240)
+                outs.append(json.loads(o.strip().splitlines()[-1]))
+            except Exception:
+                pr.kill()
+                outs.append(None)
+        ok = [o for o in outs if o]
+        if not ok:
+            return None
+        return {"processes": nproc, "threads_per_process": threads, "completed": len(ok),
+                "clips_per_s": round(sum(8.0 / o["median_s"] for o in ok), 3),
+                "per_process_clips_per_s": [round(8.0 / o["median_s"], 3) for o in ok],
+                "late_start": bool(any(o["t_end"] - go < 0 for o in ok)),
+                "what": f"{nproc} oracle processes x {threads} threads, each pinned to its own {threads} physical cores, 8 x 10 s clips per pass, "
+                        f"2 warm-ups, {passes} timed passes started together; sum of 8 / median over the processes"}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 def main():
@@ -143,7 +244,21 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
                     "object and workspace), so one step's HBM-bound kernels (LayerNorm, conv0, norms) run under the next step's MFMA-bound "
                     "ones: measured +5 %% with 2, less with 3.  The roofline leg always runs on one stream.")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of cpu_baseline.by_procs
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: start N fresh ranks (one process per GPU, as speechbrain/core.py:1150-1169 expects them:
+        # RANK / LOCAL_RANK in the environment before anything touches a device) and relay rank 0's JSON line.  This process has
+        # made no GPU call and makes none: it only waits for the launcher and exits with its code.
+        return self_launch(args.gpus)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:   # before any GPU call: never time a different job than the one asked for
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with `python -m torch.distributed.run --nproc-per-node "
+                         f"{args.gpus} bench.py --gpus {args.gpus} ...`, or run plain `python bench.py --gpus {args.gpus}` (it starts its own ranks)")
 
     import svt_speechbrain_amd as S
     from svt_speechbrain_amd import _lib, distributed as D
@@ -156,8 +271,8 @@ def main():
     rank, local, world = D.init_from_env()
     if share_gpu:
         local = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:   # never time a different job than the one asked for
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')})")
     dev = torch.device(f"cuda:{local}")
     lib = _lib.load("f16" if args.precision == "fp16" else None)   # the build the encoder lives in: its profiling hooks are per library
     _lib.require_gpu()
@@ -429,11 +544,11 @@ def main():
             res_json["notes_out"] = notes_out
         if world == 1 and not args.no_cpu_baseline:
             sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}
-            res_json["cpu_baseline"] = cpu_baseline(cfg, sd, hd)
+            res_json["cpu_baseline"] = cpu_baseline(cfg, sd, hd, model=args.model)
         print(json.dumps(res_json), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -20,6 +20,25 @@ import torch
 from . import _lib
 
 
+class ReplicaAware:
+    """``nn.DataParallel`` support for a module that uploads its parameters into a C object.
+
+    ``torch.nn.parallel.replicate`` gives every replica -- and every child module of it -- ``_parameters = {}`` and hangs the
+    per-forward broadcast copies on it as plain attributes: on a replica ``parameters()``, ``named_parameters()`` and
+    ``state_dict()`` are EMPTY (buffers survive), and the copies are new tensors on every forward.  A replica therefore never reads
+    its own tree: it remembers the module it was replicated from (``_dp_origin``, kept out of ``_modules``) and both the upload
+    loop and the "did the weights change" signature walk THAT module's tensors; the values travel through the host, so the slot of
+    device k is filled once from the original's parameters wherever they live."""
+
+    def _replicate_for_data_parallel(self):
+        r = super()._replicate_for_data_parallel()
+        r.__dict__["_dp_origin"] = self.__dict__.get("_dp_origin") or self   # not via setattr: a Module value would be registered as a child
+        return r
+
+    def _param_owner(self):
+        return self.__dict__.get("_dp_origin") or self
+
+
 class DeviceSlot:
     """One C object on one device: its handle, what was uploaded into it, and its workspace."""
     __slots__ = ("key", "handle", "sig", "gen", "ws")

@@ -130,7 +130,8 @@ def load(variant: str = None) -> C.CDLL:
     key = variant or ""
     if key in _libs:
         return _libs[key]
-    path = LIB_PATH if not variant else LIB_PATH.replace(".so", f"_{variant}.so")
+    root, ext = os.path.splitext(LIB_PATH)   # only the file's suffix: the checkout may live under a directory with ".so" in its name
+    path = LIB_PATH if not variant else f"{root}_{variant}{ext}"
     if not os.path.exists(path):
         raise SvtError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

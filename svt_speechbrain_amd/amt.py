@@ -2,8 +2,10 @@
 twin ``N20EMv2/audio_visual/train_rca_av.py:28-51``) and the decode half of ``compute_objectives``
 (``train_audio_ssl.py:85-107``), without the SpeechBrain trainer around them.
 
-``AMTForward`` takes the same ``modules`` mapping a recipe yaml builds (``wav2vec2`` + ``model`` for the audio
-recipes, ``fusion`` + ``model`` for the audio-visual one) and returns the reference's 5-tuple."""
+``AMTForward`` takes the same ``modules`` mapping a recipe yaml builds -- ``wav2vec2`` + ``model`` for the audio recipes
+(``MIR_ST500/hparams/train_audio_ssl.yaml`` ``modules:``), ``fusion`` + ``head`` for the audio-visual one
+(``N20EMv2/audio_visual/hparams/train_rca_av.yaml`` ``modules:``, used at ``train_rca_av.py:39,44``) -- and returns the
+reference's 5-tuple."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -22,21 +24,44 @@ class AMTForward:
         self.onset_threshold = onset_threshold
         self.offset_threshold = offset_threshold
         self.frame_rate = frame_rate
-        self.fuse_tail = True   # False: encoder and head as two module calls (the features are materialised)
+        # None (default): the fused tail (out-norm + head + decode behind the encoder, the features never written) in the
+        # throughput precisions only; the parity-grade precisions (fp32 / fp16x3 / bf16x3) keep the reference's order of
+        # operations -- normalise, THEN the linear head -- because the fused form (x.w - mean * sum(w)) * rstd + b re-associates
+        # it (2e-4 on the goldens, more by cancellation when |mean| >> std).  True / False force it either way.
+        self.fuse_tail = None
         self.song_pred: list = []
+
+    def _has(self, name) -> bool:
+        m = self.modules
+        if isinstance(m, dict) or hasattr(m, "__contains__"):
+            try:
+                return name in m
+            except TypeError:
+                pass
+        return hasattr(m, name)
 
     def _get(self, name):
         m = self.modules
         return m[name] if isinstance(m, dict) or hasattr(m, "__getitem__") else getattr(m, name)
 
+    def _head(self, audio_visual: bool):
+        """The frame head under the name the recipe's yaml gives it: ``head`` in the audio-visual recipe
+        (train_rca_av.py:44), ``model`` in the audio-only ones (train_audio_ssl.py:39); either is accepted in both."""
+        for name in (("head", "model") if audio_visual else ("model", "head")):
+            if self._has(name):
+                return self._get(name)
+        raise KeyError("modules has neither 'head' nor 'model' (the 20-way frame head)")
+
     def compute_forward(self, wavs: torch.Tensor, wav_lens: Optional[torch.Tensor] = None, videos: Optional[torch.Tensor] = None):
         """-> (onset_logits, offset_logits, pitch_octave_logits, pitch_class_logits, wav_lens)."""
         if videos is not None:
+            # train_rca_av.py:28-51: `wavs` / `videos` are the pre-extracted audio / video FEATURES of the batch
             feats = self._get("fusion")(wavs, videos)
-            logits = self._get("model")(feats)
+            logits = self._head(True)(feats)
         else:
-            enc, head = self._get("wav2vec2"), self._get("model")
-            if self.fuse_tail and hasattr(enc, "forward_head") and enc.can_fuse_head(head) and wavs.is_cuda \
+            enc, head = self._get("wav2vec2"), self._head(False)
+            fuse = self.fuse_tail if self.fuse_tail is not None else getattr(enc, "precision", None) in ("bf16", "fp16")
+            if fuse and hasattr(enc, "forward_head") and enc.can_fuse_head(head) and wavs.is_cuda \
                     and enc.config.hidden_size == head.w.in_features:
                 # the features are not an output of compute_forward: out-norm + head in one pass behind the encoder
                 logits = enc.forward_head(wavs, head)

@@ -69,6 +69,21 @@ struct GuardRec { void* va; size_t va_bytes; void* map; size_t map_bytes; hipMem
 std::map<void*, GuardRec> g_guard_recs;
 std::mutex g_guard_mu;
 }  // namespace
+// per (kernel, device): the largest dynamic-LDS size already granted (see common.h)
+int ensure_dyn_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> granted;
+  int dev = 0;
+  SVT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  int& have = granted[{kernel, dev}];
+  if (bytes > have) {
+    SVT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+  }
+  return 0;
+}
+
 int dev_alloc(void** out, size_t n) {
   if (n == 0) n = 16;
   if (!g_guard_alloc) { SVT_HIP(hipMalloc(out, n)); return 0; }
@@ -497,7 +512,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 7) g_gemm_skinny_max_tiles = value;
   else if (key == 8) g_flash_wide = value;
   else if (key == 9) g_conv_ln_bf16 = value;
-  else if (key == 10) g_flash_head = value;
+  else if (key == 10) { /* retired: the whole-head attention experiment */ }
   else if (key == 11) g_gemm_x3 = value;
   else if (key == 12) g_debug_keep_split = value;
   else if (key == 13) g_guard_alloc = value;

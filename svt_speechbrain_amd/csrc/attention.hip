@@ -502,195 +502,6 @@ __global__ void split_planes_kernel(const float* __restrict__ src, long ld_src, 
   *(uint2*)(d + plane) = uint2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Whole-head variant (head_dim 64, 256 < T <= 512: the encoder's 10 s clips, T = 499): ONE workgroup per (clip, head).
-// The head's entire K and V (512 keys x 128 B each = 2 x 64 KiB) are made resident in LDS by 16 LDS-DMA instructions per
-// wave issued up front in tile order, so K / V leave L2 exactly once per head (the 256-query workgroups above fetch them
-// twice) and the key sweep has no producer/consumer hand-off: a barrier only where a tile is consumed for the first time
-// (tiles 0, 1, 2 and 4: counted vmcnt, the rest of the fill is in flight behind the first tiles' MFMAs).  Each of the 8
-// waves owns 64 queries = two 32-query blocks: the K fragments of a tile are read from LDS once for both, and the two
-// blocks give the scheduler independent MFMA (S of block 1) and VALU (softmax of block 0) work inside one wave.
-// Same arithmetic as flash_attn_kernel: S^T = K Q^T with keys on the MFMA rows, P straight from the S accumulators,
-// V transposed on the fly by ds_read_b64_tr_b16, deferred rescale of the running max.
-__global__ __launch_bounds__(512) void flash_attn_head_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
-                                                            const bf16_t* __restrict__ K, long ldk, long k_bstride,
-                                                            const bf16_t* __restrict__ V, bf16_t* __restrict__ O, long ldo,
-                                                            long o_bstride, int T, int H, float c) {
-  constexpr int DH = 64, KSD = 4, DB = 2, CPR = 8, RB = 128, NT = 8;
-  extern __shared__ __attribute__((aligned(16))) uint4 KVR[];  // K image: 512 keys x 8 chunks, then the V image
-  uint4* Kimg = KVR;
-  uint4* Vimg = KVR + 512 * CPR;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
-  const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
-  const bf16_t* Vb = V + (long)b * k_bstride + (long)h * DH;
-  typedef const void __attribute__((address_space(1)))* gptr_t;
-  typedef void __attribute__((address_space(3)))* lptr_t;
-  const int q0 = wave * 64;
-  const int hh = lane >> 5, kl = lane & 31, kg = (kl >> 1) & 7;
-  // Q fragments of the two query blocks (B operand of S^T = K Q^T), issued BEFORE the fill and by inline asm: hipcc would
-  // drain the whole LDS-DMA queue (vmcnt(0)) at the first use of an ordinary load's result; as the 8 oldest operations of
-  // the wave they are complete at the first counted wait below (vmcnt(14) <= 16)
-  bf16x8 qf[2][KSD];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    int q = q0 + qb * 32 + kl;
-    if (q > T - 1) q = T - 1;
-    const bf16_t* qp = Qb + (long)q * ldq + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < KSD; ++ks)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[qb][ks]) : "v"(qp + ks * 16) : "memory");
-  }
-  // fill: instruction i of wave w moves rows (8 i + w) * 8 .. + 7, i.e. its share of key tile i; rows >= T re-read row T - 1
-  {
-    const int r8 = lane >> 3, slot = lane & 7;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int key = (i * 8 + wave) * 8 + r8;
-      const int kc = key > T - 1 ? T - 1 : key;
-      const int g = (key >> 1) & 7, sw = ((key >> 1) & 1) << 2;
-      const bf16_t* kp = Kb + (long)kc * ldk;
-      __builtin_amdgcn_global_load_lds((gptr_t)(kp + ((slot ^ g) * 8)), (lptr_t)(Kimg + (i * 8 + wave) * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(kp + (Vb - Kb) + ((slot ^ sw) * 8)), (lptr_t)(Vimg + (i * 8 + wave) * 64), 16, 0, 0);
-    }
-  }
-  f32x16 o[2][DB];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
-  float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
-  const int ntiles = (T + 63) / 64;
-  const char* vbase[DB];
-  {
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const int key0 = 4 * (g >> 1) + q;
-    const int sw = ((q >> 1) & 1) << 2;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
-      vbase[db] = (const char*)Vimg + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
-    }
-  }
-  // queries >= T of the last wave(s) compute on clamped rows and are never stored; a wave with no valid query leaves
-  // after the last barrier it takes part in
-  for (int tile = 0; tile < ntiles; ++tile) {
-    // first use of a tile: its fill (one K + one V instruction per wave, issued in tile order after the 8 Q loads) has landed
-    // for this wave after the counted wait -- 16 - 2 (tile + 1) younger operations may still be in flight -- and for every
-    // wave after the barrier.  The tile-0 wait names the Q registers as operands: nothing may read or move them before it.
-    if (tile == 0) {
-      asm volatile("s_waitcnt vmcnt(14)"
-                   : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]),
-                     "+v"(qf[1][3])
-                   :: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    } else if (tile == 1) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-    else if (tile == 2) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-    else if (tile == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-    const uint4* Kf = Kimg + tile * 64 * CPR;
-    uint4 kf[2][KSD];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KSD; ++ks) kf[kb][ks] = Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)];
-    f32x16 s[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks)
-          s[qb][kb] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, kf[kb][ks]), qf[qb][ks], s[qb][kb]);
-      }
-    const bool last = tile * 64 + 64 > T;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      if (__builtin_expect(last, 0)) {  // wave-uniform, last tile only
-        const int kbase = tile * 64 + 4 * hh;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
-            asm volatile("" : "+v"(s[qb][kb][r]));
-            if (key >= T) s[qb][kb][r] = -3e38f;
-          }
-      }
-      float mx = fmaxf(s[qb][0][0], s[qb][1][0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[qb][0][r]), s[qb][1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-      if (!__all(mx - m[qb] <= 8.0f)) {
-        const float mnew = fmaxf(m[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);
-        l[qb] *= alpha;
-        m[qb] = mnew;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
-      }
-      typedef float f32x2v __attribute__((ext_vector_type(2)));
-      f32x2v sum2 = {0.f, 0.f};
-      const f32x2v c2 = {c, c}, nm2 = {-m[qb], -m[qb]};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2v e = f32x2v{s[qb][kb][r], s[qb][kb][r + 1]} * c2 + nm2;
-          const f32x2v pp = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-          s[qb][kb][r] = pp.x;
-          s[qb][kb][r + 1] = pp.y;
-          sum2 += pp;
-        }
-      float sum = sum2.x + sum2.y;
-      sum += __shfl_xor(sum, 32, 64);
-      l[qb] += sum;
-      bf16x8 pf[2][2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[kb][ss][j] = (bf16_t)s[qb][kb][ss * 8 + j];
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss) {
-            const char* vp = vbase[db] + (tile * 64 + kb * 32 + ss * 16) * RB;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
-            const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            o[qb][db] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[qb][db]);
-          }
-    }
-  }
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int q = q0 + qb * 32 + kl;
-    if (q >= T) continue;
-    const float inv = 1.f / l[qb];
-    bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[qb][db][g * 4 + j] * inv);
-        *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
-      }
-  }
-}
 }  // namespace
 
 int launch_split_planes(int kind, const float* src, long ld_src, long rows, int cols, void* dst, long ld_dst, long plane, hipStream_t s) {
@@ -734,7 +545,6 @@ int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups
 // the lost wave-level overlap of MFMA and softmax VALU work; (ii) hipcc puts an s_waitcnt vmcnt(0) in front of the first
 // LDS read of every tile while an LDS-DMA it knows about is outstanding, so the tile-ordered fill is in fact waited for
 // in full before tile 0; (iii) 384 heads on 256 CUs are 1.5 rounds either way.  Kept for svt_debug_set(10, 1) A/B runs.
-int g_flash_head = 0;
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
@@ -759,20 +569,6 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
     else
       hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, dim3(256), dyn, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                          ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, gate, pb);
-    prof_end(s, flops, 0.0, 2);
-    SVT_LAUNCH_CHECK();
-    return 0;
-  }
-  if (dh == 64 && g_flash_head && g_flash_wide && T > 256 && T <= 512 && (long)B * H >= 128) {
-    static bool attr_set = false;
-    const size_t lds = 2 * 512 * 128;
-    if (!attr_set) {
-      SVT_HIP(hipFuncSetAttribute((const void*)flash_attn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    prof_begin(s);
-    hipLaunchKernelGGL(flash_attn_head_kernel, dim3(B * H), dim3(512), lds, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K, ldk,
-                       k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c);
     prof_end(s, flops, 0.0, 2);
     SVT_LAUNCH_CHECK();
     return 0;

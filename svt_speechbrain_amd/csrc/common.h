@@ -177,6 +177,9 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
 // large-tile LDS-DMA variant (bf16, K % 64 == 0); launch_gemm dispatches to it
 bool gemm_dma_eligible(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
+// persistent + staggered form of the LDS-DMA pipeline (gemm_pps.hip): bf16 output, no residual, activation none / GELU
+bool gemm_pps_eligible(const GemmArgs& a);
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int dma_form = 0);
 // small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
 bool gemm_skinny_eligible(const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
@@ -186,7 +189,6 @@ int split_weights_register(const void* w_f32_dev, long n_rows, int K, int kind, 
 void split_weights_forget(const void* w_f32_dev);
 int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s);  // 0 = launched, 1 = not eligible (use the register-staged kernel), < 0 = error
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
-extern int g_flash_head;  // whole-head fused attention kernel (K / V resident in LDS): off (0, default: measured slower) / on (1), svt_debug_set key 10
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
@@ -194,6 +196,10 @@ extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debu
 extern int g_gemm_force_bm;
 extern int g_gemm_ring;
 extern int g_gemm_variant;  // diagnostics: replaces dbg inside the kernel while the trace pointer stays set
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that asks for more than 64 KiB of dynamic LDS: function attributes are
+// per DEVICE, so the "already set" memory is per (kernel, device), behind a mutex (DataParallel runs replicas from threads)
+int ensure_dyn_lds(const void* kernel, int bytes);
 
 // ---- device allocations of the library (api.hip): hipMalloc, or page-guarded mappings under svt_debug_set key 13 ----
 int dev_alloc(void** out, size_t bytes);

@@ -460,12 +460,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
   GemmArgs ar = a;
   ar.raster_gm = tiles_n >= 8 ? 8 : 64 / tiles_n;
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, GEN, SPLIT, NSET, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_kernel<T, BM, BN, GEN, SPLIT, NSET, MINW>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.nz +
                        (double)a.M * a.N * a.nz * ((a.out_f32 || sizeof(T) == 4) ? 4 : 2);

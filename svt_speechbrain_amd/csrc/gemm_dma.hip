@@ -1306,11 +1306,7 @@ int launch_w4p(const GemmArgs& a, hipStream_t s) {
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 131072;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_w4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_w4p_kernel, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
   prof_begin(s);
@@ -1323,11 +1319,7 @@ int launch_w4p(const GemmArgs& a, hipStream_t s) {
 int launch_w4(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
   const size_t lds_bytes = 131072;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_w4_kernel, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
   prof_begin(s);
@@ -1343,12 +1335,7 @@ int launch_pers(const GemmArgs& a, hipStream_t s) {
   const int ntiles = tiles_m * tiles_n;
   int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pers_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pers_kernel<BM>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
   prof_begin(s);
@@ -1363,12 +1350,7 @@ int launch_pp8(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 64 * NBW - 1) / (64 * NBW);
   dim3 grid(tiles_m * tiles_n, a.nz, 1);
   const size_t lds_bytes = 5 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_pp8_kernel<BM, GEN, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pp8_kernel<BM, GEN, NBW>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   prof_begin(s);
@@ -1436,13 +1418,12 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   g.planes_f16 = kind == 3;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
-  static bool attr_set[2] = {false, false};
   prof_begin(s);
   if (kind == 3) {
-    if (!attr_set[1]) { SVT_HIP(hipFuncSetAttribute((const void*)gemm_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set[1] = true; }
+    if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<true>, (int)lds_bytes)) return r_;
     hipLaunchKernelGGL((gemm_x3_kernel<true>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
   } else {
-    if (!attr_set[0]) { SVT_HIP(hipFuncSetAttribute((const void*)gemm_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set[0] = true; }
+    if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<false>, (int)lds_bytes)) return r_;
     hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
   }
   prof_end(s, flops, bytes, 0);
@@ -1493,6 +1474,11 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   }
   const bool w4_ok = a.nz == 1 && a.c_z1 == 0 && a.c_z2 == 0 && a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
   (void)w4_ok;
+  if (g_gemm_variant >= 50 && g_gemm_variant < 70 && gemm_pps_eligible(a)) {   // diagnostics: 50 = force it, 51 / 53 / 54 = its dbg 1 / 3 / 4; 60.. = builtin DMA form
+    GemmArgs b = a;
+    b.dbg = g_gemm_variant % 10;
+    return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, g_gemm_variant >= 60);
+  }
 #ifndef SVT_OPERAND_F16   // the four-wave kernels' instruction stream names the bf16 MFMA
   if (g_gemm_variant == 40 && w4_ok) return launch_w4(a, s);
   if (g_gemm_variant == 41 && w4_ok && a.K % 128 == 0 && a.N % 256 == 0 && !a.resid) return launch_w4p(a, s);

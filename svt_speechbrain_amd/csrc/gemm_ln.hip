@@ -248,11 +248,7 @@ int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias,
   a.gamma = gamma; a.beta = beta; a.yh = (bf16_t*)yh; a.yl = (bf16_t*)yl; a.yF = yF;
   a.M = M; a.K = K; a.lda = lda; a.eps = eps;
   const size_t lds_bytes = (size_t)kLdsU4 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)outproj_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)outproj_ln_kernel, (int)lds_bytes)) return r_;
   prof_begin(s);
   hipLaunchKernelGGL(outproj_ln_kernel, dim3((M + kBM - 1) / kBM), dim3(512), lds_bytes, s, a);
   prof_end(s, 2.0 * M * (double)kD * K, ((double)M * K + (double)kD * K + 4.0 * M * kD) * 2 + (yF ? 4.0 * M * kD : 0.0), 0);

@@ -1,0 +1,347 @@
+// bf16 dense contraction for gfx950: PERSISTENT + STAGGERED form of the LDS-DMA pipeline of gemm_dma.hip.
+//
+// gemm_pp8_kernel (one tile per workgroup) multiplies a 256 x 256 x 64 slab in 1.24 us -- eight slots per slab, waves 4-7 one
+// slot behind waves 0-3, so that on every SIMD one wave issues MFMAs while its partner reads fragments and issues the ring's
+// LDS-DMA -- but pays a 2 us prologue and a 6-8 us LDS-transposed epilogue per tile with every CU storing at once.
+// gemm_pers_kernel hides prologue and stores behind the next tile, but its lockstep slab costs 1.67 us.  This kernel is the
+// staggered schedule run as ONE stream of (tile, K slab) pairs per workgroup:
+//   * a workgroup per CU walks its tile list; the ring (five 32 KiB slots, units A_g W_g A_g+1 W_g+1 ..., three in flight) never
+//     drains between tiles: during the last two slabs of a tile the units requested are the next tile's first ones;
+//   * LDS-DMA is issued from inline asm in the `voffset + SGPR base` form (global_load_lds_dwordx4 v, s[base:base+1]): one 32-bit
+//     row offset per DMA instruction instead of a 64-bit pointer (two tiles' worth of sources are live at a tile boundary), the K
+//     advance is scalar, and the compiler -- which sees no LDS write and no VMEM load -- never adds a vmcnt(0) of its own;
+//   * waves are laid out 4 (M) x 2 (N), wave tile BM/4 x 128, and the MFMA takes the ACTIVATION fragment as its first operand: a lane
+//     then holds rows 4 (lane >> 4) + r of a 16-row block and, with the W rows of a 128-column group placed in LDS so that (block
+//     nb, row j) is output column 8 j + nb, EIGHT consecutive columns of each: one buffer_store_dwordx4 writes four rows x 256
+//     contiguous bytes.  (The first form -- W fragment first, 16 lanes = 16 rows -- wrote 64 separate 16-byte pieces per
+//     instruction: the epilogue was bound by store ISSUE, 3.1 us per 256 x 256 tile without activation.)
+//   * the epilogue runs out of the accumulators (bias, GELU, bf16, bounds-checked buffer stores) in the slot where the two wave
+//     groups meet: waves 0-3 run it in front of the next tile's first LOAD slot, waves 4-7
+//     behind their last MFMA slot, i.e. in the same barrier interval, so the two waves of a SIMD interleave their VALU work
+//     instead of each running it alone against an idle partner; the stores drain under the next tile's MFMAs;
+//   * the bias of a tile is fetched by four asm loads one slot before the tile's last A unit is requested: the counted wait that
+//     retires that slab covers them (VMEM operations return in order), so the epilogue itself waits for nothing.
+// Contract: bf16 (operand type) output, no residual, alpha = 1, activation none or GELU, K % 64 == 0, K >= 128, N % 256 == 0,
+// A and W spans below 4 GiB (32-bit offsets).  Everything else stays on gemm_pers_kernel / gemm_pp8_kernel.
+#include "common.h"
+
+namespace svt {
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_addr, lds_addr + 1024)
+__device__ __forceinline__ void dma_sv(unsigned voff, const void* sbase, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+// the same request through the compiler's builtin (64-bit per-lane address): A/B of the two issue forms (DMAF = 1)
+__device__ __forceinline__ void dma_vv(unsigned voff, const void* sbase, unsigned lds_addr) {
+  __builtin_amdgcn_global_load_lds((gptr_t)((const char*)sbase + voff), (lptr_t)(size_t)lds_addr, 16, 0, 0);
+}
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+template <int BM, int ACT, int DMAF>
+__global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
+  constexpr int BN = 256, BK = 64, NSLOT = 5;
+  constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
+  constexpr int GA = BM / 64, GW = BN / 64;
+  constexpr int SLOT = 2048;        // uint4 per ring slot (32 KiB)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = (wave >> 2) & 1;   // waves 0-3 (columns 0-127) run one slot ahead of waves 4-7 (columns 128-255)
+  const int nblk = gridDim.x, b = blockIdx.x;
+  // blocks b and b + 8 share an XCD: in every round an XCD works on nblk / 8 consecutive logical tiles (n fastest)
+  const int per = nblk >> 3;
+  const int lbase = (b & 7) * per + (b >> 3);
+  if (lbase >= ntiles) return;
+  const int my_tiles = (ntiles - lbase + nblk - 1) / nblk;
+
+  const char* gA = (const char*)p.A;
+  const char* gW = (const char*)p.W;
+  const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+  unsigned aof[GA], wof[GW];     // byte offsets of the rows this lane fetches: tile whose units are being requested ...
+  unsigned aof2[GA], wof2[GW];   // ... and the tile after it
+  auto setup = [&](int logical, unsigned (&ao)[GA], unsigned (&wo)[GW]) {
+    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      int m = m0 + (wave + 8 * i) * 8 + r8;
+      if (m > p.M - 1) m = p.M - 1;
+      ao[i] = (unsigned)(((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+      const int rho = (wave + 8 * i) * 8 + r8;   // LDS row of the W unit: (128-column group, block nb, row j) <- output column 8 j + nb
+      const int n = n0 + (rho >> 7) * 128 + (rho & 15) * 8 + ((rho >> 4) & 7);   // < N: N % 256 == 0
+      wo[i] = (unsigned)(((long)n * p.ldw + ch * 8) * 2);
+    }
+  };
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(void __attribute__((address_space(3)))*)lds);
+  auto lds_unit = [&](int slot, int i) -> unsigned { return lds0 + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u; };
+
+  auto dma = [&](unsigned voff, const void* sbase, unsigned lds_addr) {
+    if constexpr (DMAF == 0) dma_sv(voff, sbase, lds_addr); else dma_vv(voff, sbase, lds_addr);
+  };
+  f32x4 acc[8][MB];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
+  const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + (cq ^ rr8);
+  const int frag1 = (r16 >> 3) * 64 + rr8 * 8 + ((4 + cq) ^ rr8);
+  const int xoff = (wm * MB) * 128;   // uint4 index of the wave's first 16-row block of the A unit
+  const int woff = (wn * 8) * 128;    // ... of the W unit
+
+  const int nk = p.K / BK;             // >= 2 (launcher)
+  const int G = my_tiles * nk;         // slabs in this workgroup's stream
+  // diagnostics (tools/gemm_trace.py, dbg = 9 sets p.trace): s_memrealtime (100 MHz) stamps at entry / first slab / around every
+  // epilogue / exit, s_memtime (core clock) over the stream; dbg 1 = no LDS-DMA after the head of the stream, 3 = no epilogue
+  const bool tr = p.trace != nullptr;
+  const bool no_dma = p.dbg == 1 || p.dbg == 4, no_epi = p.dbg == 3 || p.dbg == 4, has_bias = p.bias != nullptr;
+  long long t_begin = 0, t_first = 0, t_epi = 0, c_first = 0;
+  if (tr) t_begin = wall_clock64();
+  setup(lbase, aof, wof);
+  if (my_tiles > 1) setup(nblk + lbase, aof2, wof2);
+  // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
+#pragma unroll
+  for (int i = 0; i < GA; ++i) dma(aof[i], gA, lds_unit(0, i));
+#pragma unroll
+  for (int i = 0; i < GW; ++i) dma(wof[i], gW, lds_unit(1, i));
+#pragma unroll
+  for (int i = 0; i < GA; ++i) dma(aof[i], gA + BK * 2, lds_unit(2, i));
+  wait_vm<GA>();
+  __builtin_amdgcn_s_barrier();
+  if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
+
+  bf16x8 wfr[4], xfr[MB];
+  f32x4 bq[2];                         // bias of this lane's 8 columns (tile being multiplied), fetched in its last slab
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int sa = 0, sw = 1, kt = 0, ti = 0;
+  const int grp = wave >> 2;   // = wn
+
+  // ---- the tile's epilogue: accumulators -> (+ bias, activation) -> bf16 -> buffer stores; clears the accumulators and
+  //      rotates the source offsets to the next tile ----
+  auto epilogue = [&]() {
+    long long t_e0 = 0;
+    if (tr) t_e0 = wall_clock64();
+    const int logical = ti * nblk + lbase;
+    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // descriptor over the rows [m0, M) of C: a row >= M lands beyond num_records and is dropped by the memory pipeline
+    const long rows_left = (long)p.M - m0;
+    const unsigned long nbytes = (unsigned long)rows_left * p.ldc * 2;
+    const unsigned nrec = nbytes > 0xFFFFFFF0ul ? 0xFFFFFFF0u : (unsigned)nbytes;
+    char* cbase = (char*)p.C + (long)m0 * p.ldc * 2;
+    const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);
+    // this lane: rows 4 (lane >> 4) + r of every 16-row block of the wave, columns 8 (lane & 15) .. + 7 of the wave's 128
+    const unsigned off0 = (unsigned)((((long)(wm * (BM / 4) + 4 * (lane >> 4))) * p.ldc + n0 + wn * 128 + (lane & 15) * 8) * 2);
+    const unsigned row_pitch = (unsigned)(p.ldc * 2);
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bq[j >> 2][j & 3];
+    if (!no_epi) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf16x8 o;
+        if constexpr (ACT == ACT_GELU) {
+          f32x2_t g[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = f32x2_t{acc[2 * j][mb][r] + bv[2 * j], acc[2 * j + 1][mb][r] + bv[2 * j + 1]};
+          gelu_bf16x2_x4(g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[2 * j] = (bf16_t)g[j].x;
+            o[2 * j + 1] = (bf16_t)g[j].y;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j][mb][r] + bv[j]);
+        }
+        // the row inside the wave's tile goes into the VECTOR offset: (i) the range check of a raw buffer covers voffset only,
+        // a row >= M addressed through soffset would be written; (ii) with an SGPR in the soffset field hipcc (ROCm 7.2) assumes
+        // the ">64-bit store data, then VALU write of those registers" hazard away and packs the next row into the same four
+        // registers with no wait state: on gfx950 that tore the first dword of the previous store in the last four lanes of
+        // every 16 whenever the memory pipeline was busy (the persistent stream's LDS-DMA) -- tools/pps_probe.py
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, 0);
+      }
+    }
+    } else if (acc[0][0][0] == 123.456f && acc[7][MB - 1][3] == 1.5f) {
+      ((float*)p.C)[0] = 1.f;   // keeps the accumulators live
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ++ti;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) aof[i] = aof2[i];
+#pragma unroll
+    for (int i = 0; i < GW; ++i) wof[i] = wof2[i];
+    if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, aof2, wof2);
+    if (tr) t_epi += wall_clock64() - t_e0;
+  };
+
+  // LOAD slot Q of slab g: fragment reads of MFMA group Q (k-step Q >> 1, column half Q & 1: W blocks 4 (Q & 1) .. + 3; the
+  // activation blocks of the k-step are read in the first half) + the ring's requests: W_{g+1} during k-step 0, A_{g+2} during
+  // k-step 1, two DMA instructions per slot; the bias of the finishing tile in slot 1 of its last slab
+#define PPS_LOAD(Q)                                                                                                 \
+  {                                                                                                                 \
+    constexpr int ks_ = (Q) >> 1, half_ = (Q)&1;                                                                    \
+    if (half_ == 0) {                                                                                               \
+      _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = __builtin_bit_cast(bf16x8, xa[jj * 128 + (ks_ ? frag1 : frag0)]); \
+    }                                                                                                               \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                \
+        wfr[nb] = __builtin_bit_cast(bf16x8, wa[(half_ * 4 + nb) * 128 + (ks_ ? frag1 : frag0)]);                   \
+    if (ks_ == 0) {                                                                                                 \
+      if (have_w) {                                                                                                 \
+        const char* wb = w_cur ? gW + (long)(kt + 1) * (BK * 2) : gW;                                               \
+        _Pragma("unroll") for (int i2 = half_ * 2; i2 < half_ * 2 + 2; ++i2)                                        \
+            dma(w_cur ? wof[i2] : wof2[i2], wb, lds_unit(wslot, i2));                                               \
+      }                                                                                                             \
+      if (half_ == 1 && last_k && has_bias) {                                                                       \
+        const float* bp = p.bias + (((ti * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);             \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"                 \
+                     : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");                                            \
+      }                                                                                                             \
+    } else {                                                                                                        \
+      if (have_a) {                                                                                                 \
+        const char* ab = gA + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 2);                                      \
+        _Pragma("unroll") for (int i2 = half_ * ((GA + 1) / 2); i2 < (half_ ? GA : (GA + 1) / 2); ++i2)             \
+            dma(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(aslot, i2));                                               \
+      }                                                                                                             \
+    }                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define PPS_MMA(Q)                                                                                                  \
+  {                                                                                                                 \
+    constexpr int half_ = (Q)&1;                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                \
+      _Pragma("unroll") for (int jj = 0; jj < MB; ++jj)                                                             \
+        acc[half_ * 4 + nb][jj] = SVT_MFMA_16x16x32(xfr[jj], wfr[nb], acc[half_ * 4 + nb][jj]);                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+  // retire slab g: everything but the A unit requested during this slab (A_{g+2}) has landed -- W_{g+1}, A_{g+1}, the bias
+  // loads of a tile's last slab and the previous tile's stores are all older
+#define PPS_RETIRE()                                                                                                \
+  {                                                                                                                 \
+    if (have_a) wait_vm<GA>(); else wait_vm<0>();                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define PPS_SLAB_VARS()                                                                                             \
+  const uint4* xa = lds + sa * SLOT + xoff;                                                                         \
+  const uint4* wa = lds + sw * SLOT + woff;                                                                         \
+  const bool have_w = g + 1 < G && !no_dma, have_a = g + 2 < G && !no_dma;                                          \
+  const bool w_cur = kt + 1 < nk, a_cur = kt + 2 < nk, last_k = kt + 1 == nk;                                       \
+  const int wslot = (sa + 3) % NSLOT, aslot = (sa + 4) % NSLOT;
+#define PPS_ADVANCE()                                                                                               \
+  sa = (sa + 2) % NSLOT;                                                                                            \
+  sw = (sw + 2) % NSLOT;                                                                                            \
+  if (++kt == nk) kt = 0;
+
+  if (grp == 0) {
+    bool pending = false;   // the previous slab closed a tile: its epilogue runs in front of this slab's first LOAD slot
+    for (int g = 0;; ++g) {
+      if (pending) epilogue();
+      if (g == G) break;
+      PPS_SLAB_VARS()
+      PPS_LOAD(0) __builtin_amdgcn_s_barrier(); PPS_MMA(0) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(1) __builtin_amdgcn_s_barrier(); PPS_MMA(1) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(2) __builtin_amdgcn_s_barrier(); PPS_MMA(2) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(3) __builtin_amdgcn_s_barrier(); PPS_MMA(3)
+      PPS_RETIRE()
+      __builtin_amdgcn_s_barrier();
+      pending = last_k;
+      PPS_ADVANCE()
+    }
+  } else {
+    __builtin_amdgcn_s_barrier();  // one slot behind
+    for (int g = 0; g < G; ++g) {
+      PPS_SLAB_VARS()
+      PPS_LOAD(0) __builtin_amdgcn_s_barrier(); PPS_MMA(0) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(1) __builtin_amdgcn_s_barrier(); PPS_MMA(1) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(2) __builtin_amdgcn_s_barrier(); PPS_MMA(2) __builtin_amdgcn_s_barrier();
+      PPS_LOAD(3)
+      PPS_RETIRE()
+      __builtin_amdgcn_s_barrier();
+      PPS_MMA(3)
+      if (last_k) epilogue();
+      if (g + 1 < G) __builtin_amdgcn_s_barrier();
+      PPS_ADVANCE()
+    }
+  }
+  if (tr && lane == 0 && (wave & 3) == 0) {
+    const long long t_end = wall_clock64();
+    long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
+    o[0] = t_begin; o[1] = t_first; o[2] = t_end - t_first - t_epi; o[3] = t_epi; o[4] = t_end; o[5] = my_tiles;
+    o[6] = __builtin_amdgcn_s_memtime() - c_first; o[7] = BM;
+  }
+#undef PPS_LOAD
+#undef PPS_MMA
+#undef PPS_RETIRE
+#undef PPS_SLAB_VARS
+#undef PPS_ADVANCE
+}
+
+template <int BM, int ACT, int DMAF = 0>
+int launch_pps_t(const GemmArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  const size_t lds_bytes = 5 * 32768;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, DMAF>, (int)lds_bytes)) return r_;
+  const double flops = 2.0 * a.M * (double)a.N * a.K;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
+  prof_begin(s);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, DMAF>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  prof_end(s, flops, bytes, 0);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// span in bytes of the rows of A (implicit-conv rows overlap): the last row's end
+static unsigned long a_span_bytes(const GemmArgs& a) {
+  const long last = (long)a.M - 1;
+  return (unsigned long)(((last / a.a_rpb) * a.a_bstride + (last % a.a_rpb) * a.a_rstride + a.K) * 2);
+}
+
+bool gemm_pps_eligible(const GemmArgs& a) {
+  return !a.gen && a.nz == 1 && !a.resid && !a.out_f32 && !a.planes && a.alpha == 1.f && (a.act == ACT_NONE || a.act == ACT_GELU) &&
+         a.K % 64 == 0 && a.K >= 128 && a.N % 256 == 0 && a.M >= 128 && a.c_vec && a.ldc % 8 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
+         a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0 && a_span_bytes(a) < 0xFFFF0000ul &&
+         (unsigned long)a.N * a.ldw * 2 < 0xFFFF0000ul && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 &&
+         (a.a_rstride & 7) == 0 && (a.a_bstride & 7) == 0 && (a.ldw & 7) == 0;
+}
+
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int dma_form) {
+  if (dma_form == 1) {   // A/B of the LDS-DMA issue form (diagnostics)
+    if (a.act == ACT_GELU) return bm == 256 ? launch_pps_t<256, ACT_GELU, 1>(a, s) : launch_pps_t<192, ACT_GELU, 1>(a, s);
+    return bm == 256 ? launch_pps_t<256, ACT_NONE, 1>(a, s) : launch_pps_t<192, ACT_NONE, 1>(a, s);
+  }
+  if (a.act == ACT_GELU) {
+    if (bm == 256) return launch_pps_t<256, ACT_GELU>(a, s);
+    if (bm == 192) return launch_pps_t<192, ACT_GELU>(a, s);
+    return launch_pps_t<128, ACT_GELU>(a, s);
+  }
+  if (bm == 256) return launch_pps_t<256, ACT_NONE>(a, s);
+  if (bm == 192) return launch_pps_t<192, ACT_NONE>(a, s);
+  return launch_pps_t<128, ACT_NONE>(a, s);
+}
+
+}  // namespace svt

@@ -184,11 +184,7 @@ int launch_skinny(const GemmArgs& a, hipStream_t s) {
   const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.nz + (double)a.M * a.N * a.nz * (a.out_f32 ? 4 : 2);
   const size_t lds_bytes = 4 * TS * (TS + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)gemm_skinny_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)gemm_skinny_kernel<NB>, (int)lds_bytes)) return r_;
   prof_begin(s);
   hipLaunchKernelGGL((gemm_skinny_kernel<NB>), dim3(tiles_m * tiles_n, a.nz, 1), dim3(256), lds_bytes, s, a);
   prof_end(s, flops, bytes, 1);

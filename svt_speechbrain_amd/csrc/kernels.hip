@@ -1450,11 +1450,8 @@ int launch_add_f32(const float* a, const float* b, float* out, int64_t n, hipStr
 template <int KC>
 static int launch_linear_head_kc(const float* x, int64_t rows, const float* w, const float* b, int N, float* y, hipStream_t s) {
   const size_t lds = (size_t)N * KC * 256 * 4;
-  static size_t attr = 0;
-  if (lds > 65536 && lds > attr) {
-    SVT_HIP(hipFuncSetAttribute((const void*)linear_head_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
-  }
+  if (lds > 65536)
+    if (int r_ = ensure_dyn_lds((const void*)linear_head_kernel<KC>, (int)lds)) return r_;
   const int64_t groups = (rows + 15) / 16;
   const unsigned grid = (unsigned)(groups < 512 ? groups : 512);
   hipLaunchKernelGGL((linear_head_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, b, N, y);
@@ -1474,11 +1471,7 @@ int launch_linear_head(const float* x, int64_t rows, int K, const float* w, cons
 template <int KC>
 static int launch_head_dots_kc(const float* x, int64_t rows, const float* w, int N, float* dots, double* mom, int64_t rpg, hipStream_t s) {
   const size_t lds = (size_t)N * KC * 256 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SVT_HIP(hipFuncSetAttribute((const void*)head_dots_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * KC * 256 * 4));
-    attr_set = true;
-  }
+  if (int r_ = ensure_dyn_lds((const void*)head_dots_kernel<KC>, 32 * KC * 256 * 4)) return r_;
   const int64_t groups = (rows + 15) / 16;
   const unsigned grid = (unsigned)(groups < 512 ? groups : 512);
   hipLaunchKernelGGL((head_dots_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, N, dots, mom, rpg);

@@ -240,11 +240,7 @@ int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bi
   if (prec) {
     const size_t lds_bytes = (size_t)5 * Hp * Wp * 2;
     if (lds_bytes > 160 * 1024) { set_error("video front-end: the lip ROI is too large for the LDS-resident stem (5 frames must fit 160 KB)"); return -1; }
-    static size_t attr = 0;
-    if (lds_bytes > attr) {
-      SVT_HIP(hipFuncSetAttribute((const void*)conv3d_front_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      attr = lds_bytes;
-    }
+    if (int r_ = ensure_dyn_lds((const void*)conv3d_front_bf16_kernel, (int)lds_bytes)) return r_;
     prof_begin(s);
     hipLaunchKernelGGL(conv3d_front_bf16_kernel, dim3((unsigned)F), dim3(512), lds_bytes, s, (const bf16_t*)vp, (const uint4*)w, bias,
                        slope, T, Hp, Wp, H0, W0, (bf16_t*)out);

@@ -14,12 +14,12 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._device import DeviceObjects
+from ._device import DeviceObjects, ReplicaAware
 from .huggingface_interface import ParamTree, PRECISIONS, LIB_VARIANT
 from .weights import seeded_fusion_state_dict
 
 
-class FusionRCA(nn.Module):
+class FusionRCA(ReplicaAware, nn.Module):
     def __init__(self, alpha=0.5, nhead=8, d_ffn=3072, d_model=1024, *, precision=None, max_length=2500, seed=3986):
         super().__init__()
         import os
@@ -56,7 +56,8 @@ class FusionRCA(nn.Module):
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision, float(self.alpha)))
-        sig = tuple((t.data_ptr(), t._version) for _, t in self._tensors())
+        src = self._param_owner()   # a DataParallel replica reads the ORIGINAL's tensors (its own tree holds no parameters)
+        sig = tuple((t.data_ptr(), t._version) for _, t in src._tensors())
         if slot.handle is not None and sig == slot.sig:
             return slot
         if slot.handle is None:
@@ -64,7 +65,7 @@ class FusionRCA(nn.Module):
             _lib.check(lib.svt_rca_create(self.d_model, self.nhead, self.d_ffn, float(self.alpha), self.max_length,
                                           PRECISIONS[self.precision], idx, C.byref(h)), "svt_rca_create", lib)
             slot.handle = h
-        for name, t in self._tensors():
+        for name, t in src._tensors():
             c = t.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * c.dim())(*c.shape)
             _lib.check(lib.svt_rca_load_param(slot.handle, name.encode(), C.c_void_p(c.data_ptr()), 0, shape, c.dim()),

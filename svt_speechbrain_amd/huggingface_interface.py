@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._device import DeviceObjects
+from ._device import DeviceObjects, ReplicaAware
 from .config import EncoderConfig, PRESETS, config_from_source
 from .weights import encoder_param_shapes, seeded_encoder_state_dict
 
@@ -125,7 +125,7 @@ class _DevF64:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
-class HuggingFaceWav2Vec2(nn.Module):
+class HuggingFaceWav2Vec2(ReplicaAware, nn.Module):
     """wav2vec 2.0 / HuBERT encoder on MI355X with the reference wrapper's surface.
 
     Arguments (reference ``huggingface_interface.py:89-98``)
@@ -378,17 +378,22 @@ class HuggingFaceWav2Vec2(nn.Module):
             cc = _config_to_c(self.config, self.normalize_wav, self.output_norm, self.precision)
             _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create", lib)
             slot.handle = h
-        for name, p in self.model.state_dict().items():
-            if not p.is_floating_point():
-                continue  # BatchNorm's num_batches_tracked
+        src = self._param_owner()   # a DataParallel replica uploads the ORIGINAL's parameters (its own tree has none)
+        for name, p in src._upload_items():
             t = p.detach().to("cpu", torch.float32).contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(lib.svt_encoder_load_param(slot.handle, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
                                                   t.dim()), f"svt_encoder_load_param({name})", lib)
         _lib.check(lib.svt_encoder_finalize(slot.handle), "svt_encoder_finalize", lib)
-        slot.sig = (None if self.freeze else self._params_signature(), self._sentinel())
+        slot.sig = (None if self.freeze else src._params_signature(), src._sentinel())
         slot.gen = gen
         return slot
+
+    def _upload_items(self):
+        """(name, tensor) of everything svt_encoder_load_param receives, read from THIS module's tree."""
+        for name, p in self.model.state_dict().items():
+            if p.is_floating_point():   # not BatchNorm's num_batches_tracked
+                yield name, p
 
     def _sentinel(self):
         ts = list(self.model.parameters())
@@ -482,7 +487,7 @@ class HuggingFaceWav2Vec2(nn.Module):
             raise _lib.SvtError("the MI355X encoder needs its input on the GPU ('cuda:N'); there is no CPU fallback")
         lib = self._lib()
         slot = self._sync_device(wav.device)
-        hslot = head._sync(wav.device)
+        hslot = head._sync(wav.device, LIB_VARIANT.get(self.precision))   # the head's C object lives in the encoder's library build
         x = wav.detach().to(torch.float32).contiguous()
         B, L = x.shape
         T = self.config.frames(L)

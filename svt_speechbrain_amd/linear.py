@@ -10,10 +10,10 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._device import DeviceObjects
+from ._device import DeviceObjects, ReplicaAware
 
 
-class Linear(nn.Module):
+class Linear(ReplicaAware, nn.Module):
     def __init__(self, n_neurons, input_shape=None, input_size=None, bias=True, combine_dims=False):
         super().__init__()
         self.combine_dims = combine_dims
@@ -24,26 +24,37 @@ class Linear(nn.Module):
             if len(input_shape) == 4 and self.combine_dims:
                 input_size = input_shape[2] * input_shape[3]
         self.w = nn.Linear(input_size, n_neurons, bias=bias)
-        self._dev = DeviceObjects("svt_linear_destroy")  # one C object per device, shared with DataParallel replicas
+        # one C object per device AND per build of the library ("" = libsvt_mi355.so, "f16" = the IEEE-half build): a handle is
+        # only ever handed to the library that created it (each build has its own allocator state, registries and last_error)
+        self._devs = {"": DeviceObjects("svt_linear_destroy")}
+        self._dev = self._devs[""]
 
-    def _sync(self, device):
-        lib = _lib.load()
+    def _upload_items(self):
+        return self.w.weight, self.w.bias
+
+    def _sync(self, device, lib_variant: str = None):
+        """The head's C object on ``device`` inside the library build ``lib_variant`` (the fused tail of an encoder that lives in
+        the IEEE-half build asks for "f16"); shared with DataParallel replicas, which upload the original's parameters."""
+        lib = _lib.load(lib_variant)
         _lib.require_gpu()
         idx = _lib.dev_index(device)
-        slot = self._dev.slot(idx, (self.w.in_features, self.w.out_features, self.w.bias is not None))
-        sig = (self.w.weight.data_ptr(), self.w.weight._version,
-               None if self.w.bias is None else (self.w.bias.data_ptr(), self.w.bias._version))
+        key = lib_variant or ""
+        if key not in self._devs:
+            self._devs[key] = DeviceObjects("svt_linear_destroy", lib_variant)
+        slot = self._devs[key].slot(idx, (self.w.in_features, self.w.out_features, self.w.bias is not None))
+        weight, bias = self._param_owner()._upload_items()
+        sig = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version))
         if slot.handle is not None and sig == slot.sig:
             return slot
         if slot.handle is None:
             h = C.c_void_p()
-            _lib.check(lib.svt_linear_create(self.w.in_features, self.w.out_features, int(self.w.bias is not None), idx,
-                                             C.byref(h)), "svt_linear_create")
+            _lib.check(lib.svt_linear_create(self.w.in_features, self.w.out_features, int(bias is not None), idx,
+                                             C.byref(h)), "svt_linear_create", lib)
             slot.handle = h
-        w = self.w.weight.detach().to("cpu", torch.float32).contiguous()
-        b = None if self.w.bias is None else self.w.bias.detach().to("cpu", torch.float32).contiguous()
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
         _lib.check(lib.svt_linear_load(slot.handle, C.c_void_p(w.data_ptr()),
-                                       C.c_void_p(b.data_ptr()) if b is not None else None), "svt_linear_load")
+                                       C.c_void_p(b.data_ptr()) if b is not None else None), "svt_linear_load", lib)
         slot.sig = sig
         return slot
 

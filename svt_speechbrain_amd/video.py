@@ -17,12 +17,12 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._device import DeviceObjects
+from ._device import DeviceObjects, ReplicaAware
 from .huggingface_interface import ParamTree, PRECISIONS, LIB_VARIANT
 from .weights import seeded_video_frontend_state_dict
 
 
-class SubModel(nn.Module):
+class SubModel(ReplicaAware, nn.Module):
     def __init__(self, input_dim=512, embed_dim=1024, relu_type="prelu", weights=None, *, precision=None, seed=4986):
         super().__init__()
         if input_dim != 512:
@@ -66,14 +66,15 @@ class SubModel(nn.Module):
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision,))
-        sig = tuple((t.data_ptr(), t._version) for _, t in self._tensors())
+        src = self._param_owner()   # a DataParallel replica reads the ORIGINAL's tensors (its own tree holds no parameters)
+        sig = tuple((t.data_ptr(), t._version) for _, t in src._tensors())
         if slot.handle is not None and sig == slot.sig:
             return slot
         if slot.handle is None:
             h = C.c_void_p()
             _lib.check(lib.svt_video_create(self.embed_dim, PRECISIONS[self.precision], idx, C.byref(h)), "svt_video_create", lib)
             slot.handle = h
-        for name, t in self._tensors():
+        for name, t in src._tensors():
             if name.endswith("num_batches_tracked"):
                 continue
             c = t.detach().to("cpu", torch.float32).contiguous()
@@ -116,7 +117,7 @@ from .weights import seeded_avhubert_video_state_dict, fairseq_to_hf_key  # noqa
 _IGNORED_PREFIXES = ("mask_emb", "label_embs_concat", "final_proj.", "target_glu.", "feature_extractor_audio.")
 
 
-class FairseqAVHubertPretrain(nn.Module):
+class FairseqAVHubertPretrain(ReplicaAware, nn.Module):
     """Drop-in for ``N20EMv2/video_only/fairseq_interface.py:350-499`` on the video modality: ``forward({"video": x,
     "audio": None})`` with ``x`` the ``(B, 1, T, H, W)`` lip ROI returns the ``(B, T, D)`` AV-HuBERT encoding
     (``extract_finetune``, ``hubert.py:688-739``: front-end -> cat([zeros, video]) -> LayerNorm -> post_extract_proj ->
@@ -201,7 +202,8 @@ class FairseqAVHubertPretrain(nn.Module):
         _lib.require_gpu()
         idx = _lib.dev_index(device)
         slot = self._dev.slot(idx, (self.precision, bool(self.output_norm)))
-        sig = tuple((p.data_ptr(), p._version) for _, p in self._transformer_tensors())
+        src = self._param_owner()   # a DataParallel replica reads the ORIGINAL's tensors
+        sig = tuple((p.data_ptr(), p._version) for _, p in src._transformer_tensors())
         if slot.handle is not None and sig == slot.sig:
             return slot
         if slot.handle is None:
@@ -209,7 +211,7 @@ class FairseqAVHubertPretrain(nn.Module):
             cc = _config_to_c(self.config, False, bool(self.output_norm), self.precision)
             _lib.check(lib.svt_encoder_create(C.byref(cc), idx, C.byref(h)), "svt_encoder_create", lib)
             slot.handle = h
-        for name, p in self._transformer_tensors():
+        for name, p in src._transformer_tensors():
             hf = fairseq_to_hf_key(name)
             if hf is None:
                 raise _lib.SvtError(f"no encoder slot for parameter {name}")

@@ -45,3 +45,19 @@ def test_two_ranks_frames_gather_with_global_norms():
     assert j["verified"] is True and j["rccl_ranks"] == 2
     c = j["collective"]
     assert c["payload"] == "frames" and c["bytes_per_rank_per_step"] == 3 * 99 * 16 and c["norm_all_reduce"]
+
+
+def test_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE): bench.py starts two fresh ranks itself, before any GPU call,
+    and relays rank 0's JSON line -- n_gpus == rccl_ranks == 2 (the driver's 8-GPU run must not silently time one rank)."""
+    env = dict(os.environ, SVT_SHARE_GPU="1", SVT_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seconds", "2",
+           "--no-cpu-baseline", "--no-extra-legs", "--verify"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["verified"] is True and j["config"]["global_batch"] == 4
+    assert "launching 2 ranks" in r.stderr

@@ -536,6 +536,83 @@ def test_replica_and_data_parallel_replica_device_state():
     d.close()
 
 
+def simulated_replicate(net):
+    """What ``torch.nn.parallel.replicate`` does to a module tree, without devices: every module is shallow-copied by its own
+    ``_replicate_for_data_parallel`` (which empties ``_parameters``), children are re-linked to the copies, and the broadcast
+    parameter copies (here: clones) become PLAIN attributes -- so ``parameters()`` / ``state_dict()`` of a replica hold no weights."""
+    mods = list(net.modules())
+    idx = {id(m): i for i, m in enumerate(mods)}
+    copies = [m._replicate_for_data_parallel() for m in mods]
+    for m, r in zip(mods, copies):
+        for k, child in m._modules.items():
+            r._modules[k] = None if child is None else copies[idx[id(child)]]
+        for k, p_ in m._parameters.items():
+            if p_ is not None:
+                setattr(r, k, p_.detach().clone())
+    return copies[0]
+
+
+def test_data_parallel_replica_uploads_the_original_parameters():
+    """A REAL replica has no parameters of its own (``replicate`` hangs per-forward copies on it as plain attributes): the upload
+    loop and the change signature of a replica must walk the module it was replicated from."""
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg)
+    rep = simulated_replicate(enc)
+    assert rep is not enc and rep._param_owner() is enc and "_dp_origin" not in rep._modules
+    assert len(list(rep.model.parameters())) == 0          # the trap: nothing to upload from the replica's own tree
+    own = {k for k, v in enc.model.state_dict().items() if v.is_floating_point()}
+    got = dict(rep._param_owner()._upload_items())
+    assert set(got) == own and len(own) > 20
+    assert rep._param_owner()._sentinel() == enc._sentinel()
+    # a replica of a replica (nested DataParallel) still points at the original
+    assert simulated_replicate(rep)._param_owner() is enc
+    head = S.Linear(20, input_size=64)
+    hr = simulated_replicate(head)
+    w, b = hr._param_owner()._upload_items()
+    assert w is head.w.weight and b is head.w.bias and hr._devs is head._devs
+    fus = S.FusionRCA(d_model=64, nhead=8, d_ffn=128, max_length=50)
+    fr = simulated_replicate(fus)
+    assert len(list(fr.fusion.parameters())) == 0
+    assert [n for n, _ in fr._param_owner()._tensors()] == [n for n, _ in fus._tensors()] and len(list(fus._tensors())) > 10
+    from svt_speechbrain_amd.video import SubModel
+    sm = SubModel(embed_dim=32)
+    sr = simulated_replicate(sm)
+    assert [n for n, _ in sr._param_owner()._tensors()] == [n for n, _ in sm._tensors()]
+
+
+def test_amt_forward_accepts_both_recipes_module_names():
+    """The audio-visual recipe names its modules ``fusion`` + ``head`` (train_rca_av.py:39,44 / its yaml ``modules:``), the
+    audio-only ones ``wav2vec2`` + ``model`` (train_audio_ssl.py:36-39)."""
+    calls = []
+
+    class M:
+        def __init__(self, tag): self.tag = tag
+        def __call__(self, *a):
+            calls.append(self.tag)
+            return torch.zeros(2, 5, 20) if self.tag != "fusion" else torch.zeros(2, 5, 8)
+    amt = S.AMTForward({"fusion": M("fusion"), "head": M("head")})
+    out = amt.compute_forward(torch.zeros(2, 5, 8), torch.ones(2), videos=torch.zeros(2, 5, 8))
+    assert calls == ["fusion", "head"] and len(out) == 5 and out[2].shape == (2, 5, 5) and out[3].shape == (2, 5, 13)
+    calls.clear()
+    S.AMTForward({"fusion": M("fusion"), "model": M("model")}).compute_forward(torch.zeros(2, 5, 8), None, videos=torch.zeros(2, 5, 8))
+    assert calls == ["fusion", "model"]
+    with pytest.raises(KeyError):
+        S.AMTForward({"fusion": M("fusion")}).compute_forward(torch.zeros(2, 5, 8), None, videos=torch.zeros(2, 5, 8))
+    # the fused tail re-associates the out-norm and the head: default only in the throughput precisions
+    assert S.AMTForward({}).fuse_tail is None
+
+
+def test_bench_refuses_a_rank_count_mismatch_and_lib_variant_path():
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])
+    # the IEEE-half build's file name is derived from the SUFFIX of the library path only
+    root, ext = os.path.splitext(_lib.LIB_PATH)
+    assert ext == ".so" and os.path.exists(f"{root}_f16{ext}")
+
+
 def test_local_directory_picks_the_weights_file_and_reads_shards(tmp_path):
     """A Trainer output directory holds optimizer.bin / training_args.bin beside the weights, and large checkpoints come as
     shards with an index: the wrapper must load pytorch_model.bin (or the shards), never the alphabetically first *.bin."""

@@ -20,7 +20,13 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("out_proj", 15968, 768, 768, None, 0, 1, 0),
     ("ffn1", 15968, 3072, 768, None, 1, 0, 0),
     ("ffn2", 15968, 768, 3072, None, 0, 1, 0),
+    ("out_b", 15968, 768, 768, None, 0, 0, 0),        # bf16 branch outputs (what the bf16-mode encoder asks for)
+    ("ffn2_b", 15968, 768, 3072, None, 0, 0, 0),
+    ("conv4_plain", 32 * 1999, 512, 1536, None, 1, 0, 0),   # conv4's product with non-overlapping rows (pitch 3072 B)
     ("large_ffn1", 31936, 4096, 1024, None, 1, 0, 0),
+    ("large_ffn2_b", 31936, 1024, 4096, None, 0, 0, 0),
+    ("large_out_b", 31936, 1024, 1024, None, 0, 0, 0),
+    ("large_conv1", 64 * 15999, 512, 1536, (31999, 15999, 2, 512), 0, 0, 0),   # layer-norm conv stack: no activation in the GEMM
     ("large_ffn2", 31936, 1024, 4096, None, 0, 1, 0),
     ("large_qkv", 31936, 3072, 1024, None, 0, 0, 0),
     ("large_out", 31936, 1024, 1024, None, 0, 1, 0),
@@ -46,7 +52,33 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
 ]
 
 
-def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nobias=False):
+def full_check(A, W, bias, C, conv, M, N, K, act, chunk=16384):
+    """every row of C against an fp32 torch product (checker only; chunks keep the fp32 copies small)"""
+    worst = 0.0
+    dev = A.device
+    Wf = W[:, :K].float().t().contiguous()
+    if conv:
+        T_in, T_out, st, cin = conv
+        k = K // cin
+        B = M // T_out
+        idx = (torch.arange(T_out, device=dev) * st)[:, None] + torch.arange(k, device=dev)[None, :]
+        for b0 in range(B):
+            ref = A[b0, idx].reshape(T_out, K).float() @ Wf + bias
+            if act == 1:
+                ref = torch.nn.functional.gelu(ref)
+            got = C[b0 * T_out:(b0 + 1) * T_out].float()
+            worst = max(worst, ((got - ref).abs() / (1.0 + ref.abs())).max().item())
+    else:
+        for r0 in range(0, M, chunk):
+            ref = A[r0:r0 + chunk, :K].float() @ Wf + bias
+            if act == 1:
+                ref = torch.nn.functional.gelu(ref)
+            got = C[r0:r0 + chunk].float()
+            worst = max(worst, ((got - ref).abs() / (1.0 + ref.abs())).max().item())
+    return worst
+
+
+def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nobias=False, fullcheck=False):
     lib = _lib.load()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if prec == 1 else torch.float32  # prec 2 / 3: split-operand engine, fp32 operands in memory
@@ -73,10 +105,13 @@ def run(name, M, N, K, conv, act, out_f32, resid, prec, check, iters, pad=0, nob
                                       R.data_ptr() if resid else None, M, N, K, rpb, bstr, rstr, ldw, act, out_f32, 0, st_),
                    "svt_debug_gemm")
 
+    C.fill_(float("nan"))
     call()
     torch.cuda.synchronize()
     err = None
-    if check:
+    if fullcheck and not resid:
+        err = full_check(A, W, bias, C, conv, M, N, K, act)
+    elif check:
         if conv:
             T_in, T_out, st, cin = conv
             k = K // cin
@@ -112,6 +147,8 @@ if __name__ == "__main__":
     ap.add_argument("--prec", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--names", default=None, help="comma-separated exact shape names")
+    ap.add_argument("--fullcheck", action="store_true", help="compare EVERY output row with an fp32 torch product (relative to 1 + |ref|)")
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--bm", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0)
@@ -133,4 +170,6 @@ if __name__ == "__main__":
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
-        run(*s, a.prec, a.check, a.iters, a.pad, a.nobias)
+        if a.names and s[0] not in a.names.split(","):
+            continue
+        run(*s, a.prec, a.check, a.iters, a.pad, a.nobias, a.fullcheck)

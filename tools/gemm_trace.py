@@ -23,13 +23,16 @@ def main():
                     help="run the kernel back to back for this long before the stamped launch (the clock the chip holds under "
                          "load: MI355X_MICROARCH.md 'DVFS give-back' item 6 asks for >= 2 s)")
     ap.add_argument("--variant", type=int, default=0, help="extra diagnostic variant: 10 = no stores, 11 = no pointer setup")
+    ap.add_argument("--force-variant", type=int, default=0, help="svt_debug_set key 3 for the whole run (50 = the persistent staggered kernel, "
+                    "51 / 53 / 54 = without LDS-DMA / epilogue / both)")
     a = ap.parse_args()
     lib = _lib.load()
     lib.svt_debug_set(1, a.bm)
     lib.svt_debug_set(2, a.ring)
+    lib.svt_debug_set(3, a.force_variant)
     dev = torch.device("cuda:0")
     for name, M, N, K, conv, act, out_f32, resid in SHAPES:
-        if a.only not in name:
+        if a.only != name and not (a.only not in [x[0] for x in SHAPES] and a.only in name):
             continue
         g = torch.Generator().manual_seed(1)
         if conv:
@@ -83,10 +86,18 @@ def main():
         print(f"  main loop   (sum over tiles)     : mean {(t[:,2]*us).mean():.2f}  max {(t[:,2]*us).max():.2f} us   per tile {(t[:,2]/t[:,5]*us).mean():.2f}")
         print(f"  epilogue    (sum over tiles)     : mean {(t[:,3]*us).mean():.2f}  max {(t[:,3]*us).max():.2f} us   per tile {(t[:,3]/t[:,5]*us).mean():.2f}")
         print(f"  exit        (end - first begin)  : mean {((t[:,4]-t0)*us).mean():.2f}  min {((t[:,4]-t0)*us).min():.2f} max {((t[:,4]-t0)*us).max():.2f} us")
-        if (t[:, 6] > 0).any():
+        if (t[:, 6] > 0).any() and a.force_variant >= 50:
+            # persistent staggered kernel: core clocks over the whole stream (first slab ready .. exit), all tiles of the workgroup
+            mhz = (t[:, 6] / (t[:, 4] - t[:, 1]).clamp(min=1)) * 100.0
+            clk = mhz.median().item() * 1e6
+            busy = (2.0 * t[:, 7] * 256 * K * t[:, 5]) / (t[:, 2] * 1e-8) / (4 * 1024 * clk)
+            nk = K // 64
+            print(f"  per K slab (main loop / slabs): mean {(t[:,2] / (t[:,5] * nk) * us).mean():.3f} us   per epilogue: mean {(t[:,3] / t[:,5] * us).mean():.2f} us")
+        elif (t[:, 6] > 0).any():
             mhz = (t[:, 6] / t[:, 2].clamp(min=1)) * 100.0
             clk = mhz.median().item() * 1e6
             busy = (2.0 * t[:, 7] * 256 * K) / (t[:, 2] * 1e-8) / (4 * 1024 * clk)   # per workgroup = per CU
+        if (t[:, 6] > 0).any():
             print(f"  core clock over the main loop (s_memtime / s_memrealtime): median {mhz.median():.0f} MHz "
                   f"(min {mhz.min():.0f}, max {mhz.max():.0f}); MFMA pipe busy for {busy.mean():.2f} of the main-loop cycles "
                   f"(1024 bf16 FLOP/clk/SIMD)")

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 import gemm_bench  # noqa: E402
 
-NAMES = ["conv1", "conv2", "conv3", "proj", "qkv", "out_proj", "ffn1", "ffn2", "large_ffn1", "s35_qkv", "s35_ffn1", "s35_ffn2",
-         "sq4096", "sq8192"]
+NAMES = ["conv1", "conv2", "conv3", "conv4", "conv5", "proj", "qkv", "out_b", "ffn1", "ffn2_b", "large_qkv", "large_out_b", "large_ffn1",
+         "large_ffn2_b", "s35_qkv", "s35_ffn1", "s35_ffn2", "sq4096", "sq8192"]
 
 
 def library(M, N, K, iters):
@@ -37,14 +37,22 @@ def library(M, N, K, iters):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--variants", default="0", help="comma-separated svt_debug_set key-3 values to time on this build's side (0 = default dispatch)")
+    ap.add_argument("--names", default=None)
+    ap.add_argument("--no-library", action="store_true")
     a = ap.parse_args()
     from svt_speechbrain_amd import _lib
     _lib.load().svt_debug_set(12, 1)
     print(f"torch {torch.__version__}  blas backend: {torch.backends.cuda.preferred_blas_library()}")
     for s in gemm_bench.SHAPES:
-        if s[0] not in NAMES:
+        if s[0] not in (a.names.split(",") if a.names else NAMES):
             continue
         name, M, N, K = s[:4]
-        ms = library(M, N, K, a.iters)
-        print(f"{name:12s} M={M:7d} N={N:5d} K={K:5d} library (plain GEMM + bias)      {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
-        gemm_bench.run(*s, 1, False, a.iters)
+        ms = 0.0 if a.no_library else library(M, N, K, a.iters)
+        if not a.no_library:
+            print(f"{name:12s} M={M:7d} N={N:5d} K={K:5d} library (plain GEMM + bias)      {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        for v in a.variants.split(","):
+            _lib.load().svt_debug_set(3, int(v))
+            print(f"  variant {v:>3s}: ", end="")
+            gemm_bench.run(*s, 1, False, a.iters)
+        _lib.load().svt_debug_set(3, 0)
