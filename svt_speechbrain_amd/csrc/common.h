@@ -179,7 +179,7 @@ bool gemm_dma_eligible(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
 // persistent + staggered form of the LDS-DMA pipeline (gemm_pps.hip): bf16 output, no residual, activation none / GELU
 bool gemm_pps_eligible(const GemmArgs& a);
-int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int dma_form = 0);
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy = 0);   // 0 default, 1 nt, 2 sc1 stores
 // small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
 bool gemm_skinny_eligible(const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);

@@ -949,6 +949,203 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* ws
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staggered form of gemm_x3_kernel (round 3).  The lockstep kernel above kept the matrix pipe busy for 0.43 of its cycles: all eight
+// waves read their W fragments, issue their LDS-DMA and cut their A pieces at the same moments, so the two waves of a SIMD never
+// cover each other.  Here waves 4-7 run ONE SLOT behind waves 0-3, exactly like gemm_pp8_kernel: a 32-deep slab is four MMA slots of
+// NBS W blocks x 2 row blocks x 3 products (24 MFMAs at NBS = 4) and four LOAD slots that carry the next slot's W fragment reads
+// (hi + lo pieces), two LDS-DMA instructions of the ring, and -- for the NEXT slab -- the raw fp32 reads of this wave's A rows (slot 0)
+// and their cuts into (hi, lo) pieces (slots 1 and 2).  On every SIMD one wave multiplies while its partner loads.
+// Ring (five 32 KiB slots, unit u = 2g (A_g) / 2g + 1 (W_g) in slot u % 5): slab g reads W_g and, for cutting, A_{g+1}; it requests
+// A_{g+2} during its first two LOAD slots (into the slot W_{g-1} left) and W_{g+2} during the last two (into the slot of A_g, which has
+// lived in registers since slab g - 1); the counted wait that retires the slab leaves only W_{g+2} in flight.  Requests past the last
+// slab re-read slab nk - 1 (never used) so that the counts stay constant; one vmcnt(0) drains them before the LDS-transposed epilogue.
+// NBS = 4: 256-column tiles; NBS = 3: 192-column tiles (N = 768: 63 x 4 = 252 tiles fill the 256 CUs; 256-column tiles give 189).
+typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));   // register image of a 16-byte fragment (an ext vector: usable as an asm operand)
+template <bool F16, int NBS>
+__global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* wsplit) {
+  constexpr int BM = 256, BN = 64 * NBS, BK = 32, NSLOT = 5, SLOT = 2048, GA = 4, GW = NBS;
+  constexpr int NB = 4 * NBS;   // 16-column W blocks per tile
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* A = (const float*)p.A;
+  const unsigned short* W = (const unsigned short*)wsplit;  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
+  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
+  const float* asrc[GA];
+  const unsigned short* wsrc[GW];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    int m = m0 + (wave + 8 * i) * 8 + r8;
+    if (m > p.M - 1) m = p.M - 1;
+    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < GW; ++i) {
+    const int rho = (wave + 8 * i) * 8 + r8;
+    const int i16 = rho & 15;
+    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
+    if (n > p.N - 1) n = p.N - 1;
+    wsrc[i] = W + (long)n * (2 * p.K) + ch * 8;
+  }
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds);
+  auto unit_addr = [&](int slot, int i) -> unsigned {
+    return __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u);
+  };
+  const int nk = p.K / BK;
+  auto kc = [&](int k) { return k < nk ? k : nk - 1; };   // requests past the end re-read the last slab
+  f32x4 acc[NB][2];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
+  const int rowb = (r16 >> 3) * 64 + rr8 * 8;
+  const int fa0 = rowb + ((2 * cq) ^ rr8), fa1 = rowb + ((2 * cq + 1) ^ rr8);
+  const int fwh = rowb + (cq ^ rr8), fwl = rowb + ((4 + cq) ^ rr8);
+  const x3_u32x4* ldsv = (const x3_u32x4*)lds;
+  auto mma = [&](const x3_u32x4& a, const x3_u32x4& b, const f32x4& c) -> f32x4 {
+    if constexpr (F16) {
+      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+    } else {
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(real_bf16x8, a), __builtin_bit_cast(real_bf16x8, b), c, 0, 0, 0);
+    }
+  };
+  auto cut = [&](const x3_u32x4& r0, const x3_u32x4& r1, x3_u32x4& hi, x3_u32x4& lo) {
+    const f32x4 v0 = __builtin_bit_cast(f32x4, r0), v1 = __builtin_bit_cast(f32x4, r1);
+    if constexpr (F16) {
+      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+      f16x8v h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)v0[j]; l[j] = (_Float16)(v0[j] - (float)h[j]);
+        h[4 + j] = (_Float16)v1[j]; l[4 + j] = (_Float16)(v1[j] - (float)h[4 + j]);
+      }
+      hi = __builtin_bit_cast(x3_u32x4, h);
+      lo = __builtin_bit_cast(x3_u32x4, l);
+    } else {
+      bf16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (bf16_t)v0[j]; l[j] = (bf16_t)(v0[j] - (float)h[j]);
+        h[4 + j] = (bf16_t)v1[j]; l[4 + j] = (bf16_t)(v1[j] - (float)h[4 + j]);
+      }
+      hi = __builtin_bit_cast(x3_u32x4, h);
+      lo = __builtin_bit_cast(x3_u32x4, l);
+    }
+  };
+  // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2, W_1 -> slot 3; everything but W_1 landed before slab 0
+#pragma unroll
+  for (int i = 0; i < GA; ++i) dma16_asm(asrc[i], unit_addr(0, i));
+#pragma unroll
+  for (int i = 0; i < GW; ++i) dma16_asm(wsrc[i], unit_addr(1, i));
+#pragma unroll
+  for (int i = 0; i < GA; ++i) dma16_asm(asrc[i] + kc(1) * BK, unit_addr(2, i));
+#pragma unroll
+  for (int i = 0; i < GW; ++i) dma16_asm(wsrc[i] + kc(1) * 64, unit_addr(3, i));
+  wait_vm<GW>();
+  __builtin_amdgcn_s_barrier();
+  x3_u32x4 xh[2], xl[2], nh[2], nl[2], raw[2][2], wh[NBS], wl[NBS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) cut(ldsv[(wave * 2 + mb) * 128 + fa0], ldsv[(wave * 2 + mb) * 128 + fa1], xh[mb], xl[mb]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave holds its pieces of A_0 before the first slab's requests may reuse slots
+  int sw = 1;                     // slot of W_g; A_{g+1} sits in the next one
+  const int grp = wave >> 2;
+#define X3S_LOAD(Q)                                                                                                 \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NBS; ++i) {                                                               \
+      wh[i] = wa[((Q) * NBS + i) * 128 + fwh];                                                                      \
+      wl[i] = wa[((Q) * NBS + i) * 128 + fwl];                                                                      \
+    }                                                                                                               \
+    if ((Q) == 0) {                                                                                                 \
+      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { raw[mb][0] = xn[mb * 128 + fa0]; raw[mb][1] = xn[mb * 128 + fa1]; } \
+    }                                                                                                               \
+    if ((Q) < 2) {   /* A_{g+2} -> the slot W_{g-1} left */                                                         \
+      _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
+          dma16_asm(asrc[i2] + (long)kc(g + 2) * BK, unit_addr((sw + 3) % NSLOT, i2));                              \
+    } else {         /* W_{g+2} -> the slot of A_g */                                                               \
+      _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) == 2 ? 2 : GW); ++i2)                                \
+          dma16_asm(wsrc[i2] + (long)kc(g + 2) * 64, unit_addr((sw + 4) % NSLOT, i2));                              \
+    }                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    if ((Q) == 0) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]));            \
+    _Pragma("unroll") for (int i = 0; i < NBS; ++i) asm volatile("" : "+v"(wh[i]), "+v"(wl[i]));                    \
+    if ((Q) == 1) cut(raw[0][0], raw[0][1], nh[0], nl[0]);                                                          \
+    if ((Q) == 2) cut(raw[1][0], raw[1][1], nh[1], nl[1]);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define X3S_MMA(Q)                                                                                                  \
+  {                                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NBS; ++i) {                                                               \
+      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[(Q) * NBS + i][mb] = mma(wl[i], xh[mb], acc[(Q) * NBS + i][mb]); \
+      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[(Q) * NBS + i][mb] = mma(wh[i], xl[mb], acc[(Q) * NBS + i][mb]); \
+      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) acc[(Q) * NBS + i][mb] = mma(wh[i], xh[mb], acc[(Q) * NBS + i][mb]); \
+    }                                                                                                               \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define X3S_VARS()                                                                                                  \
+  const x3_u32x4* wa = ldsv + sw * SLOT;                                                                            \
+  const x3_u32x4* xn = ldsv + ((sw + 1) % NSLOT) * SLOT + (wave * 2) * 128;
+#define X3S_END()                                                                                                   \
+  _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { xh[mb] = nh[mb]; xl[mb] = nl[mb]; }                            \
+  sw = (sw + 2) % NSLOT;
+  if (grp == 0) {
+    for (int g = 0; g < nk; ++g) {
+      X3S_VARS()
+      X3S_LOAD(0) __builtin_amdgcn_s_barrier(); X3S_MMA(0) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(3) __builtin_amdgcn_s_barrier(); X3S_MMA(3)
+      wait_vm<GW>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      X3S_END()
+    }
+  } else {
+    __builtin_amdgcn_s_barrier();  // one slot behind
+    for (int g = 0; g < nk; ++g) {
+      X3S_VARS()
+      X3S_LOAD(0) __builtin_amdgcn_s_barrier(); X3S_MMA(0) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
+      X3S_LOAD(3)
+      wait_vm<GW>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      X3S_MMA(3)
+      if (g + 1 < nk) __builtin_amdgcn_s_barrier();
+      X3S_END()
+    }
+  }
+#undef X3S_LOAD
+#undef X3S_MMA
+#undef X3S_VARS
+#undef X3S_END
+  // ---- epilogue: LDS-transposed coalesced fp32 stores (epilogue_block: row base m0 + wm * (BM_/2) + mb * 16 with BM_ = 64, wm = wave;
+  //      column base n0 + wn * 64 with wn = the 64-column group) ----
+  wait_vm<0>();   // the surplus requests of the last two slabs: the ring becomes transpose patches
+  __syncthreads();
+  const float* bias = p.bias;
+  float* patch = (float*)lds + wave * (16 * 68);
+#pragma unroll
+  for (int g = 0; g < NBS; ++g) {
+    const BiasRegs br = load_bias_regs<true>(p, bias, lane, g, n0);
+    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, br);
+    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, br);
+  }
+}
+
 // fp32 (N, K) -> per row and 32-deep K slab [32 hi pieces | 32 lo pieces] (16-bit): one thread per 8 consecutive k
 template <bool F16>
 __global__ void split_pack_kernel(const float* __restrict__ w, long n_rows, int K, unsigned short* __restrict__ out) {
@@ -975,358 +1172,6 @@ __global__ void split_pack_kernel(const float* __restrict__ w, long n_rows, int 
   unsigned short* dst = out + n * (2L * K) + (long)(k0 / 32) * 64 + (k0 % 32);
 #pragma unroll
   for (int j = 0; j < 8; ++j) { dst[j] = h[j]; dst[32 + j] = l[j]; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Four-wave kernel: 256 x 256 x 64 tiles, ONE wave per SIMD, each wave owns 128 x 128 of the tile (8 x 8 MFMA blocks, 256
-// accumulator registers in the AGPR half of the file) -- 128 KiB of fragment reads per slab and CU instead of the 192 KiB of
-// the eight-wave kernels, and no second wave competing for the SIMD's issue port.  The slab is one hand-ordered instruction
-// stream (gemm_w4_body.inc, generated by tools/gen_w4_body.py): 128 MFMAs back to back, W-fragment-major so consecutive
-// MFMAs never share an accumulator, with everything else placed in fixed slots between them:
-//   * fragments are double-buffered by k-step in registers (2 x 16 x 4 VGPRs): while k-step 0 multiplies, k-step 1 is read;
-//     while k-step 1 multiplies, k-step 0 of the NEXT slab is read from the other LDS stage;
-//   * two LDS stages of 64 KiB (X half + W half).  As soon as every wave holds its X fragments of the slab (barrier 1) the X
-//     half of the stage being multiplied is refilled with the slab after next; same for W after barrier 2 -- requests for
-//     slab kt + 2 are in flight for a whole slab time before they are needed (counted vmcnt(16) + barrier 3);
-//   * LDS-DMA by `global_load_lds_dwordx4 voffset, sbase`: per-lane 32-bit row offsets computed once per tile, the K
-//     advance is one scalar add per slab -- no vector ALU work in the loop at all.
-// The LDS image (XOR-swizzled 128-byte rows, W rows in MFMA order) and the epilogue are those of gemm_pp8_kernel.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#include "gemm_w4_body.inc"
-
-#define W4_OPERANDS                                                                                                          \
-  [xa0] "v"(xaddr[0]), [xa1] "v"(xaddr[1]), [wa0] "v"(waddr[0]), [wa1] "v"(waddr[1]), [xv0] "v"(xvoff[0]), [xv1] "v"(xvoff[1]),   \
-      [xv2] "v"(xvoff[2]), [xv3] "v"(xvoff[3]), [xv4] "v"(xvoff[4]), [xv5] "v"(xvoff[5]), [xv6] "v"(xvoff[6]), [xv7] "v"(xvoff[7]), \
-      [wv0] "v"(wvoff[0]), [wv1] "v"(wvoff[1]), [wv2] "v"(wvoff[2]), [wv3] "v"(wvoff[3]), [wv4] "v"(wvoff[4]), [wv5] "v"(wvoff[5]), \
-      [wv6] "v"(wvoff[6]), [wv7] "v"(wvoff[7])
-
-// Epilogue straight from the accumulators, no LDS transpose and no barriers.  MFMA src0 is the X fragment, so a lane (q = lane >> 4,
-// j = lane & 15) of block (X block B, W block nb of 64-column group G) holds rows B*16 + q*4 + i (i = 0..3) of ONE W row j; the W rows
-// are placed in LDS so that (block nb, row j) is output column G*64 + j*4 + nb.  A lane therefore owns 4 CONSECUTIVE columns of each
-// of its 4 rows across the four blocks nb = 0..3, and the 16 lanes of a q-group cover 64 consecutive columns: every store instruction
-// writes whole 128-byte (bf16) / 256-byte (fp32) row segments.
-// PRELOADED: the bias values were fetched by the caller (gemm_w4p_kernel: at the start of the tile, so that the epilogue holds no
-// load the compiler would put a vmcnt(0) in front of -- that wait would also cover the LDS-DMA requests of the next tile)
-template <bool OUT32, bool PRELOADED = false>
-__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, int lane, int wm, int wn, int m0, int n0, const f32x4* pre = nullptr) {
-  // the fields used in the loop, read once: the kernel arguments live in memory, and behind an asm "memory" clobber the compiler
-  // re-reads them (scalar load + lgkmcnt(0)) in every iteration
-  const int pM = p.M, pN = p.N, pact = p.act;
-  const long pldc = p.ldc;
-  const float palpha = p.alpha;
-  const float* presid = p.resid;
-  void* pC = p.C;
-  // bias of this lane's 4 columns in each of the two 64-column groups
-  float bias8[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  const int nbase = n0 + wn * 128 + (lane & 15) * 4;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    if constexpr (PRELOADED) {
-      bias8[g][0] = pre[g][0]; bias8[g][1] = pre[g][1]; bias8[g][2] = pre[g][2]; bias8[g][3] = pre[g][3];
-    } else if (p.bias && nbase + g * 64 < p.N) {
-      const float4 b = *(const float4*)(p.bias + nbase + g * 64);
-      bias8[g][0] = b.x; bias8[g][1] = b.y; bias8[g][2] = b.z; bias8[g][3] = b.w;
-    }
-  }
-  const int mbase = m0 + wm * 128 + (lane >> 4) * 4;
-  // A real loop: only the 16 accumulator reads of a block differ between iterations (register numbers are part of the instruction);
-  // fully unrolled, the epilogue was 21 000 instructions (170 KB of code against a 64 KiB instruction cache shared by two CUs)
-  // and cost 20 us per tile in instruction fetch alone.
-#pragma nounroll
-  for (int blk = 0; blk < 16; ++blk) {
-    f32x4 q0, q1, q2, q3;
-    switch (blk) {
-      case 0: W4_ACC_READ_0_0(q0, q1, q2, q3) break;
-      case 1: W4_ACC_READ_0_1(q0, q1, q2, q3) break;
-      case 2: W4_ACC_READ_0_2(q0, q1, q2, q3) break;
-      case 3: W4_ACC_READ_0_3(q0, q1, q2, q3) break;
-      case 4: W4_ACC_READ_0_4(q0, q1, q2, q3) break;
-      case 5: W4_ACC_READ_0_5(q0, q1, q2, q3) break;
-      case 6: W4_ACC_READ_0_6(q0, q1, q2, q3) break;
-      case 7: W4_ACC_READ_0_7(q0, q1, q2, q3) break;
-      case 8: W4_ACC_READ_1_0(q0, q1, q2, q3) break;
-      case 9: W4_ACC_READ_1_1(q0, q1, q2, q3) break;
-      case 10: W4_ACC_READ_1_2(q0, q1, q2, q3) break;
-      case 11: W4_ACC_READ_1_3(q0, q1, q2, q3) break;
-      case 12: W4_ACC_READ_1_4(q0, q1, q2, q3) break;
-      case 13: W4_ACC_READ_1_5(q0, q1, q2, q3) break;
-      case 14: W4_ACC_READ_1_6(q0, q1, q2, q3) break;
-      default: W4_ACC_READ_1_7(q0, q1, q2, q3) break;
-    }
-    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
-    const int g = blk >> 3, mb = blk & 7;
-    const int n = nbase + g * 64;
-    const int mrow = mbase + mb * 16;
-    if (n >= pN) continue;
-    const float b0 = g ? bias8[1][0] : bias8[0][0], b1 = g ? bias8[1][1] : bias8[0][1], b2 = g ? bias8[1][2] : bias8[0][2],
-                b3 = g ? bias8[1][3] : bias8[0][3];
-    float v[4][4];  // [row i][column c]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i][0] = fmaf(q0[i], palpha, b0);
-      v[i][1] = fmaf(q1[i], palpha, b1);
-      v[i][2] = fmaf(q2[i], palpha, b2);
-      v[i][3] = fmaf(q3[i], palpha, b3);
-    }
-    if (!OUT32 && pact == ACT_GELU && !presid) {
-      f32x2_t gg[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { gg[2 * i] = f32x2_t{v[i][0], v[i][1]}; gg[2 * i + 1] = f32x2_t{v[i][2], v[i][3]}; }
-      gelu_bf16x2_xn<8>(gg);   // eight independent Horner chains: one wave per SIMD has nobody else to hide VALU latency behind
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i][0] = gg[2 * i].x; v[i][1] = gg[2 * i].y; v[i][2] = gg[2 * i + 1].x; v[i][3] = gg[2 * i + 1].y; }
-    } else if (pact != ACT_NONE) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[i][c] = apply_act(v[i][c], pact);
-    }
-    long idx = (long)mrow * pldc + n;
-#pragma unroll
-    for (int i = 0; i < 4; ++i, idx += pldc) {
-      if (mrow + i < pM) {
-        if (presid) {
-          const float4 r4 = *(const float4*)(presid + idx);
-          v[i][0] += r4.x; v[i][1] += r4.y; v[i][2] += r4.z; v[i][3] += r4.w;
-        }
-        if constexpr (OUT32) {
-          *(float4*)((float*)pC + idx) = float4{v[i][0], v[i][1], v[i][2], v[i][3]};
-        } else {
-          typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
-          bf16x4_t o = {(bf16_t)v[i][0], (bf16_t)v[i][1], (bf16_t)v[i][2], (bf16_t)v[i][3]};
-          *(bf16x4_t*)((bf16_t*)pC + idx) = o;
-        }
-      }
-    }
-  }
-}
-
-// amdgpu_num_vgpr(128): the compiler's own values stay in v0..v127 -- the fragments in v128..v255 live ACROSS the asm statements
-// (a clobber only tells the compiler they are dead there; with the GELU epilogue's register pressure it did reuse v128..v139)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void gemm_w4_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // X stage 0 | X stage 1 | W stage 0 | W stage 1, 32 KiB each
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const char* gA = (const char*)p.A;
-  const char* gW = (const char*)p.W;
-
-  // DMA sources: instruction i of this wave fills LDS rows (wave * 8 + i) * 8 .. + 8 of the X / W half; 8 consecutive lanes fetch
-  // the 8 chunks of one 128-byte row, lane (row r8, slot) takes chunk slot ^ r8 (the swizzle is applied on the source side)
-  const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
-  unsigned xvoff[8], wvoff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int rho = (wave * 8 + i) * 8 + r8;
-    int m = m0 + rho;
-    if (m > p.M - 1) m = p.M - 1;
-    xvoff[i] = (unsigned)(((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8) * 2);
-    int n = n0 + (rho >> 6) * 64 + (rho & 15) * 4 + ((rho >> 4) & 3);   // LDS row (64-group g, block nb, j) <- output column g*64 + j*4 + nb
-    if (n > p.N - 1) n = p.N - 1;
-    wvoff[i] = (unsigned)(((long)n * p.ldw + ch * 8) * 2);
-  }
-  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
-  unsigned xaddr[2], waddr[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    xaddr[ks] = (unsigned)((wm * 128 + r16) * 128 + (((ks * 4 + cq) ^ rr8) * 16));
-    waddr[ks] = (unsigned)(65536 + (wn * 128 + r16) * 128 + (((ks * 4 + cq) ^ rr8) * 16));
-  }
-  const unsigned m0x0 = wave * 8192, m0w0 = 65536 + wave * 8192;
-
-  const int nk = p.K / BK;
-  // prologue: slab 0 -> stage 0, slab 1 -> stage 1
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0x0 + i * 1024), "v"(xvoff[i]), "s"(gA) : "memory");
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w0 + i * 1024), "v"(wvoff[i]), "s"(gW) : "memory");
-  }
-  if (nk > 1) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0x0 + 32768 + i * 1024), "v"(xvoff[i]), "s"(gA + 128) : "memory");
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w0 + 32768 + i * 1024), "v"(wvoff[i]), "s"(gW + 128) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  asm volatile("s_barrier" ::: "memory");
-  asm volatile(W4_INIT ::W4_OPERANDS : W4_CLOBBERS);
-
-  int kt = 0;
-  for (;;) {
-    {
-      const char* ga = gA + (long)(kt + 2) * 128;
-      const char* gw = gW + (long)(kt + 2) * 128;
-      if (kt + 2 < nk && p.dbg != 1 && p.dbg != 4) asm volatile(W4_SLAB_0_1 ::W4_OPERANDS, [ga] "s"(ga), [gw] "s"(gw), [m0x] "s"(m0x0), [m0w] "s"(m0w0) : W4_CLOBBERS);
-      else asm volatile(W4_SLAB_0_0 ::W4_OPERANDS : W4_CLOBBERS);
-    }
-    if (++kt >= nk) break;
-    {
-      const char* ga = gA + (long)(kt + 2) * 128;
-      const char* gw = gW + (long)(kt + 2) * 128;
-      if (kt + 2 < nk && p.dbg != 1 && p.dbg != 4) asm volatile(W4_SLAB_1_1 ::W4_OPERANDS, [ga] "s"(ga), [gw] "s"(gw), [m0x] "s"(m0x0 + 32768), [m0w] "s"(m0w0 + 32768) : W4_CLOBBERS);
-      else asm volatile(W4_SLAB_1_0 ::W4_OPERANDS : W4_CLOBBERS);
-    }
-    if (++kt >= nk) break;
-  }
-
-  if (p.dbg == 3 || p.dbg == 4) return;
-  if (p.out_f32) w4_epilogue<true>(p, lane, wm, wn, m0, n0);
-  else w4_epilogue<false>(p, lane, wm, wn, m0, n0);
-}
-
-// Persistent form: one workgroup per CU walks its list of tiles and the (tile, K slab) pairs form ONE stream for the two LDS
-// stages -- the slab body never changes, only the rows it fetches: during the last two slabs of a tile the requests are those of the
-// NEXT tile's first two slabs, and the fragment reads at the end of the last slab are the next tile's first fragments.  Between
-// tiles the wave only runs the epilogue (accumulators -> bias / activation -> stores, no LDS, no barrier) and clears the
-// accumulators; its stores drain while the next tile multiplies.  The counted wait of the slab body stays exact across the
-// epilogue's stores: a slab waits until at most 16 operations are outstanding, and exactly 16 LOADS are newer than the ones it
-// needs -- loads return in order, so whatever the 64 stores in between do, "<= 16 outstanding" implies the older loads are in.
-// Requires an even number of K slabs (a tile then starts on stage 0 like the stream does).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void gemm_w4p_kernel(GemmArgs p, int tiles_n, int ntiles) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // X stage 0 | X stage 1 | W stage 0 | W stage 1, 32 KiB each
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nblk = gridDim.x, b = blockIdx.x;
-  // blocks b and b + 8 share an XCD: in every round an XCD works on nblk / 8 consecutive logical tiles (n fastest)
-  const int per = nblk >> 3;
-  const int lbase = (b & 7) * per + (b >> 3);
-  int my_tiles = 0;
-  while (my_tiles * nblk + lbase < ntiles) ++my_tiles;
-  if (my_tiles == 0) return;
-  const char* gA = (const char*)p.A;
-  const char* gW = (const char*)p.W;
-  const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
-
-  unsigned xvoff[8], wvoff[8];     // rows of the tile whose slabs are being requested
-  unsigned xvoff2[8], wvoff2[8];   // ... of the tile after it
-  auto setup = [&](int logical, unsigned (&xv)[8], unsigned (&wv)[8]) {
-    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rho = (wave * 8 + i) * 8 + r8;
-      int m = m0 + rho;
-      if (m > p.M - 1) m = p.M - 1;
-      xv[i] = (unsigned)(((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8) * 2);
-      int n = n0 + (rho >> 6) * 64 + (rho & 15) * 4 + ((rho >> 4) & 3);   // LDS row (64-group g, block nb, j) <- output column g*64 + j*4 + nb
-      if (n > p.N - 1) n = p.N - 1;
-      wv[i] = (unsigned)(((long)n * p.ldw + ch * 8) * 2);
-    }
-  };
-  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
-  unsigned xaddr[2], waddr[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    xaddr[ks] = (unsigned)((wm * 128 + r16) * 128 + (((ks * 4 + cq) ^ rr8) * 16));
-    waddr[ks] = (unsigned)(65536 + (wn * 128 + r16) * 128 + (((ks * 4 + cq) ^ rr8) * 16));
-  }
-  const unsigned m0x0 = wave * 8192, m0w0 = 65536 + wave * 8192;
-  const int nk = p.K / BK;   // even, >= 2
-
-  setup(lbase, xvoff, wvoff);
-  if (my_tiles > 1) setup(nblk + lbase, xvoff2, wvoff2);
-  // head of the stream: slab 0 -> stage 0, slab 1 -> stage 1
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0x0 + i * 1024), "v"(xvoff[i]), "s"(gA) : "memory");
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w0 + i * 1024), "v"(wvoff[i]), "s"(gW) : "memory");
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0x0 + 32768 + i * 1024), "v"(xvoff[i]), "s"(gA + 128) : "memory");
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0w0 + 32768 + i * 1024), "v"(wvoff[i]), "s"(gW + 128) : "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  asm volatile("s_barrier" ::: "memory");
-  asm volatile(W4_INIT ::W4_OPERANDS : W4_CLOBBERS);
-
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    const int logical = ti * nblk + lbase;
-    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
-    const bool has_next = ti + 1 < my_tiles;
-    // this tile's bias, requested now: older than every LDS-DMA request of the slabs below, so the first slab's counted wait
-    // covers it (loads return in order) and the epilogue starts without a memory wait
-    f32x4 pre[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (p.bias) {
-      const float* bp = p.bias + n0 + wn * 128 + (lane & 15) * 4;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[0]) : "v"(bp) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[1]) : "v"(bp + 64) : "memory");
-    }
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 == nk && has_next) {   // from here on the requests are the next tile's
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { xvoff[i] = xvoff2[i]; wvoff[i] = wvoff2[i]; }
-      }
-      const bool fetch = kt + 2 < nk || has_next;
-      const long koff = (long)(kt + 2 < nk ? kt + 2 : 0) * 128;
-      {
-        const char* ga = gA + koff;
-        const char* gw = gW + koff;
-        if (fetch && p.dbg != 1) asm volatile(W4_SLAB_0_1 ::W4_OPERANDS, [ga] "s"(ga), [gw] "s"(gw), [m0x] "s"(m0x0), [m0w] "s"(m0w0) : W4_CLOBBERS);
-        else asm volatile(W4_SLAB_0_0 ::W4_OPERANDS : W4_CLOBBERS);
-      }
-      {
-        const char* ga = gA + koff + 128;
-        const char* gw = gW + koff + 128;
-        if (fetch && p.dbg != 1) asm volatile(W4_SLAB_1_1 ::W4_OPERANDS, [ga] "s"(ga), [gw] "s"(gw), [m0x] "s"(m0x0 + 32768), [m0w] "s"(m0w0 + 32768) : W4_CLOBBERS);
-        else asm volatile(W4_SLAB_1_0 ::W4_OPERANDS : W4_CLOBBERS);
-      }
-    }
-    if (p.dbg != 3) {
-      asm volatile("" : "+v"(pre[0]), "+v"(pre[1]));   // every use of the preloaded bias stays behind the slabs above
-      if (p.out_f32) w4_epilogue<true, true>(p, lane, wm, wn, m0, n0, pre);
-      else w4_epilogue<false, true>(p, lane, wm, wn, m0, n0, pre);
-    }
-    if (has_next) {
-      asm volatile(W4_ZERO ::: W4_CLOBBERS);
-      if (ti + 2 < my_tiles) setup((ti + 2) * nblk + lbase, xvoff2, wvoff2);
-    }
-  }
-}
-
-#pragma clang diagnostic pop
-
-int launch_w4p(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-  const int ntiles = tiles_m * tiles_n;
-  const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
-  const size_t lds_bytes = 131072;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_w4p_kernel, (int)lds_bytes)) return r_;
-  const double flops = 2.0 * a.M * (double)a.N * a.K;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL(gemm_w4p_kernel, dim3(nblk), dim3(256), lds_bytes, s, a, tiles_n, ntiles);
-  prof_end(s, flops, bytes, 0);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_w4(const GemmArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-  const size_t lds_bytes = 131072;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_w4_kernel, (int)lds_bytes)) return r_;
-  const double flops = 2.0 * a.M * (double)a.N * a.K;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * (a.out_f32 ? 4 : 2);
-  prof_begin(s);
-  hipLaunchKernelGGL(gemm_w4_kernel, dim3(tiles_m * tiles_n), dim3(256), lds_bytes, s, a);
-  prof_end(s, flops, bytes, 0);
-  SVT_LAUNCH_CHECK();
-  return 0;
 }
 
 template <int BM>
@@ -1411,20 +1256,43 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     if (row + a.N > (size_t)it->second.N) return 1;
     packed = (const char*)it->second.packed + row * (size_t)a.K * 4;
   }
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   const size_t lds_bytes = 5 * 32768;
   GemmArgs g = a;
   g.out_f32 = 1;
   g.planes_f16 = kind == 3;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
+  // tile width: 192 columns when that fills the chip better (N = 768: 252 tiles against 189); g_gemm_variant 30 = the lockstep kernel (A/B)
+  const long tm = (a.M + 255) / 256;
+  const long t256 = tm * ((a.N + 255) / 256), t192 = tm * ((a.N + 191) / 192);
+  auto rounds = [](long t) { return (t + 255) / 256; };
+  const bool narrow = a.N % 192 == 0 && rounds(t192) * 3 < rounds(t256) * 4;
   prof_begin(s);
-  if (kind == 3) {
-    if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<true>, (int)lds_bytes)) return r_;
-    hipLaunchKernelGGL((gemm_x3_kernel<true>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+  if (g_gemm_variant == 30) {
+    const int tiles = (int)t256;
+    if (kind == 3) {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<true>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3_kernel<true>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+    } else {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<false>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+    }
+  } else if (narrow) {
+    if (kind == 3) {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 3>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 3>), dim3((unsigned)t192), dim3(512), lds_bytes, s, g, packed);
+    } else {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<false, 3>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<false, 3>), dim3((unsigned)t192), dim3(512), lds_bytes, s, g, packed);
+    }
   } else {
-    if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<false>, (int)lds_bytes)) return r_;
-    hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
+    if (kind == 3) {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 4>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+    } else {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<false, 4>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<false, 4>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+    }
   }
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
@@ -1472,18 +1340,20 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     if (best == 192) return launch_pp8<192, true>(a, s);
     return launch_pp8<128, true>(a, s);
   }
-  const bool w4_ok = a.nz == 1 && a.c_z1 == 0 && a.c_z2 == 0 && a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
-  (void)w4_ok;
-  if (g_gemm_variant >= 50 && g_gemm_variant < 70 && gemm_pps_eligible(a)) {   // diagnostics: 50 = force it, 51 / 53 / 54 = its dbg 1 / 3 / 4; 60.. = builtin DMA form
+  const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
+  // Persistent staggered kernel (gemm_pps.hip): bf16 outputs without residual.  It wins wherever a workgroup gets more than one tile
+  // (prologue, epilogue stores and the next tile's fills overlap) and on short-K single-round launches (its register epilogue costs
+  // 1.3 us against 4 us for the LDS-transposed one); long-K single-round launches (FFN-2, K = 3072 / 4096) stay on gemm_pp8_kernel, whose
+  // main loop is ~10 % faster per slab.  Measured per shape: profiles/r03_gemm_yardstick.txt.  Write-through (sc1) stores: the
+  // output leaves L2 while the kernel runs instead of at the kernel boundary (FFN-1: 98 MB, 16 us).
+  // svt_debug_set key 3: 50 / 60 / 70 force it with default / nt / sc1 stores (53: without epilogue), 49 switches it off.
+  if (g_gemm_variant >= 50 && g_gemm_variant < 80 && gemm_pps_eligible(a)) {
     GemmArgs b = a;
     b.dbg = g_gemm_variant % 10;
-    return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, g_gemm_variant >= 60);
+    return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, (g_gemm_variant - 50) / 10);
   }
-#ifndef SVT_OPERAND_F16   // the four-wave kernels' instruction stream names the bf16 MFMA
-  if (g_gemm_variant == 40 && w4_ok) return launch_w4(a, s);
-  if (g_gemm_variant == 41 && w4_ok && a.K % 128 == 0 && a.N % 256 == 0 && !a.resid) return launch_w4p(a, s);
-#endif
-  const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
+  if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 200 && (ntiles > 256 || a.K < 2048) && gemm_pps_eligible(a))
+    return launch_gemm_pps(a, best, s, 2);
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
                        a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
   int mode = g_gemm_ring;

@@ -35,16 +35,18 @@ __device__ __forceinline__ void dma_sv(unsigned voff, const void* sbase, unsigne
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
 
-typedef const void __attribute__((address_space(1)))* gptr_t;
-typedef void __attribute__((address_space(3)))* lptr_t;
-// the same request through the compiler's builtin (64-bit per-lane address): A/B of the two issue forms (DMAF = 1)
-__device__ __forceinline__ void dma_vv(unsigned voff, const void* sbase, unsigned lds_addr) {
-  __builtin_amdgcn_global_load_lds((gptr_t)((const char*)sbase + voff), (lptr_t)(size_t)lds_addr, 16, 0, 0);
-}
-
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
-template <int BM, int ACT, int DMAF>
+// an empty asm that "reads and writes" every register of a fragment array: whatever loads them must have completed here
+template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
+  static_assert(N >= 2 && N <= 4, "fragment arrays of 2..4 blocks");
+  if constexpr (N == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+  else if constexpr (N == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
+  else asm volatile("" : "+v"(r[0]), "+v"(r[1]));
+}
+
+// STAUX: cache policy of the epilogue stores (buffer instruction aux bits: 0 = default write-back, 2 = nt, 16 = sc1 write-through)
+template <int BM, int ACT, int STAUX>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -86,9 +88,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(void __attribute__((address_space(3)))*)lds);
   auto lds_unit = [&](int slot, int i) -> unsigned { return lds0 + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u; };
 
-  auto dma = [&](unsigned voff, const void* sbase, unsigned lds_addr) {
-    if constexpr (DMAF == 0) dma_sv(voff, sbase, lds_addr); else dma_vv(voff, sbase, lds_addr);
-  };
+  auto dma = [&](unsigned voff, const void* sbase, unsigned lds_addr) { dma_sv(voff, sbase, lds_addr); };
   f32x4 acc[8][MB];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   // diagnostics (tools/gemm_trace.py, dbg = 9 sets p.trace): s_memrealtime (100 MHz) stamps at entry / first slab / around every
   // epilogue / exit, s_memtime (core clock) over the stream; dbg 1 = no LDS-DMA after the head of the stream, 3 = no epilogue
   const bool tr = p.trace != nullptr;
-  const bool no_dma = p.dbg == 1 || p.dbg == 4, no_epi = p.dbg == 3 || p.dbg == 4, has_bias = p.bias != nullptr;
+  const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
   long long t_begin = 0, t_first = 0, t_epi = 0, c_first = 0;
   if (tr) t_begin = wall_clock64();
   setup(lbase, aof, wof);
-  if (my_tiles > 1) setup(nblk + lbase, aof2, wof2);
+  setup(my_tiles > 1 ? nblk + lbase : lbase, aof2, wof2);   // always rows that exist: the stream's surplus requests (below) read them
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aof[i], gA, lds_unit(0, i));
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
         // the ">64-bit store data, then VALU write of those registers" hazard away and packs the next row into the same four
         // registers with no wait state: on gfx950 that tore the first dword of the previous store in the last four lanes of
         // every 16 whenever the memory pipeline was busy (the persistent stream's LDS-DMA) -- tools/pps_probe.py
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, STAUX);
       }
     }
     } else if (acc[0][0][0] == 123.456f && acc[7][MB - 1][3] == 1.5f) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     for (int i = 0; i < GA; ++i) aof[i] = aof2[i];
 #pragma unroll
     for (int i = 0; i < GW; ++i) wof[i] = wof2[i];
-    if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, aof2, wof2);
+    if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, aof2, wof2);   // else: keeps the last tile's rows (surplus requests)
     if (tr) t_epi += wall_clock64() - t_e0;
   };
 
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                \
         wfr[nb] = __builtin_bit_cast(bf16x8, wa[(half_ * 4 + nb) * 128 + (ks_ ? frag1 : frag0)]);                   \
     if (ks_ == 0) {                                                                                                 \
-      if (have_w) {                                                                                                 \
+      {                                                                                                             \
         const char* wb = w_cur ? gW + (long)(kt + 1) * (BK * 2) : gW;                                               \
         _Pragma("unroll") for (int i2 = half_ * 2; i2 < half_ * 2 + 2; ++i2)                                        \
             dma(w_cur ? wof[i2] : wof2[i2], wb, lds_unit(wslot, i2));                                               \
@@ -216,13 +216,18 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
                      : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");                                            \
       }                                                                                                             \
     } else {                                                                                                        \
-      if (have_a) {                                                                                                 \
+      {                                                                                                             \
         const char* ab = gA + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 2);                                      \
         _Pragma("unroll") for (int i2 = half_ * ((GA + 1) / 2); i2 < (half_ ? GA : (GA + 1) / 2); ++i2)             \
             dma(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(aslot, i2));                                               \
       }                                                                                                             \
     }                                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    /* every fragment register of this slot is "used" here, in the LOAD slot: hipcc cannot see the asm wait above, and what it  \
+       otherwise does is put its own s_waitcnt lgkmcnt(3 / 2 / 1 / 0) BETWEEN the MFMAs of the next slot (one per W block as   \
+       their operands "arrive"): four sequencer stalls per 16 MFMAs, 3 200 instead of 2 600 cycles per slab */            \
+    if (half_ == 0) touch_regs(xfr);                                                                                \
+    touch_regs(wfr);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 #define PPS_MMA(Q)                                                                                                  \
@@ -236,16 +241,18 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
   // retire slab g: everything but the A unit requested during this slab (A_{g+2}) has landed -- W_{g+1}, A_{g+1}, the bias
-  // loads of a tile's last slab and the previous tile's stores are all older
+  // loads of a tile's last slab and the previous tile's stores are all older.  The requests are UNCONDITIONAL: the last two slabs of
+  // the stream ask for three units nobody reads (rows of the last tile, into ring slots that are dead by then) instead of carrying
+  // "is there a next unit" branches through every LOAD slot (five scalar branches per slot made the slot longer than the partner's
+  // 16 MFMAs); they are drained by one vmcnt(0) behind the last epilogue, before the workgroup gives its LDS back.
 #define PPS_RETIRE()                                                                                                \
   {                                                                                                                 \
-    if (have_a) wait_vm<GA>(); else wait_vm<0>();                                                                   \
+    wait_vm<GA>();                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 #define PPS_SLAB_VARS()                                                                                             \
   const uint4* xa = lds + sa * SLOT + xoff;                                                                         \
   const uint4* wa = lds + sw * SLOT + woff;                                                                         \
-  const bool have_w = g + 1 < G && !no_dma, have_a = g + 2 < G && !no_dma;                                          \
   const bool w_cur = kt + 1 < nk, a_cur = kt + 2 < nk, last_k = kt + 1 == nk;                                       \
   const int wslot = (sa + 3) % NSLOT, aslot = (sa + 4) % NSLOT;
 #define PPS_ADVANCE()                                                                                               \
@@ -284,8 +291,13 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       PPS_ADVANCE()
     }
   }
+  long long t_loop = 0;
+  if (tr) t_loop = wall_clock64();
+  // the surplus requests of the stream's tail: nothing may land in LDS after the workgroup is gone.  They are older than the last
+  // epilogue's MB * 4 stores, which need not be waited for (VMEM operations retire in order).
+  if (no_epi) wait_vm<0>(); else wait_vm<MB * 4>();
   if (tr && lane == 0 && (wave & 3) == 0) {
-    const long long t_end = wall_clock64();
+    const long long t_end = t_loop;
     long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
     o[0] = t_begin; o[1] = t_first; o[2] = t_end - t_first - t_epi; o[3] = t_epi; o[4] = t_end; o[5] = my_tiles;
     o[6] = __builtin_amdgcn_s_memtime() - c_first; o[7] = BM;
@@ -297,17 +309,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #undef PPS_ADVANCE
 }
 
-template <int BM, int ACT, int DMAF = 0>
+template <int BM, int ACT, int STAUX = 0>
 int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, DMAF>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, DMAF>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -329,19 +341,22 @@ bool gemm_pps_eligible(const GemmArgs& a) {
          (a.a_rstride & 7) == 0 && (a.a_bstride & 7) == 0 && (a.ldw & 7) == 0;
 }
 
-int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int dma_form) {
-  if (dma_form == 1) {   // A/B of the LDS-DMA issue form (diagnostics)
-    if (a.act == ACT_GELU) return bm == 256 ? launch_pps_t<256, ACT_GELU, 1>(a, s) : launch_pps_t<192, ACT_GELU, 1>(a, s);
-    return bm == 256 ? launch_pps_t<256, ACT_NONE, 1>(a, s) : launch_pps_t<192, ACT_NONE, 1>(a, s);
-  }
+template <int STAUX>
+static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
   if (a.act == ACT_GELU) {
-    if (bm == 256) return launch_pps_t<256, ACT_GELU>(a, s);
-    if (bm == 192) return launch_pps_t<192, ACT_GELU>(a, s);
-    return launch_pps_t<128, ACT_GELU>(a, s);
+    if (bm == 256) return launch_pps_t<256, ACT_GELU, STAUX>(a, s);
+    if (bm == 192) return launch_pps_t<192, ACT_GELU, STAUX>(a, s);
+    return launch_pps_t<128, ACT_GELU, STAUX>(a, s);
   }
-  if (bm == 256) return launch_pps_t<256, ACT_NONE>(a, s);
-  if (bm == 192) return launch_pps_t<192, ACT_NONE>(a, s);
-  return launch_pps_t<128, ACT_NONE>(a, s);
+  if (bm == 256) return launch_pps_t<256, ACT_NONE, STAUX>(a, s);
+  if (bm == 192) return launch_pps_t<192, ACT_NONE, STAUX>(a, s);
+  return launch_pps_t<128, ACT_NONE, STAUX>(a, s);
+}
+
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) {
+  if (store_policy == 1) return launch_pps_aux<2>(a, bm, s);    // nt
+  if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
+  return launch_pps_aux<0>(a, bm, s);
 }
 
 }  // namespace svt

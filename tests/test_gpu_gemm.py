@@ -92,33 +92,60 @@ def test_gemm_vs_torch(name, prec, M, N, K, conv, act, out_f32, resid):
     assert err < tol, (name, err)
 
 
-W4_CASES = [
-    # name, M, N, K, conv, act, out_f32, resid   (variant 40: one tile per workgroup; 41: persistent, needs K % 128 == 0, N % 256 == 0, no residual)
-    ("ffn1_gelu", 15968, 3072, 768, None, 1, 0, False),
-    ("conv_gelu_mtail", 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, 0, False),
-    ("f32out", 4999, 768, 768, None, 0, 1, False),
-    ("f32out_resid_ntail", 1000, 200, 128, None, 0, 1, True),
-    ("relu_two_slabs", 777, 256, 128, None, 2, 0, False),
-    ("one_slab", 300, 256, 64, None, 0, 0, False),
-    ("many_tiles_per_cu", 70000, 512, 256, None, 1, 0, False),
+PPS_CASES = [
+    # name, M, N, K, conv, act, bias   -- gemm_pps_kernel: bf16 output, no residual, N % 256 == 0, K % 64 == 0, K >= 128
+    ("ffn1_gelu_3_tiles_per_cu", 15968, 3072, 768, None, 1, True),
+    ("qkv_no_act", 15968, 2304, 768, None, 0, True),
+    ("conv_gelu_mtail", 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, True),
+    ("conv_k1024", 4 * 999, 512, 1024, (1999, 999, 2, 512), 1, True),
+    ("no_bias_two_slabs", 70000, 512, 128, None, 0, False),
+    ("one_tile_ragged", 845, 512, 256, None, 0, True),
+    ("many_tiles_per_cu", 70000, 512, 256, None, 1, True),
+    ("long_k_single_round", 15968, 768, 3072, None, 0, True),
 ]
 
 
-@pytest.mark.parametrize("variant", [40, 41])
-@pytest.mark.parametrize("name,M,N,K,conv,act,out_f32,resid", W4_CASES, ids=[c[0] for c in W4_CASES])
-def test_four_wave_kernel_variants(variant, name, M, N, K, conv, act, out_f32, resid):
-    """The experimental four-wave kernels (gemm_w4_kernel / gemm_w4p_kernel: one wave per SIMD, 128 x 128 wave tiles, hand-ordered
-    slab body, register-direct epilogue; svt_debug_set key 3 = 40 / 41) against the same torch reference.  Shapes the persistent form
-    does not take fall through to the default dispatch, which must stay correct with the switch set."""
+@pytest.mark.parametrize("bm", [0, 256, 192, 128])
+@pytest.mark.parametrize("name,M,N,K,conv,act,bias", PPS_CASES, ids=[c[0] for c in PPS_CASES])
+def test_persistent_staggered_kernel(bm, name, M, N, K, conv, act, bias):
+    """gemm_pps_kernel forced for every eligible launch (svt_debug_set key 3 = 70: write-through stores, the form the dispatch uses;
+    key 1 = tile height, 0 = the dispatch's choice) against the torch reference: several tiles per workgroup (the ring and the
+    source offsets carry over tile boundaries), M tails (rows >= M dropped by the buffer range check), conv rows, bias fetched
+    inside the stream, GELU."""
     lib = _lib.load()
-    lib.svt_debug_set(3, variant)
+    lib.svt_debug_set(3, 70)
+    lib.svt_debug_set(1, bm)
     try:
-        got, ref = run_gemm(1, M, N, K, conv, act, out_f32, resid)
+        got, ref = run_gemm(1, M, N, K, conv, act, 0, False, bias=bias)
     finally:
         lib.svt_debug_set(3, 0)
+        lib.svt_debug_set(1, 0)
     assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
-    err = (got - ref).abs().max().item()
-    assert err < (2e-4 if out_f32 else 3e-2), (name, variant, err)
+    err = ((got - ref).abs() / (1.0 + ref.abs())).max().item()
+    assert err < 8e-3, (name, bm, err)   # bf16 rounding of the stored value: 2^-9 relative
+
+
+@pytest.mark.parametrize("variant", [50, 70])
+def test_persistent_kernel_exact_integers_under_load(variant):
+    """Regression for a store-data hazard met on gfx950: with an SGPR in the soffset field of buffer_store_dwordx4 hipcc adds no
+    wait state before the next VALU write of the data registers, and while the persistent stream's LDS-DMA kept the memory
+    pipeline busy the first dword of a store was torn in lanes 12-15 of every 16.  Exact small-integer data, several tiles per
+    workgroup, every output element compared."""
+    lib = _lib.load()
+    M, N, K = 256 * 96, 2048, 768
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-2, 3, (M, K), generator=g).to(DEV, torch.bfloat16)
+    W = torch.randint(-2, 3, (N, K), generator=g).to(DEV, torch.bfloat16)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    lib.svt_debug_set(3, variant)
+    try:
+        _lib.check(lib.svt_debug_gemm(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, M, N, K, M, 0, K, K, 0, 0, 0,
+                                      torch.cuda.current_stream().cuda_stream), "svt_debug_gemm")
+        torch.cuda.synchronize()
+    finally:
+        lib.svt_debug_set(3, 0)
+    ref = (A.float() @ W.float().t()).to(torch.bfloat16)
+    assert torch.equal(C, ref)
 
 
 def test_gemm_rejects_unaligned():

@@ -679,10 +679,14 @@ def test_fused_tail_equals_encoder_then_head_then_decode(cfg_name, B, L, cpg, pr
     # ... and with the separate path wherever the top-2 logits are further apart than the re-association noise
     mism = (got["octave"] != ref_frames["octave"]) | (got["pitch_class"] != ref_frames["pitch_class"])
     assert mism.mean() < 0.002
-    # AMTForward takes the fused path by itself
+    # AMTForward takes the fused path by itself in the throughput precisions; the parity-grade ones keep the reference's order of
+    # operations (normalise, then the head) unless fuse_tail is set
     amt = S.AMTForward({"wav2vec2": enc, "model": head})
     amt.compute_forward(wav)
     if cpg == 0:
+        assert torch.equal(amt.last_logits, logits if prec in ("bf16", "fp16") else ref_logits)
+        amt.fuse_tail = True
+        amt.compute_forward(wav)
         assert torch.equal(amt.last_logits, logits)
     # no output norm: the head reads the encoder output as is
     enc2 = S.HuggingFaceWav2Vec2(cfg_name, None, config=cfg, normalize_wav=True, output_norm=False, precision=prec, seed=13).to(DEV)
