@@ -188,6 +188,9 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
 int split_weights_register(const void* w_f32_dev, long n_rows, int K, int kind, hipStream_t s);
 void split_weights_forget(const void* w_f32_dev);
 int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s);  // 0 = launched, 1 = not eligible (use the register-staged kernel), < 0 = error
+// persistent staggered form of the LDS-DMA split kernel (gemm_x3p.hip); `packed` = the registered (hi, lo) image of the weight rows
+bool gemm_x3p_eligible(const GemmArgs& a);
+int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t s);
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;

@@ -962,7 +962,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* ws
 // slab re-read slab nk - 1 (never used) so that the counts stay constant; one vmcnt(0) drains them before the LDS-transposed epilogue.
 // NBS = 4: 256-column tiles; NBS = 3: 192-column tiles (N = 768: 63 x 4 = 252 tiles fill the 256 CUs; 256-column tiles give 189).
 typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));   // register image of a 16-byte fragment (an ext vector: usable as an asm operand)
-template <bool F16, int NBS>
+// DBG (diagnostic builds, svt_debug_set key 3 = 31 / 33): 1 = no LDS-DMA after the head of the stream, 3 = no epilogue
+template <bool F16, int NBS, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* wsplit) {
   constexpr int BM = 256, BN = 64 * NBS, BK = 32, NSLOT = 5, SLOT = 2048, GA = 4, GW = NBS;
   constexpr int NB = 4 * NBS;   // 16-column W blocks per tile
@@ -1069,7 +1070,8 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
     if ((Q) == 0) {                                                                                                 \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { raw[mb][0] = xn[mb * 128 + fa0]; raw[mb][1] = xn[mb * 128 + fa1]; } \
     }                                                                                                               \
-    if ((Q) < 2) {   /* A_{g+2} -> the slot W_{g-1} left */                                                         \
+    if (DBG == 1) {                                                                                                 \
+    } else if ((Q) < 2) {   /* A_{g+2} -> the slot W_{g-1} left */                                                  \
       _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
           dma16_asm(asrc[i2] + (long)kc(g + 2) * BK, unit_addr((sw + 3) % NSLOT, i2));                              \
     } else {         /* W_{g+2} -> the slot of A_g */                                                               \
@@ -1107,7 +1109,7 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
       X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
       X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
       X3S_LOAD(3) __builtin_amdgcn_s_barrier(); X3S_MMA(3)
-      wait_vm<GW>();
+      if (DBG != 1) wait_vm<GW>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       X3S_END()
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
       X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
       X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
       X3S_LOAD(3)
-      wait_vm<GW>();
+      if (DBG != 1) wait_vm<GW>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       X3S_MMA(3)
@@ -1138,6 +1140,11 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   __syncthreads();
   const float* bias = p.bias;
   float* patch = (float*)lds + wave * (16 * 68);
+  if constexpr (DBG == 3) {   // every accumulator stays live: a check of two of them lets hipcc delete the MFMAs of all the others
+#pragma unroll
+    for (int i = 0; i < NB; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < NBS; ++g) {
     const BiasRegs br = load_bias_regs<true>(p, bias, lane, g, n0);
@@ -1268,7 +1275,24 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   auto rounds = [](long t) { return (t + 255) / 256; };
   const bool narrow = a.N % 192 == 0 && rounds(t192) * 3 < rounds(t256) * 4;
   prof_begin(s);
-  if (g_gemm_variant == 30) {
+  // persistent form (gemm_x3p.hip: register epilogue, stores under the next tile's MFMAs) wherever it is eligible; 192-column tiles of
+  // the one-tile kernel when they fill the chip better and the launch is a single round anyway (svt_debug_set key 3: 32 = never the
+  // persistent form, 34 = always when eligible -- A/B)
+  // Measured per shape (profiles/r03_gemm_x3_variants.txt): the persistent form is ahead on the launches with a heavy epilogue and
+  // several tiles per CU (conv 1-4, FFN-1: GELU over fp32 outputs), the one-tile kernel on the plain projections (QKV, out-proj, FFN-2).
+  const bool x3p_ok = gemm_x3p_eligible(g) && g_gemm_variant != 30 && g_gemm_variant != 31 && g_gemm_variant != 32 && g_gemm_variant != 33;
+  if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256))) {
+    g.dbg = g_gemm_dbg;
+    if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
+  } else if ((g_gemm_variant == 31 || g_gemm_variant == 33) && kind == 3) {
+    if (g_gemm_variant == 31) {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4, 1>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 4, 1>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+    } else {
+      if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4, 3>, (int)lds_bytes)) return r_;
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 4, 3>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+    }
+  } else if (g_gemm_variant == 30) {
     const int tiles = (int)t256;
     if (kind == 3) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<true>, (int)lds_bytes)) return r_;

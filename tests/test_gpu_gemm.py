@@ -148,6 +148,35 @@ def test_persistent_kernel_exact_integers_under_load(variant):
     assert torch.equal(C, ref)
 
 
+X3P_CASES = [
+    # name, prec, M, N, K, conv, act, bias  -- gemm_x3p_kernel: N % 256 == 0, K % 32 == 0, K >= 64, no residual, act none / GELU
+    ("fp16_conv_gelu_mtail", 3, 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, True),
+    ("bf16_conv_k1024", 2, 4 * 999, 512, 1024, (1999, 999, 2, 512), 1, True),
+    ("fp16_qkv_3_tiles_per_cu", 3, 15968, 2304, 768, None, 0, True),
+    ("fp16_ffn1_gelu", 3, 15968, 3072, 768, None, 1, True),
+    ("bf16_two_slabs_no_bias", 2, 70000, 512, 64, None, 0, False),
+    ("fp16_one_tile_ragged", 3, 845, 512, 256, None, 0, True),
+    ("fp16_n768_single_round", 3, 15968, 768, 3072, None, 0, True),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 34])
+@pytest.mark.parametrize("name,prec,M,N,K,conv,act,bias", X3P_CASES, ids=[c[0] for c in X3P_CASES])
+def test_split_operand_persistent_kernel(variant, name, prec, M, N, K, conv, act, bias):
+    """gemm_x3p_kernel (split-operand products as a persistent staggered stream; svt_debug_set key 3 = 34 forces it wherever it is
+    eligible, 0 = the dispatch's choice) against an fp64 reference: tile boundaries inside a workgroup's stream, M tails, conv rows,
+    GELU, bias fetched in the epilogue."""
+    lib = _lib.load()
+    lib.svt_debug_set(3, variant)
+    try:
+        got, ref = run_gemm(prec, M, N, K, conv, act, 0, False, bias=bias)
+    finally:
+        lib.svt_debug_set(3, 0)
+    assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
+    err = (got - ref).abs().max().item()
+    assert err < {2: 3e-5, 3: 4e-6}[prec] * max(1.0, (K / 768) ** 0.5), (name, variant, err)
+
+
 def test_gemm_rejects_unaligned():
     lib = _lib.load()
     A = torch.zeros(64, 36, device=DEV, dtype=torch.bfloat16)
