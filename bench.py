@@ -45,7 +45,7 @@ import torch  # noqa: E402
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
 
 
 def synth_wav(B, L, seed=1986):
@@ -479,7 +479,7 @@ def main():
         if os.path.exists(PMC_TRAFFIC_FILE) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
             try:
                 pm = json.load(open(PMC_TRAFFIC_FILE))
-                fam = [v for k, v in pm.items() if k.startswith(("gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel", "ffn_fused_kernel"))]
+                fam = [v for k, v in pm.items() if k.startswith(("gemm_pps_kernel", "gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel"))]
                 tot_n = sum(v["launches"] for v in fam)
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
             except Exception:
@@ -514,10 +514,12 @@ def main():
                                                    "norm_all_reduce": "2 x 16 B per step (global-batch norms)" if args.global_norm else None},
             "per_rank_clips_per_s": [round(B * args.steps / t, 3) for t in res["elapsed_per_rank"]],
             "roofline": {"bound": "mfma",
-                         "kernel": ("svt::gemm_kernel<float, 128, 128, SPLIT> (register-staged, fp32 operands cut into 16-bit (hi, lo) pieces on "
-                                    "their way into LDS, three MFMAs per 16x16x32 block)") if split else
-                                   ("svt::gemm_pers_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline: "
-                                    "persistent, one tile per workgroup, or row-complete with fused LayerNorm)"),
+                         "kernel": ("svt::gemm_x3p_kernel / gemm_x3s_kernel (LDS-DMA split-operand products: fp32 activations cut into 16-bit (hi, lo) "
+                                    "pieces in the kernel, pre-cut weight pieces, three MFMAs per 16x16x32 block; staggered 8-slot schedule, "
+                                    "persistent for the GELU launches)") if split else
+                                   ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline, staggered "
+                                    "8-slot schedule: persistent stream of tiles per CU, one tile per workgroup for long-K single-round launches, or "
+                                    "row-complete with fused LayerNorm)"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"GB of HBM traffic per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
