@@ -332,7 +332,6 @@ using namespace svt;
 static int g_debug_keep_split = 0;  // svt_debug_set(12, 1): svt_debug_gemm keeps the split copy of its weight operand between calls
 static int g_conv_ln_bf16 = 1;     // svt_debug_set(9, 0): fp32 conv output + LayerNorm (A/B)
 static int g_fuse_outproj_ln = 1;  // svt_debug_set(5, 0) falls back to GEMM + LayerNorm kernels (A/B measurements)
-static int g_ln_fold = 0;          // svt_debug_set(14, 0): pre-LN encoders keep their standalone residual-add + LayerNorm passes (A/B)
 
 // =================================================================================================
 // encoder
@@ -344,9 +343,6 @@ struct ConvLayerW {
 };
 struct EncLayerW {
   DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, w1, b1, w2, b2, ln2g, ln2b;
-  // LN fold (pre-LN encoders, throughput precisions): W diag(gamma) in the operand type, its row sums (of the STORED values: what the
-  // matrix pipe multiplies), and beta W^T + bias -- for the two products that read a LayerNorm output (QKV: layer_norm, FFN-1: final_layer_norm)
-  DevBuf wqkv_f, s_qkv, t_qkv, w1_f, s_1, t_1;
   DevBuf g_wab, g_bab, g_const;   // WavLM gate: folded gru_rel_pos_linear (2 x dh, 2) and gru_rel_pos_const (H)
 };
 
@@ -364,7 +360,6 @@ struct svt_encoder {
   DevBuf rel_embed;                     // WavLM: (buckets, H) relative position embedding of layer 0
   DevBuf ones, zeros;                   // LayerNorm without affine parameters
   std::vector<EncLayerW> layers;
-  bool ln_fold = false;                 // the folded weights exist (svt_encoder_finalize)
   // optional cross-rank reduction of the wrapper's two whole-batch norm statistics (svt_encoder_set_norm_reduce)
   svt_norm_reduce_fn reduce_fn = nullptr;
   void* reduce_user = nullptr;
@@ -521,7 +516,6 @@ int svt_debug_set(int key, int value) {
   else if (key == 11) g_gemm_x3 = value;
   else if (key == 12) g_debug_keep_split = value;
   else if (key == 13) g_guard_alloc = value;
-  else if (key == 14) g_ln_fold = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -760,9 +754,6 @@ int svt_encoder_finalize(svt_encoder* e) {
 
   e->layers.clear();
   e->layers.resize(c.num_layers);
-  // LN fold: pre-LN (stable_layer_norm) encoders in the throughput precisions whose layer products fit the LDS-DMA kernels
-  const bool fold = c.stable_layer_norm && prec && !c.rel_pos_buckets && (D == 512 || D == 768 || D == 1024) && D % 256 == 0 && F % 256 == 0;
-  e->ln_fold = fold;
   for (int l = 0; l < c.num_layers; ++l) {
     const std::string pre = "encoder.layers." + std::to_string(l) + ".";
     EncLayerW& L = e->layers[l];
@@ -796,34 +787,6 @@ int svt_encoder_finalize(svt_encoder* e) {
     if (int r = upload_f32(L.ln2g, p->v.data(), p->v.size())) return r;
     if (int r = need(P, pre + "final_layer_norm.bias", {D}, &p)) return r;
     if (int r = upload_f32(L.ln2b, p->v.data(), p->v.size())) return r;
-    if (fold) {
-      // y = LN(h) W^T + b  =  rstd_m (h W'^T)  -  rstd_m mean_m s  +  t,   W' = W diag(gamma), s_n = sum_k W'_nk, t_n = sum_k beta_k W_nk + b_n
-      auto fold_one = [&](const std::vector<float>& Wm, const float* bias, size_t N, const std::string& gname, const std::string& bname,
-                          DevBuf& Wf, DevBuf& S, DevBuf& T) -> int {
-        const Param *pg = nullptr, *pb = nullptr;
-        if (int r = need(P, gname, {D}, &pg)) return r;
-        if (int r = need(P, bname, {D}, &pb)) return r;
-        std::vector<float> wf(N * (size_t)D), t(N);
-        for (size_t n = 0; n < N; ++n) {
-          double acc = (double)bias[n];
-          for (int k = 0; k < D; ++k) {
-            const float wv = Wm[n * (size_t)D + k];
-            wf[n * (size_t)D + k] = wv * pg->v[k];
-            acc += (double)pb->v[k] * (double)wv;
-          }
-          t[n] = (float)acc;
-        }
-        if (int r = upload_operand(prec, Wf, wf.data(), wf.size())) return r;
-        if (int r = S.alloc(N * 4)) return r;
-        if (int r = launch_rowsum_operand(Wf.p, (int64_t)N, D, S.as<float>(), 0)) return r;
-        return upload_f32(T, t.data(), t.size());
-      };
-      if (int r = fold_one(wqkv, bqkv.data(), (size_t)3 * D, pre + "layer_norm.weight", pre + "layer_norm.bias", L.wqkv_f, L.s_qkv, L.t_qkv)) return r;
-      const Param *pw1 = nullptr, *pb1 = nullptr;
-      if (int r = need(P, pre + "feed_forward.intermediate_dense.weight", {F, D}, &pw1)) return r;
-      if (int r = need(P, pre + "feed_forward.intermediate_dense.bias", {F}, &pb1)) return r;
-      if (int r = fold_one(pw1->v, pb1->v.data(), (size_t)F, pre + "final_layer_norm.weight", pre + "final_layer_norm.bias", L.w1_f, L.s_1, L.t_1)) return r;
-    }
     if (c.rel_pos_buckets) {
       // gate = a (b const - 1) + 2, a / b = sigmoid of the sums of rows 0-3 / 4-7 of gru_rel_pos_linear(x_head): fold the row sums
       const int Hh = c.num_heads, dhh = D / Hh;
@@ -885,8 +848,6 @@ struct EncWs {
   void* attn_o;
   void* ffn;
   float* dots;      // fused tail: raw head dots, rows x 32
-  float* rstat;     // LN fold: (rstd, rstd * mean) per row
-  float* rpart;     // LN fold: per-row partial (sum, sum of squares) per 64-column group
   size_t total;
 };
 
@@ -940,8 +901,6 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.gate = c.rel_pos_buckets ? (float*)cv.take((size_t)B * H * T * 4) : nullptr;
   w.relpb = c.rel_pos_buckets ? (float*)cv.take((size_t)H * (2 * T - 1) * 4) : nullptr;
   w.dots = (float*)cv.take(rows * 32 * 4);
-  w.rstat = e->ln_fold ? (float*)cv.take(rows * 2 * 4) : nullptr;
-  w.rpart = e->ln_fold ? (float*)cv.take(rows * (size_t)(D / 64) * 2 * 4) : nullptr;
   w.total = cv.off;
   return w;
 }
@@ -1275,39 +1234,6 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     final_x = w.xF;
   } else {
     float* h = w.preF;
-    if (e->ln_fold && g_ln_fold && rows >= 4096 && w.rstat) {
-      // LN fold: no standalone residual-add + LayerNorm pass.  The products that read a LayerNorm output (QKV,
-      // FFN-1) run on the UN-normalised residual stream in the operand type (hh) against W diag(gamma), and their epilogue applies
-      // the row statistics: r_m acc - r_m mean_m s_n + t_n.  The branch products (out-projection, FFN-2) add the fp32 residual in
-      // their epilogue (h += branch, in place) and leave hh = cast(h) and the per-row partial sums for the next statistics.
-      const int n_part = D / 64;
-      if (int r = launch_rowstats_cast(h, rows, D, eps, w.xb, w.rstat, s)) return r;
-      auto consumer = [&](const DevBuf& Wf, const DevBuf& S, const DevBuf& Tt, int N, void* Cout, int act) -> int {
-        GemmArgs g;
-        g.A = w.xb; g.W = Wf.p; g.C = Cout; g.bias = Tt.as<float>(); g.colsum = S.as<float>(); g.rstat = w.rstat;
-        g.M = (int)rows; g.N = N; g.K = D; g.a_rpb = (int)rows; g.a_rstride = D; g.ldw = D; g.ldc = N; g.out_f32 = 0; g.act = act;
-        return launch_gemm(gp, g, s);
-      };
-      auto producer = [&](const void* A, int K, const DevBuf& Wm, const DevBuf& bias) -> int {
-        GemmArgs g;
-        g.A = A; g.W = Wm.p; g.C = h; g.bias = bias.as<float>(); g.resid = h;
-        g.M = (int)rows; g.N = D; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = D; g.out_f32 = 1; g.act = ACT_NONE;
-        g.c_cast = w.xb; g.row_part = w.rpart; g.row_part_n = n_part;
-        if (int r = launch_gemm(gp, g, s)) return r;
-        return launch_rowstats_finalize(w.rpart, rows, n_part, D, eps, w.rstat, s);
-      };
-      for (int l = 0; l < c.num_layers; ++l) {
-        const EncLayerW& Lw = e->layers[l];
-        if (int r = consumer(Lw.wqkv_f, Lw.s_qkv, Lw.t_qkv, 3 * D, w.qkv, ACT_NONE)) return r;
-        if (int r = attention()) return r;
-        if (int r = producer(w.attn_o, D, Lw.wo, Lw.bo)) return r;
-        if (int r = consumer(Lw.w1_f, Lw.s_1, Lw.t_1, F, w.ffn, ACT_GELU)) return r;
-        if (int r = producer(w.ffn, F, Lw.w2, Lw.b2)) return r;
-      }
-      float* fin = (float*)w.qkv;
-      if (int r = launch_layernorm(prec, h, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, fin, s, nullptr, nullptr)) return r;
-      final_x = fin;
-    } else {
     const void* pending = nullptr;  // branch output not yet added to h
     // branch outputs in the operand type in throughput mode (bf16: half the GEMM store burst and 2 of the 14 bytes per
     // element the LayerNorm moves); the fp32 residual stream h is updated in place by the LayerNorm kernel (sumF)
@@ -1333,7 +1259,6 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     float* fin = (float*)w.qkv;
     if (int r = ln_add(e->enc_g.as<float>(), e->enc_b.as<float>(), pending, nullptr, fin)) return r;
     final_x = fin;
-    }
   }
   // ---- wrapper's whole-batch output LayerNorm (+ frame head + decode when a head was given) ----
   const int64_t n_out = rows * D;

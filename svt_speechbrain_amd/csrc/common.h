@@ -169,17 +169,6 @@ struct GemmArgs {
   long plane_stride = 0;
   int planes_f16 = 0;          // piece type: 1 = IEEE half, 0 = bf16
   long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
-  // ---- LayerNorm folded into the products around it (pre-LN encoders, throughput precisions; api.hip "LN fold") ----
-  // producer (fp32 C, usually with C == resid: h += branch): the LDS-transposed epilogue of gemm_pp8_kernel also writes the result in
-  // the operand type (c_cast, same indexing as C: the next product's A operand) and, per row and 64-column group of the tile, the
-  // partial (sum, sum of squares) of the result into row_part[(row * row_part_n + column / 64) * 2 ..] -- one writer per slot
-  void* c_cast = nullptr;
-  float* row_part = nullptr;
-  int row_part_n = 0;
-  // consumer (gemm_pps_kernel): C = r_m * acc - (r mu)_m * colsum_n + bias_n with (r, r mu) pairs per row in rstat: the product runs on
-  // the UN-normalised rows, gamma is folded into W, beta into the bias
-  const float* rstat = nullptr;
-  const float* colsum = nullptr;
 };
 
 // operand type: 0 = fp32 (v_mfma_f32_16x16x4_f32, exact fp32 fma chain), 1 = bf16 (v_mfma_f32_16x16x32_bf16)
@@ -190,8 +179,6 @@ bool gemm_dma_eligible(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s);
 // persistent + staggered form of the LDS-DMA pipeline (gemm_pps.hip): bf16 output, no residual, activation none / GELU
 bool gemm_pps_eligible(const GemmArgs& a);
-bool gemm_pps_resup_eligible(const GemmArgs& a);   // LayerNorm-fold producer (fp32 C = resid + product, operand-type copy, row partials)
-int launch_gemm_pps_resup(const GemmArgs& a, int bm, hipStream_t s);
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy = 0);   // 0 default, 1 nt, 2 sc1 stores
 // small problems (a single utterance): 64 x 64 tiles, K split four ways inside the workgroup, operands straight from L2
 bool gemm_skinny_eligible(const GemmArgs& a);
@@ -242,11 +229,6 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s,
                      const float* add = nullptr, float* sumF = nullptr);
 
-// LN fold helpers (kernels.hip): operand-type copy + finalized (rstd, rstd * mean) per row of an fp32 (rows, D) tensor (D in
-// {512, 768, 1024}); the same pair from the producer epilogue's per-row partials; row sums of an operand-type (N, K) matrix
-int launch_rowstats_cast(const float* x, int64_t rows, int D, float eps, void* yT, float* rstat, hipStream_t s);
-int launch_rowstats_finalize(const float* row_part, int64_t rows, int n_part, int D, float eps, float* rstat, hipStream_t s);
-int launch_rowsum_operand(const void* w, int64_t n_rows, int K, float* out, hipStream_t s);
 // conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
 int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,
                                 double* wm /*B x 65*/, hipStream_t s);

@@ -526,11 +526,7 @@ int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
     if (split == 2) return narrow ? launch_one<float, 256, 64, true, 2, 1>(g, s) : launch_one<float, 128, 128, true, 2, 2, 2>(g, s);
     return narrow ? launch_one<float, 256, 64, true>(g, s) : launch_one<float, 128, 128, true>(g, s);
   }
-  if ((g.c_cast || g.row_part || g.rstat) && !(prec && gemm_dma_eligible(g))) {
-    set_error("gemm: the LayerNorm-fold epilogues exist on the LDS-DMA kernels only (K % 64, N >= 128, M >= 128)");
-    return -1;
-  }
-  if (prec && g_gemm_skinny && gemm_skinny_eligible(g) && !g.c_cast && !g.row_part && !g.rstat) return launch_gemm_skinny(g, s);
+  if (prec && g_gemm_skinny && gemm_skinny_eligible(g)) return launch_gemm_skinny(g, s);
   if (prec && gemm_dma_eligible(g)) return launch_gemm_dma(g, s);
   if (prec) return narrow ? launch_one<bf16_t, 256, 64>(g, s) : launch_one<bf16_t, 128, 128>(g, s);
   if (split && g_gemm_x3) {

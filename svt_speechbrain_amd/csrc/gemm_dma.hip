@@ -94,7 +94,6 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
         const int r = pass * 4 + (lane >> 4);
         const int m = mbase + r;
         float4 v = *(const float4*)(patch + r * PITCH + c4);
-        float rs1 = 0.f, rs2 = 0.f;   // LN fold: this lane's share of the row's (sum, sum of squares)
         if (m < p.M && n < p.N) {
           v.x = apply_act(v.x + b4.x, p.act); v.y = apply_act(v.y + b4.y, p.act);
           v.z = apply_act(v.z + b4.z, p.act); v.w = apply_act(v.w + b4.w, p.act);
@@ -103,13 +102,6 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
             const float4 r4 = *(const float4*)(p.resid + idx);
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
           }
-          if (p.c_cast) {
-            bf16x4 o;
-            o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
-            *(bf16x4*)((bf16_t*)p.c_cast + idx) = o;
-          }
-          rs1 = (v.x + v.y) + (v.z + v.w);
-          rs2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
           if (p.planes) {   // (hi, lo) planes instead of fp32 (GemmArgs::planes): 8 + 8 bytes per lane, whole 128-byte lines per row
             const float x[4] = {v.x, v.y, v.z, v.w};
             unsigned short hi[4], lo[4];
@@ -128,12 +120,6 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
           } else {
             *(float4*)((float*)p.C + idx) = v;
           }
-        }
-        if (p.row_part) {   // wave-uniform: the 16 lanes of a row fold their shares (fixed order: deterministic), lane 0 of the row stores
-#pragma unroll
-          for (int o = 8; o >= 1; o >>= 1) { rs1 += __shfl_xor(rs1, o); rs2 += __shfl_xor(rs2, o); }
-          if ((lane & 15) == 0 && m < p.M && n < p.N)
-            *(float2*)(p.row_part + ((long)m * p.row_part_n + (n0 + wn * 64) / 64) * 2) = float2{rs1, rs2};
         }
       }
     } else {
@@ -1385,13 +1371,6 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   // main loop is ~10 % faster per slab.  Measured per shape: profiles/r03_gemm_yardstick.txt.  Write-through (sc1) stores: the
   // output leaves L2 while the kernel runs instead of at the kernel boundary (FFN-1: 98 MB, 16 us).
   // svt_debug_set key 3: 50 / 60 / 70 force it with default / nt / sc1 stores (53: without epilogue), 49 switches it off.
-  // LayerNorm-fold producer (h += branch in the epilogue): the persistent kernel, whose stores drain under the next tile; the one-tile
-  // kernel's LDS-transposed form of the same epilogue (below) costs ~33 us per 256 x 256 tile (svt_debug_set key 3 = 48: A/B)
-  if (a.c_cast && a.row_part && g_gemm_variant != 48 && gemm_pps_resup_eligible(a)) return launch_gemm_pps_resup(a, best == 192 ? 192 : 256, s);
-  if (a.rstat) {   // LayerNorm-fold consumer epilogue: gemm_pps_kernel only
-    if (!gemm_pps_eligible(a)) { set_error("gemm: the LayerNorm-fold consumer needs a gemm_pps-eligible product (bf16 C, N % 256 == 0, K % 64 == 0)"); return -1; }
-    return launch_gemm_pps(a, best == 192 ? 192 : 256, s, 2);
-  }
   if (g_gemm_variant >= 50 && g_gemm_variant < 80 && gemm_pps_eligible(a)) {
     GemmArgs b = a;
     b.dbg = g_gemm_variant % 10;

@@ -46,10 +46,7 @@ template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
 }
 
 // STAUX: cache policy of the epilogue stores (buffer instruction aux bits: 0 = default write-back, 2 = nt, 16 = sc1 write-through)
-// ROWAFF: the LayerNorm-fold consumer epilogue (GemmArgs::rstat / colsum): C = r_m * acc - (r mu)_m * colsum_n + bias_n
-// RESUP:  the LayerNorm-fold producer epilogue: fp32 C = resid + acc + bias (C == resid allowed: h += branch), the same values in the
-//         operand type to c_cast, and per row and 64-column group the partial (sum, sum of squares) to row_part
-template <int BM, int ACT, int STAUX, bool ROWAFF = false, bool RESUP = false>
+template <int BM, int ACT, int STAUX>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -109,7 +106,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   // diagnostics (tools/gemm_trace.py, dbg = 9 sets p.trace): s_memrealtime (100 MHz) stamps at entry / first slab / around every
   // epilogue / exit, s_memtime (core clock) over the stream; dbg 1 = no LDS-DMA after the head of the stream, 3 = no epilogue
   const bool tr = p.trace != nullptr;
-  const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr && !ROWAFF;   // ROWAFF: the column terms are fetched in the epilogue
+  const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
   long long t_begin = 0, t_first = 0, t_epi = 0, c_first = 0;
   if (tr) t_begin = wall_clock64();
   setup(lbase, aof, wof);
@@ -152,93 +149,16 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     float bv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = bq[j >> 2][j & 3];
-    // LayerNorm fold: (rstd, rstd * mean) of this lane's 4 MB rows and the column sums of its 8 columns, fetched here with ordinary
-    // loads (their wait also covers the last slab's ring requests; the registers are the dead fragment registers).  The lane index is
-    // laundered so that hipcc does not hoist these addresses out of the slab loop (gemm_x3p.hip).
-    float2 rst[2][4];   // (rstd, rstd * mean) of the four rows of block mb (slot mb & 1): block mb + 1 is fetched while block mb is stored
-    float sv[8];
-    int row0 = 0;
-    auto load_rst = [&](int mb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = row0 + mb * 16 + r;
-        if (row > p.M - 1) row = p.M - 1;
-        rst[mb & 1][r] = ((const float2*)p.rstat)[row];
-      }
-    };
-    if constexpr (ROWAFF) {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      row0 = m0 + wm * (BM / 4) + 4 * (ln >> 4);
-      const int col0 = n0 + wn * 128 + (ln & 15) * 8;
-      const float4 s0 = *(const float4*)(p.colsum + col0), s1 = *(const float4*)(p.colsum + col0 + 4);
-      const float4 t0 = *(const float4*)(p.bias + col0), t1 = *(const float4*)(p.bias + col0 + 4);
-      sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
-      bv[0] = t0.x; bv[1] = t0.y; bv[2] = t0.z; bv[3] = t0.w; bv[4] = t1.x; bv[5] = t1.y; bv[6] = t1.z; bv[7] = t1.w;
-      load_rst(0);
-    }
-    if constexpr (RESUP) {
-      // h += branch: per 16-row block the lane's 4 rows x 8 columns of the fp32 residual are fetched with ordinary loads (one wait
-      // per block: 32 registers, the dead fragment registers), updated, and stored three ways
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const long hrow0 = (long)(m0 + wm * (BM / 4) + 4 * (ln >> 4));
-      const int hcol = n0 + wn * 128 + (ln & 15) * 8;
-      float* const hC = (float*)p.C;
-      bf16_t* const hT = (bf16_t*)p.c_cast;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        float4 hv[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          long row = hrow0 + mb * 16 + r;
-          if (row > p.M - 1) row = p.M - 1;
-          const float4* hp = (const float4*)(p.resid + row * p.ldc + hcol);
-          hv[r][0] = hp[0]; hv[r][1] = hp[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long row = hrow0 + mb * 16 + r;
-          float v[8] = {hv[r][0].x, hv[r][0].y, hv[r][0].z, hv[r][0].w, hv[r][1].x, hv[r][1].y, hv[r][1].z, hv[r][1].w};
-          float s1 = 0.f, s2 = 0.f;
-          bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] += acc[j][mb][r] + bv[j];
-            s1 += v[j];
-            s2 = fmaf(v[j], v[j], s2);
-            o[j] = (bf16_t)v[j];
-          }
-          // the 8 lanes that share a row and a 64-column group fold their shares in a fixed order
-#pragma unroll
-          for (int x = 4; x >= 1; x >>= 1) { s1 += __shfl_xor(s1, x); s2 += __shfl_xor(s2, x); }
-          if (row < p.M) {
-            float4* cp = (float4*)(hC + row * p.ldc + hcol);
-            cp[0] = float4{v[0], v[1], v[2], v[3]};
-            cp[1] = float4{v[4], v[5], v[6], v[7]};
-            *(bf16x8*)(hT + row * p.ldc + hcol) = o;
-            if ((ln & 7) == 0) *(float2*)(p.row_part + (row * p.row_part_n + hcol / 64) * 2) = float2{s1, s2};
-          }
-        }
-      }
-    } else
     if (!no_epi) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      if constexpr (ROWAFF) { if (mb + 1 < MB) load_rst(mb + 1); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         bf16x8 o;
-        float av[8];   // the pre-activation values of this row's 8 columns
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if constexpr (ROWAFF) av[j] = fmaf(rst[mb & 1][r].x, acc[j][mb][r], fmaf(-rst[mb & 1][r].y, sv[j], bv[j]));
-          else av[j] = acc[j][mb][r] + bv[j];
-        }
         if constexpr (ACT == ACT_GELU) {
           f32x2_t g[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] = f32x2_t{av[2 * j], av[2 * j + 1]};
+          for (int j = 0; j < 4; ++j) g[j] = f32x2_t{acc[2 * j][mb][r] + bv[2 * j], acc[2 * j + 1][mb][r] + bv[2 * j + 1]};
           gelu_bf16x2_x4(g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -247,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)av[j];
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j][mb][r] + bv[j]);
         }
         // the row inside the wave's tile goes into the VECTOR offset: (i) the range check of a raw buffer covers voffset only,
         // a row >= M addressed through soffset would be written; (ii) with an SGPR in the soffset field hipcc (ROCm 7.2) assumes
@@ -378,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   if (tr) t_loop = wall_clock64();
   // the surplus requests of the stream's tail: nothing may land in LDS after the workgroup is gone.  They are older than the last
   // epilogue's MB * 4 stores, which need not be waited for (VMEM operations retire in order).
-  if (no_epi || RESUP) wait_vm<0>(); else wait_vm<MB * 4>();
+  if (no_epi) wait_vm<0>(); else wait_vm<MB * 4>();
   if (tr && lane == 0 && (wave & 3) == 0) {
     const long long t_end = t_loop;
     long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 2)) * 8;
@@ -392,17 +312,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #undef PPS_ADVANCE
 }
 
-template <int BM, int ACT, int STAUX = 0, bool ROWAFF = false, bool RESUP = false>
+template <int BM, int ACT, int STAUX = 0>
 int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, ROWAFF, RESUP>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, ROWAFF, RESUP>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -414,18 +334,6 @@ int launch_pps_t(const GemmArgs& a, hipStream_t s) {
 static unsigned long a_span_bytes(const GemmArgs& a) {
   const long last = (long)a.M - 1;
   return (unsigned long)(((last / a.a_rpb) * a.a_bstride + (last % a.a_rpb) * a.a_rstride + a.K) * 2);
-}
-
-// the LayerNorm-fold producer: fp32 C = resid + product + bias with the operand-type copy and the row partials (RESUP epilogue)
-bool gemm_pps_resup_eligible(const GemmArgs& a) {
-  return !a.gen && a.nz == 1 && a.resid && a.out_f32 && a.c_cast && a.row_part && !a.planes && a.alpha == 1.f && a.act == ACT_NONE &&
-         a.K % 64 == 0 && a.K >= 128 && a.N % 256 == 0 && a.M >= 128 && a.c_vec && a.ldc % 8 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
-         a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0 && a_span_bytes(a) < 0xFFFF0000ul &&
-         (unsigned long)a.N * a.ldw * 2 < 0xFFFF0000ul && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 &&
-         (a.a_rstride & 7) == 0 && (a.a_bstride & 7) == 0 && (a.ldw & 7) == 0 && a.row_part_n * 64 == a.N;
-}
-int launch_gemm_pps_resup(const GemmArgs& a, int bm, hipStream_t s) {
-  return bm == 192 ? launch_pps_t<192, ACT_NONE, 0, false, true>(a, s) : launch_pps_t<256, ACT_NONE, 0, false, true>(a, s);
 }
 
 bool gemm_pps_eligible(const GemmArgs& a) {
@@ -449,11 +357,6 @@ static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
 }
 
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) {
-  if (a.rstat) {   // LayerNorm-fold consumer (QKV / FFN-1 of the pre-LN encoders): write-through stores, 256- or 192-row tiles
-    if (!a.colsum || !a.bias) { set_error("gemm: the LayerNorm-fold epilogue needs rstat, colsum and bias"); return -1; }
-    if (a.act == ACT_GELU) return bm == 192 ? launch_pps_t<192, ACT_GELU, 16, true>(a, s) : launch_pps_t<256, ACT_GELU, 16, true>(a, s);
-    return bm == 192 ? launch_pps_t<192, ACT_NONE, 16, true>(a, s) : launch_pps_t<256, ACT_NONE, 16, true>(a, s);
-  }
   if (store_policy == 1) return launch_pps_aux<2>(a, bm, s);    // nt
   if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
   return launch_pps_aux<0>(a, bm, s);

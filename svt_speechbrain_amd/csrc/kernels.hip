@@ -1231,77 +1231,6 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
   return 0;
 }
 
-// ---- LayerNorm fold helpers (api.hip, pre-LN encoders in the throughput precisions) ----
-// x (rows, D = 64 VPT) fp32 -> operand-type copy + (rstd, rstd * mean) per row; statistics as in layernorm_f32_vec_kernel
-template <int VPT>
-__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* x, int64_t rows, float eps, bf16_t* yT, float* rstat) {
-  constexpr int D = 64 * VPT, NV = VPT / 4;
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float v[VPT];
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const float4 t = ((const float4*)(x + row * D))[lane + 64 * j];
-    bf16x4 o;
-    o[0] = (bf16_t)t.x; o[1] = (bf16_t)t.y; o[2] = (bf16_t)t.z; o[3] = (bf16_t)t.w;
-    *(bf16x4*)(yT + row * D + (lane + 64 * j) * 4) = o;
-    v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-    s += (t.x + t.y) + (t.z + t.w);
-  }
-  const float mean = wave_sum(s) * (1.f / D);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < VPT; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
-  const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
-  if (lane == 0) *(float2*)(rstat + row * 2) = float2{rstd, rstd * mean};
-}
-// per-row partial (sum, sum of squares) over n_part 64-column groups -> (rstd, rstd * mean); sums folded in double, fixed order
-__global__ void rowstats_finalize_kernel(const float* part, int64_t rows, int n_part, int D, float eps, float* rstat) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  const float2* p2 = (const float2*)part + row * n_part;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < n_part; ++i) { const float2 t = p2[i]; s1 += (double)t.x; s2 += (double)t.y; }
-  const double mean = s1 / D;
-  double var = s2 / D - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  *(float2*)(rstat + row * 2) = float2{rstd, rstd * (float)mean};
-}
-// out[n] = sum_k w[n][k] of an operand-type matrix (the values the matrix pipe will multiply), one wave per row
-__global__ __launch_bounds__(256) void rowsum_operand_kernel(const bf16_t* w, int64_t n_rows, int K, float* out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
-  double s = 0.0;
-  for (int k = lane; k < K; k += 64) s += (double)(float)w[row * K + k];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) out[row] = (float)s;
-}
-
-int launch_rowstats_cast(const float* x, int64_t rows, int D, float eps, void* yT, float* rstat, hipStream_t s) {
-  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (D == 512) hipLaunchKernelGGL((rowstats_cast_kernel<8>), grid, block, 0, s, x, rows, eps, (bf16_t*)yT, rstat);
-  else if (D == 768) hipLaunchKernelGGL((rowstats_cast_kernel<12>), grid, block, 0, s, x, rows, eps, (bf16_t*)yT, rstat);
-  else if (D == 1024) hipLaunchKernelGGL((rowstats_cast_kernel<16>), grid, block, 0, s, x, rows, eps, (bf16_t*)yT, rstat);
-  else { set_error("rowstats_cast: D must be 512, 768 or 1024"); return -1; }
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-int launch_rowstats_finalize(const float* row_part, int64_t rows, int n_part, int D, float eps, float* rstat, hipStream_t s) {
-  hipLaunchKernelGGL(rowstats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, row_part, rows, n_part, D, eps, rstat);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-int launch_rowsum_operand(const void* w, int64_t n_rows, int K, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(rowsum_operand_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)w, n_rows, K, out);
-  SVT_LAUNCH_CHECK();
-  return 0;
-}
-
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s, const float* add,
                      float* sumF) {
