@@ -168,6 +168,7 @@ struct GemmArgs {
   unsigned short* planes = nullptr;
   long plane_stride = 0;
   int planes_f16 = 0;          // piece type: 1 = IEEE half, 0 = bf16
+  int stamp_ends = 0;           // diagnostics (gemm_pps_kernel slot stamps): 0 = slot starts, 1 = slot ends
   long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
 };
 
@@ -195,6 +196,7 @@ extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
+extern int g_stamp_ends;
 extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debug_set)
 extern int g_gemm_force_bm;
 extern int g_gemm_ring;

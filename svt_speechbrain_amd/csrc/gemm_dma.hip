@@ -1332,6 +1332,7 @@ bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 &
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
 int g_gemm_variant = 0;
+int g_stamp_ends = 0;   // gemm_pps_kernel slot stamps (tools/gemm_trace.py --slots): 0 = slot starts, 1 = slot ends
 int g_gemm_ring = 0;  // 0 = auto; 2 = force the one-tile-per-workgroup kernel, 4 = force the persistent kernel (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
@@ -1374,6 +1375,7 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   if (g_gemm_variant >= 50 && g_gemm_variant < 80 && gemm_pps_eligible(a)) {
     GemmArgs b = a;
     b.dbg = g_gemm_variant % 10;
+    b.stamp_ends = g_stamp_ends;
     return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, (g_gemm_variant - 50) / 10);
   }
   if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 200 && (ntiles > 256 || a.K < 2048) && gemm_pps_eligible(a))

@@ -46,7 +46,8 @@ template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
 }
 
 // STAUX: cache policy of the epilogue stores (buffer instruction aux bits: 0 = default write-back, 2 = nt, 16 = sc1 write-through)
-template <int BM, int ACT, int STAUX>
+// STAMP (tools/gemm_trace.py --slots): s_memtime at both ends of every slot of one slab of the stream, per wave
+template <int BM, int ACT, int STAUX, int STAMP = 0>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -128,6 +129,22 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int sa = 0, sw = 1, kt = 0, ti = 0;
   const int grp = wave >> 2;   // = wn
+  // slot stamps of slab gs (dbg 5: middle of the second tile, 6: last slab of the first tile, 7: first slab of the second)
+  unsigned raw[9], st[9];   // STAMP 1: both ends of slots 0-3 (stamps 0..8), 2: of slots 4-7 (stamps 8..15 + the next slab's first)
+  const int gs = p.dbg == 6 ? nk - 1 : p.dbg == 7 ? nk : (my_tiles > 1 ? nk + nk / 2 : nk / 2);
+  if constexpr (STAMP) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st[i] = 0;
+  }
+#define PPS_S(k)                                                                                        \
+  if constexpr (STAMP == 1 && (k) <= 8) raw[(k) % 9] = (unsigned)__builtin_amdgcn_s_memtime();                \
+  if constexpr (STAMP == 2 && (k) >= 8) raw[((k) - 8) & 7] = (unsigned)__builtin_amdgcn_s_memtime();\
+  if constexpr (STAMP == 2 && (k) == 0) raw[8] = (unsigned)__builtin_amdgcn_s_memtime();
+#define PPS_COMMIT()                                                              \
+  if constexpr (STAMP) {                                                          \
+    if (g == gs) { _Pragma("unroll") for (int i = 0; i < (STAMP == 1 ? 9 : 8); ++i) st[i] = raw[i]; } \
+    if (STAMP == 2 && g == gs + 1) st[8] = raw[8];                                \
+  }
 
   // ---- the tile's epilogue: accumulators -> (+ bias, activation) -> bf16 -> buffer stores; clears the accumulators and
   //      rotates the source offsets to the next tile ----
@@ -269,12 +286,14 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       if (pending) epilogue();
       if (g == G) break;
       PPS_SLAB_VARS()
-      PPS_LOAD(0) __builtin_amdgcn_s_barrier(); PPS_MMA(0) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(1) __builtin_amdgcn_s_barrier(); PPS_MMA(1) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(2) __builtin_amdgcn_s_barrier(); PPS_MMA(2) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(3) __builtin_amdgcn_s_barrier(); PPS_MMA(3)
+      PPS_S(0) PPS_LOAD(0) PPS_S(1) __builtin_amdgcn_s_barrier(); PPS_S(2) PPS_MMA(0) PPS_S(3) __builtin_amdgcn_s_barrier();
+      PPS_S(4) PPS_LOAD(1) PPS_S(5) __builtin_amdgcn_s_barrier(); PPS_S(6) PPS_MMA(1) PPS_S(7) __builtin_amdgcn_s_barrier();
+      PPS_S(8) PPS_LOAD(2) PPS_S(9) __builtin_amdgcn_s_barrier(); PPS_S(10) PPS_MMA(2) PPS_S(11) __builtin_amdgcn_s_barrier();
+      PPS_S(12) PPS_LOAD(3) PPS_S(13) __builtin_amdgcn_s_barrier(); PPS_S(14) PPS_MMA(3)
       PPS_RETIRE()
+      PPS_S(15)
       __builtin_amdgcn_s_barrier();
+      PPS_COMMIT()
       pending = last_k;
       PPS_ADVANCE()
     }
@@ -282,15 +301,18 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     __builtin_amdgcn_s_barrier();  // one slot behind
     for (int g = 0; g < G; ++g) {
       PPS_SLAB_VARS()
-      PPS_LOAD(0) __builtin_amdgcn_s_barrier(); PPS_MMA(0) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(1) __builtin_amdgcn_s_barrier(); PPS_MMA(1) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(2) __builtin_amdgcn_s_barrier(); PPS_MMA(2) __builtin_amdgcn_s_barrier();
-      PPS_LOAD(3)
+      PPS_S(0) PPS_LOAD(0) PPS_S(1) __builtin_amdgcn_s_barrier(); PPS_S(2) PPS_MMA(0) PPS_S(3) __builtin_amdgcn_s_barrier();
+      PPS_S(4) PPS_LOAD(1) PPS_S(5) __builtin_amdgcn_s_barrier(); PPS_S(6) PPS_MMA(1) PPS_S(7) __builtin_amdgcn_s_barrier();
+      PPS_S(8) PPS_LOAD(2) PPS_S(9) __builtin_amdgcn_s_barrier(); PPS_S(10) PPS_MMA(2) PPS_S(11) __builtin_amdgcn_s_barrier();
+      PPS_S(12) PPS_LOAD(3)
       PPS_RETIRE()
+      PPS_S(13)
       __builtin_amdgcn_s_barrier();
-      PPS_MMA(3)
+      PPS_S(14) PPS_MMA(3)
       if (last_k) epilogue();
+      PPS_S(15)
       if (g + 1 < G) __builtin_amdgcn_s_barrier();
+      PPS_COMMIT()
       PPS_ADVANCE()
     }
   }
@@ -305,6 +327,16 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     o[0] = t_begin; o[1] = t_first; o[2] = t_end - t_first - t_epi; o[3] = t_epi; o[4] = t_end; o[5] = my_tiles;
     o[6] = __builtin_amdgcn_s_memtime() - c_first; o[7] = BM;
   }
+  if constexpr (STAMP) {
+    if (tr && lane == 0) {
+      long long* o = p.trace + 65536 + ((long)blockIdx.x * 8 + wave) * 32;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o[i] = st[i];
+      o[9] = G; o[10] = gs; o[11] = STAMP;
+    }
+  }
+#undef PPS_S
+#undef PPS_COMMIT
 #undef PPS_LOAD
 #undef PPS_MMA
 #undef PPS_RETIRE
@@ -312,17 +344,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #undef PPS_ADVANCE
 }
 
-template <int BM, int ACT, int STAUX = 0>
+template <int BM, int ACT, int STAUX = 0, int STAMP = 0>
 int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -346,6 +378,12 @@ bool gemm_pps_eligible(const GemmArgs& a) {
 
 template <int STAUX>
 static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
+  if constexpr (STAUX == 16) {   // slot stamps: the dispatched store policy, 256-row tiles only
+    if (a.trace && bm == 256 && a.dbg >= 5 && a.dbg <= 7) {
+      if (a.stamp_ends) return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 2>(a, s) : launch_pps_t<256, ACT_NONE, 16, 2>(a, s);
+      return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 1>(a, s) : launch_pps_t<256, ACT_NONE, 16, 1>(a, s);
+    }
+  }
   if (a.act == ACT_GELU) {
     if (bm == 256) return launch_pps_t<256, ACT_GELU, STAUX>(a, s);
     if (bm == 192) return launch_pps_t<192, ACT_GELU, STAUX>(a, s);

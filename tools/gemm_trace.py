@@ -25,7 +25,11 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="extra diagnostic variant: 10 = no stores, 11 = no pointer setup")
     ap.add_argument("--force-variant", type=int, default=0, help="svt_debug_set key 3 for the whole run (50 = the persistent staggered kernel, "
                     "51 / 53 / 54 = without LDS-DMA / epilogue / both)")
+    ap.add_argument("--slots", type=int, default=0, help="gemm_pps_kernel slot stamps of one slab: 5 = middle of the second tile, 6 = last slab of "
+                    "the first tile, 7 = first slab of the second tile (uses --force-variant 70 + this digit)")
     a = ap.parse_args()
+    if a.slots:
+        a.force_variant = 70 + a.slots
     lib = _lib.load()
     lib.svt_debug_set(1, a.bm)
     lib.svt_debug_set(2, a.ring)
@@ -102,7 +106,36 @@ def main():
                   f"(min {mhz.min():.0f}, max {mhz.max():.0f}); MFMA pipe busy for {busy.mean():.2f} of the main-loop cycles "
                   f"(1024 bf16 FLOP/clk/SIMD)")
         print(f"  tiles per workgroup: min {int(t[:,5].min())} max {int(t[:,5].max())}")
-        lib.svt_debug_set(0, 0)
+        if a.slots:
+            def stamps():
+                r = trace[65536:65536 + 256 * 8 * 32].view(256, 8, 32).cpu()
+                return r[r[:, 0, 9] > 0]
+            starts = stamps()
+            lib.svt_debug_set(15, 1)
+            trace.zero_()
+            call(9)
+            torch.cuda.synchronize()
+            ends = stamps()
+            lib.svt_debug_set(15, 0)
+            # launch 1 holds stamps 0..8 (both ends of slots 0-3), launch 2 stamps 8..16 (slots 4-7 and the next slab's start)
+            def d(x, y):
+                return ((y - x) & 0xFFFFFFFF).double()
+            names0 = ["LOAD0", "MMA0", "LOAD1", "MMA1", "LOAD2", "MMA2", "LOAD3", "MMA3+retire"]
+            names1 = ["LOAD0", "MMA0", "LOAD1", "MMA1", "LOAD2", "MMA2", "LOAD3+retire", "MMA3(+epi)"]
+            print(f"  slab {int(starts[0,0,10])} of {int(starts[0,0,9])}: core cycles per slot, work = slot start .. the wave's arrival at the barrier, "
+                  f"wait = arrival .. release; median over {starts.shape[0]} workgroups x 4 waves")
+            for grp, names in ((0, names0), (1, names1)):
+                w = slice(4 * grp, 4 * grp + 4)
+                tot = 0.0
+                print(f"   waves {4*grp}-{4*grp+3}:")
+                for k in range(8):
+                    src = starts if k < 4 else ends
+                    b = 2 * (k & 3)
+                    work = d(src[:, w, b], src[:, w, b + 1]).median().item()
+                    wait = d(src[:, w, b + 1], src[:, w, b + 2]).median().item()
+                    tot += work + wait
+                    print(f"     {names[k]:14s} work {work:6.0f}   wait {wait:6.0f}")
+                print(f"     slab total {tot:.0f} cycles (2048 = the MFMA pipe's share)")
 
 
 if __name__ == "__main__":

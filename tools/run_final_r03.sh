@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_final
 mkdir -p $O
+(time python -m pytest tests -q -m gpu -x 2>&1 | tail -5) > $O/r03_gputests.log 2>&1
 python bench.py > $O/r03_bench.json 2> $O/bench.err
 python bench.py --no-cpu-baseline --streams 1 > $O/r03_bench_streams1.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --precision fp16 > $O/r03_bench_fp16.json 2>> $O/bench.err
@@ -27,11 +28,11 @@ bash tools/pmc.sh r03_final/pmc_write WRITE_SIZE -- $GRAFT_REPO_ROOT/bench.py --
 bash tools/pmc.sh r03_final/pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --streams 1
 bash tools/pmc.sh r03_final/pmc_mfma_x3 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --streams 1 --precision fp16x3
 cd $GRAFT_REPO_ROOT
-python tools/trace_summary.py $O/prof_s1 23 > $O/r03_bench_kernel_trace_summary.txt
-python tools/trace_summary.py $O/prof_s2 23 > $O/r03_bench_2streams_kernel_trace_summary.txt
-python tools/trace_summary.py $O/prof_f16 23 > $O/r03_bench_fp16_kernel_trace_summary.txt
-python tools/trace_summary.py $O/prof_x3 7 > $O/r03_fp16x3_kernel_trace_summary.txt
-python tools/trace_summary.py $O/prof_c3 7 > $O/r03_c3_hubert_large_kernel_trace_summary.txt
+python tools/trace_summary.py $O/prof_s1 43 > $O/r03_bench_kernel_trace_summary.txt
+python tools/trace_summary.py $O/prof_s2 43 > $O/r03_bench_2streams_kernel_trace_summary.txt
+python tools/trace_summary.py $O/prof_f16 43 > $O/r03_bench_fp16_kernel_trace_summary.txt
+python tools/trace_summary.py $O/prof_x3 12 > $O/r03_fp16x3_kernel_trace_summary.txt
+python tools/trace_summary.py $O/prof_c3 12 > $O/r03_c3_hubert_large_kernel_trace_summary.txt
 cp $(ls $O/prof_s1/*/*kernel_stats.csv | head -1) $O/r03_bench_kernel_stats.csv
 cp $(ls $O/prof_c3/*/*kernel_stats.csv | head -1) $O/r03_c3_hubert_large_kernel_stats.csv
 cp $(ls $O/prof_f16/*/*kernel_stats.csv | head -1) $O/r03_bench_fp16_kernel_stats.csv
