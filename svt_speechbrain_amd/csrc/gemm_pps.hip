@@ -68,8 +68,13 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W;
   const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
-  unsigned aof[GA], wof[GW];     // byte offsets of the rows this lane fetches: tile whose units are being requested ...
-  unsigned aof2[GA], wof2[GW];   // ... and the tile after it
+  // byte offsets of the rows this lane fetches, one set for the workgroup's even tiles (0, 2, ..) and one for its odd tiles: the
+  // tile being multiplied reads one set, the requests that run ahead into the next tile read the other, and a finished tile's set
+  // is overwritten IN PLACE with the offsets of the tile after next.  (A first form kept "current" and "next" sets and copied
+  // next -> current at every tile end: hipcc turned that rotation into a swap of the two sets through temporaries on EVERY slab,
+  // 32 v_mov between a wave's last MFMA slot and its next LOAD slot -- the slot stamps of tools/gemm_trace.py --slots found ~400
+  // cycles per slab and wave group outside the slots, 3 100 cycles per slab against 2 600 in the one-tile kernel.)
+  unsigned aofE[GA], wofE[GW], aofO[GA], wofO[GW];
   auto setup = [&](int logical, unsigned (&ao)[GA], unsigned (&wo)[GW]) {
     const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -110,15 +115,15 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
   long long t_begin = 0, t_first = 0, t_epi = 0, c_first = 0;
   if (tr) t_begin = wall_clock64();
-  setup(lbase, aof, wof);
-  setup(my_tiles > 1 ? nblk + lbase : lbase, aof2, wof2);   // always rows that exist: the stream's surplus requests (below) read them
+  setup(lbase, aofE, wofE);
+  setup(my_tiles > 1 ? nblk + lbase : lbase, aofO, wofO);   // always rows that exist: the stream's surplus requests (below) read them
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
 #pragma unroll
-  for (int i = 0; i < GA; ++i) dma(aof[i], gA, lds_unit(0, i));
+  for (int i = 0; i < GA; ++i) dma(aofE[i], gA, lds_unit(0, i));
 #pragma unroll
-  for (int i = 0; i < GW; ++i) dma(wof[i], gW, lds_unit(1, i));
+  for (int i = 0; i < GW; ++i) dma(wofE[i], gW, lds_unit(1, i));
 #pragma unroll
-  for (int i = 0; i < GA; ++i) dma(aof[i], gA + BK * 2, lds_unit(2, i));
+  for (int i = 0; i < GA; ++i) dma(aofE[i], gA + BK * 2, lds_unit(2, i));
   wait_vm<GA>();
   __builtin_amdgcn_s_barrier();
   if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
@@ -205,11 +210,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
       for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     ++ti;
+    // the finished tile's offset set now belongs to tile ti + 1 (same parity); with no such tile it keeps rows that exist, which is
+    // all the stream's surplus requests need
+    if (ti + 1 < my_tiles) {
+      unsigned na[GA], nw[GW];
+      setup((ti + 1) * nblk + lbase, na, nw);
+      const bool into_odd = (ti & 1) == 0;
 #pragma unroll
-    for (int i = 0; i < GA; ++i) aof[i] = aof2[i];
+      for (int i = 0; i < GA; ++i) { aofO[i] = into_odd ? na[i] : aofO[i]; aofE[i] = into_odd ? aofE[i] : na[i]; }
 #pragma unroll
-    for (int i = 0; i < GW; ++i) wof[i] = wof2[i];
-    if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, aof2, wof2);   // else: keeps the last tile's rows (surplus requests)
+      for (int i = 0; i < GW; ++i) { wofO[i] = into_odd ? nw[i] : wofO[i]; wofE[i] = into_odd ? wofE[i] : nw[i]; }
+    }
     if (tr) t_epi += wall_clock64() - t_e0;
   };
 
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       {                                                                                                             \
         const char* wb = w_cur ? gW + (long)(kt + 1) * (BK * 2) : gW;                                               \
         _Pragma("unroll") for (int i2 = half_ * 2; i2 < half_ * 2 + 2; ++i2)                                        \
-            dma(w_cur ? wof[i2] : wof2[i2], wb, lds_unit(wslot, i2));                                               \
+            dma(w_even ? wofE[i2] : wofO[i2], wb, lds_unit(wslot, i2));                                             \
       }                                                                                                             \
       if (half_ == 1 && last_k && has_bias) {                                                                       \
         const float* bp = p.bias + (((ti * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);             \
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       {                                                                                                             \
         const char* ab = gA + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 2);                                      \
         _Pragma("unroll") for (int i2 = half_ * ((GA + 1) / 2); i2 < (half_ ? GA : (GA + 1) / 2); ++i2)             \
-            dma(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(aslot, i2));                                               \
+            dma(a_even ? aofE[i2] : aofO[i2], ab, lds_unit(aslot, i2));                                             \
       }                                                                                                             \
     }                                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
@@ -274,10 +285,11 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   const uint4* xa = lds + sa * SLOT + xoff;                                                                         \
   const uint4* wa = lds + sw * SLOT + woff;                                                                         \
   const bool w_cur = kt + 1 < nk, a_cur = kt + 2 < nk, last_k = kt + 1 == nk;                                       \
-  const int wslot = (sa + 3) % NSLOT, aslot = (sa + 4) % NSLOT;
+  const bool t_even = (ti & 1) == 0, w_even = w_cur == t_even, a_even = a_cur == t_even;                            \
+  const int wslot = sa + 3 >= NSLOT ? sa + 3 - NSLOT : sa + 3, aslot = sa + 4 >= NSLOT ? sa + 4 - NSLOT : sa + 4;
 #define PPS_ADVANCE()                                                                                               \
-  sa = (sa + 2) % NSLOT;                                                                                            \
-  sw = (sw + 2) % NSLOT;                                                                                            \
+  sa = sa + 2 >= NSLOT ? sa + 2 - NSLOT : sa + 2;                                                                   \
+  sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;                                                                   \
   if (++kt == nk) kt = 0;
 
   if (grp == 0) {

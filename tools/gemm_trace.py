@@ -79,7 +79,7 @@ def main():
             call(9)
             torch.cuda.synchronize()
             lib.svt_debug_set(3, 0)
-        t = trace.view(-1, 8).cpu()
+        t = trace[:65536].view(-1, 8).cpu()
         t = t[t[:, 5] > 0].double()
         t0 = t[:, 0].min()
         us = 0.01
