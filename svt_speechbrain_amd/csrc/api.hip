@@ -508,6 +508,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 2) g_gemm_ring = value;
   else if (key == 3) g_gemm_variant = value;
   else if (key == 15) g_stamp_ends = value;
+  else if (key == 16) g_pps_half_barriers = value;
   else if (key == 5) g_fuse_outproj_ln = value;
   else if (key == 6) g_gemm_skinny = value;
   else if (key == 7) g_gemm_skinny_max_tiles = value;

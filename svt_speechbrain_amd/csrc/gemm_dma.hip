@@ -1332,6 +1332,7 @@ bool gemm_dma_eligible(const GemmArgs& a) { return a.K % 64 == 0 && a.N >= 128 &
 int g_gemm_dbg = 0;
 int g_gemm_force_bm = 0;
 int g_gemm_variant = 0;
+int g_pps_half_barriers = 1;   // gemm_pps_kernel, four barriers per slab: 0 = never (A/B, slot stamps), 1 = always, 2 = GELU tiles with K <= 1024 only (svt_debug_set key 16)
 int g_stamp_ends = 0;   // gemm_pps_kernel slot stamps (tools/gemm_trace.py --slots): 0 = slot starts, 1 = slot ends
 int g_gemm_ring = 0;  // 0 = auto; 2 = force the one-tile-per-workgroup kernel, 4 = force the persistent kernel (diagnostics)
 int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {

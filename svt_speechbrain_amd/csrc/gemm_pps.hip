@@ -47,7 +47,8 @@ template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
 
 // STAUX: cache policy of the epilogue stores (buffer instruction aux bits: 0 = default write-back, 2 = nt, 16 = sc1 write-through)
 // STAMP (tools/gemm_trace.py --slots): s_memtime at both ends of every slot of one slab of the stream, per wave
-template <int BM, int ACT, int STAUX, int STAMP = 0>
+// HB: four barriers per slab instead of eight (see the loops)
+template <int BM, int ACT, int STAUX, int STAMP = 0, bool HB = false>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   // 32 v_mov between a wave's last MFMA slot and its next LOAD slot -- the slot stamps of tools/gemm_trace.py --slots found ~400
   // cycles per slab and wave group outside the slots, 3 100 cycles per slab against 2 600 in the one-tile kernel.)
   unsigned aofE[GA], wofE[GW], aofO[GA], wofO[GW];
+  const bool plain_a = p.a_rpb >= p.M;
   auto setup = [&](int logical, unsigned (&ao)[GA], unsigned (&wo)[GW]) {
     const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     for (int i = 0; i < GA; ++i) {
       int m = m0 + (wave + 8 * i) * 8 + r8;
       if (m > p.M - 1) m = p.M - 1;
-      ao[i] = (unsigned)(((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8) * 2);
+      if (plain_a) ao[i] = (unsigned)(((long)m * p.a_rstride + ch * 8) * 2);   // one run of rows: no per-lane division
+      else ao[i] = (unsigned)(((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
@@ -96,10 +99,6 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 
   auto dma = [&](unsigned voff, const void* sbase, unsigned lds_addr) { dma_sv(voff, sbase, lds_addr); };
   f32x4 acc[8][MB];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
   const int frag0 = (r16 >> 3) * 64 + rr8 * 8 + (cq ^ rr8);
@@ -117,6 +116,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   if (tr) t_begin = wall_clock64();
   setup(lbase, aofE, wofE);
   setup(my_tiles > 1 ? nblk + lbase : lbase, aofO, wofO);   // always rows that exist: the stream's surplus requests (below) read them
+  // The bias is the INITIAL value of the accumulators (one v_mov per register, what clearing them costs anyway) instead of 128
+  // additions per lane in the epilogue: bq holds the bias of this lane's 8 columns for the NEXT tile to start, fetched here for
+  // the first tile and in the last slab of every tile for the one after it.
+  f32x4 bq[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (has_bias) {
+    const float* bp = p.bias + ((lbase % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");
+  }
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aofE[i], gA, lds_unit(0, i));
@@ -124,14 +134,15 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   for (int i = 0; i < GW; ++i) dma(wofE[i], gW, lds_unit(1, i));
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aofE[i], gA + BK * 2, lds_unit(2, i));
-  wait_vm<GA>();
+  wait_vm<GA>();   // the bias loads are older than every request of the head
   __builtin_amdgcn_s_barrier();
   if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
 
   bf16x8 wfr[4], xfr[MB];
-  f32x4 bq[2];                         // bias of this lane's 8 columns (tile being multiplied), fetched in its last slab
-#pragma unroll
-  for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int sa = 0, sw = 1, kt = 0, ti = 0;
   const int grp = wave >> 2;   // = wn
   // slot stamps of slab gs (dbg 5: middle of the second tile, 6: last slab of the first tile, 7: first slab of the second)
@@ -168,9 +179,6 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     // this lane: rows 4 (lane >> 4) + r of every 16-row block of the wave, columns 8 (lane & 15) .. + 7 of the wave's 128
     const unsigned off0 = (unsigned)((((long)(wm * (BM / 4) + 4 * (lane >> 4))) * p.ldc + n0 + wn * 128 + (lane & 15) * 8) * 2);
     const unsigned row_pitch = (unsigned)(p.ldc * 2);
-    float bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = bq[j >> 2][j & 3];
     if (!no_epi) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
         if constexpr (ACT == ACT_GELU) {
           f32x2_t g[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] = f32x2_t{acc[2 * j][mb][r] + bv[2 * j], acc[2 * j + 1][mb][r] + bv[2 * j + 1]};
+          for (int j = 0; j < 4; ++j) g[j] = f32x2_t{acc[2 * j][mb][r], acc[2 * j + 1][mb][r]};
           gelu_bf16x2_x4(g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j][mb][r] + bv[j]);
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j][mb][r];
         }
         // the row inside the wave's tile goes into the VECTOR offset: (i) the range check of a raw buffer covers voffset only,
         // a row >= M addressed through soffset would be written; (ii) with an SGPR in the soffset field hipcc (ROCm 7.2) assumes
@@ -205,10 +213,11 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
         for (int j = 0; j < MB; ++j) asm volatile("" ::"v"(acc[i][j]));
     }
+    // the next tile starts from its bias (fetched during this tile's last slab)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
     ++ti;
     // the finished tile's offset set now belongs to tile ti + 1 (same parity); with no such tile it keeps rows that exist, which is
     // all the stream's surplus requests need
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
             dma(w_even ? wofE[i2] : wofO[i2], wb, lds_unit(wslot, i2));                                             \
       }                                                                                                             \
       if (half_ == 1 && last_k && has_bias) {                                                                       \
-        const float* bp = p.bias + (((ti * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);             \
+        const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);       \
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"                 \
                      : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");                                            \
       }                                                                                                             \
@@ -292,6 +301,53 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;                                                                   \
   if (++kt == nk) kt = 0;
 
+  if constexpr (HB) {
+    // Four barriers per slab.  An interval between two barriers holds a LOAD slot AND an MFMA slot of every wave, in opposite
+    // order for the two groups: waves 0-3 multiply group q and then read group q + 1, waves 4-7 read group q and then multiply
+    // it, so on a SIMD the halves still alternate, but a LOAD slot that runs longer than its partner's 16 MFMAs (the eight-read
+    // slots do) is paid back inside the interval instead of at a barrier of its own.  Both groups retire the slab in front of
+    // barrier 4 (waves 0-3 behind their last LOAD slot, waves 4-7 behind MFMA group 2 with half of the A requests of the slab
+    // still to be issued): behind that barrier waves 0-3 read the next slab.
+    constexpr int GA_HALF = (GA + 1) / 2;
+    if (grp == 0) {
+      bool pending = false;
+      {
+        PPS_SLAB_VARS()
+        PPS_LOAD(0)
+      }
+      for (int g = 0; g < G; ++g) {
+        PPS_SLAB_VARS()
+        __builtin_amdgcn_s_barrier();
+        PPS_MMA(0) PPS_LOAD(1) __builtin_amdgcn_s_barrier();
+        PPS_MMA(1) PPS_LOAD(2) __builtin_amdgcn_s_barrier();
+        PPS_MMA(2) PPS_LOAD(3)
+        PPS_RETIRE()
+        __builtin_amdgcn_s_barrier();
+        PPS_MMA(3)
+        pending = last_k;
+        PPS_ADVANCE()
+        if (pending) epilogue();
+        if (g + 1 < G) {
+          PPS_SLAB_VARS()
+          PPS_LOAD(0)
+        }
+      }
+    } else {
+      for (int g = 0; g < G; ++g) {
+        PPS_SLAB_VARS()
+        __builtin_amdgcn_s_barrier();
+        PPS_LOAD(0) PPS_MMA(0) __builtin_amdgcn_s_barrier();
+        PPS_LOAD(1) PPS_MMA(1) __builtin_amdgcn_s_barrier();
+        PPS_LOAD(2) PPS_MMA(2)
+        wait_vm<GA_HALF>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        PPS_LOAD(3) PPS_MMA(3)
+        if (last_k) epilogue();
+        PPS_ADVANCE()
+      }
+    }
+  } else
   if (grp == 0) {
     bool pending = false;   // the previous slab closed a tile: its epilogue runs in front of this slab's first LOAD slot
     for (int g = 0;; ++g) {
@@ -356,17 +412,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #undef PPS_ADVANCE
 }
 
-template <int BM, int ACT, int STAUX = 0, int STAMP = 0>
+template <int BM, int ACT, int STAUX = 0, int STAMP = 0, bool HB = false>
 int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -394,6 +450,20 @@ static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
     if (a.trace && bm == 256 && a.dbg >= 5 && a.dbg <= 7) {
       if (a.stamp_ends) return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 2>(a, s) : launch_pps_t<256, ACT_NONE, 16, 2>(a, s);
       return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 1>(a, s) : launch_pps_t<256, ACT_NONE, 16, 1>(a, s);
+    }
+  }
+  if constexpr (STAUX == 16) {
+    // four barriers per slab: FFN-1 78.9 -> 73.6 us, large FFN-1 285 -> 282, conv1 762 -> 778, the plain tiles equal; end to end
+    // C2 5 881 / 5 903 / 5 943 clips/s for never / GELU-short-K only / always, C3 2 432 / 2 445 / 2 443
+    if (g_pps_half_barriers == 1 || (g_pps_half_barriers == 2 && a.act == ACT_GELU && a.K <= 1024)) {
+      if (a.act == ACT_GELU) {
+        if (bm == 256) return launch_pps_t<256, ACT_GELU, 16, 0, true>(a, s);
+        if (bm == 192) return launch_pps_t<192, ACT_GELU, 16, 0, true>(a, s);
+        return launch_pps_t<128, ACT_GELU, 16, 0, true>(a, s);
+      }
+      if (bm == 256) return launch_pps_t<256, ACT_NONE, 16, 0, true>(a, s);
+      if (bm == 192) return launch_pps_t<192, ACT_NONE, 16, 0, true>(a, s);
+      return launch_pps_t<128, ACT_NONE, 16, 0, true>(a, s);
     }
   }
   if (a.act == ACT_GELU) {
