@@ -1367,11 +1367,13 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     return launch_pp8<128, true>(a, s);
   }
   const long ntiles = (long)((a.M + best - 1) / best) * tiles_n;
-  // Persistent staggered kernel (gemm_pps.hip): bf16 outputs without residual.  It wins wherever a workgroup gets more than one tile
-  // (prologue, epilogue stores and the next tile's fills overlap) and on short-K single-round launches (its register epilogue costs
-  // 1.3 us against 4 us for the LDS-transposed one); long-K single-round launches (FFN-2, K = 3072 / 4096) stay on gemm_pp8_kernel, whose
-  // main loop is ~10 % faster per slab.  Measured per shape: profiles/r03_gemm_yardstick.txt.  Write-through (sc1) stores: the
-  // output leaves L2 while the kernel runs instead of at the kernel boundary (FFN-1: 98 MB, 16 us).
+  // Persistent staggered kernel (gemm_pps.hip): bf16 outputs without residual, from 100 tiles up.  With several tiles per workgroup
+  // the prologue, the epilogue stores and the next tile's fills overlap; on single-round launches its register epilogue costs
+  // 1.3 us against 4 us for the LDS-transposed one of gemm_pp8_kernel, and since its slab loop lost the per-slab register swaps
+  // (gemm_pps.hip) it is as fast per slab: FFN-2 (252 tiles, K = 3072) 68.3 -> 61.1 us, the 138-tile FFN-2 of a 35-utterance song
+  // 52.7 -> 48.0, 4096^3 115 -> 109; large FFN-2 (500 tiles, K = 4096) equal.  Measured per shape:
+  // profiles/r03_gemm_vendor_library_yardstick.txt.  Write-through (sc1) stores: the output leaves L2 while the kernel runs instead
+  // of at the kernel boundary (FFN-1: 98 MB, 16 us).
   // svt_debug_set key 3: 50 / 60 / 70 force it with default / nt / sc1 stores (53: without epilogue), 49 switches it off.
   if (g_gemm_variant >= 50 && g_gemm_variant < 80 && gemm_pps_eligible(a)) {
     GemmArgs b = a;
@@ -1379,7 +1381,7 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     b.stamp_ends = g_stamp_ends;
     return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, (g_gemm_variant - 50) / 10);
   }
-  if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 200 && (ntiles > 256 || a.K < 2048) && gemm_pps_eligible(a))
+  if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 100 && gemm_pps_eligible(a))
     return launch_gemm_pps(a, best, s, 2);
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
                        a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
