@@ -518,8 +518,8 @@ def main():
                                     "pieces in the kernel, pre-cut weight pieces, three MFMAs per 16x16x32 block; staggered 8-slot schedule, "
                                     "persistent for the GELU launches)") if split else
                                    ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline, staggered "
-                                    "8-slot schedule: persistent stream of tiles per CU, one tile per workgroup for long-K single-round launches, or "
-                                    "row-complete with fused LayerNorm)"),
+                                    "schedule: persistent stream of tiles per CU; one tile per workgroup for the batched positional conv; "
+                                    "row-complete with fused LayerNorm for the post-LN out-projection)"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"GB of HBM traffic per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
