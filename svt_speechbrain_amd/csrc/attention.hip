@@ -537,14 +537,9 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   return 0;
 }
 
-int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones, 2 = also the whole-head kernel
-// whole-head kernel (K / V of a head resident in LDS, head_dim 64, 256 < T <= 512): OFF by default.  Measured on MI355X
-// (tools/attn_bench.py, round 2): 32 x 12 heads x 499 frames 60.4 us against 46.1 us for the 256-query workgroups above,
-// 64 x 16 heads 132.5 against ~114 us.  It does read K / V once per head, but (i) 128 KiB of LDS means one workgroup =
-// two waves per SIMD per CU, against four with the 32 KiB tiles, and the dual query blocks of a wave do not make up for
-// the lost wave-level overlap of MFMA and softmax VALU work; (ii) hipcc puts an s_waitcnt vmcnt(0) in front of the first
-// LDS read of every tile while an LDS-DMA it knows about is outstanding, so the tile-ordered fill is in fact waited for
-// in full before tile 0; (iii) 384 heads on 256 CUs are 1.5 rounds either way.  Kept for svt_debug_set(10, 1) A/B runs.
+int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones.  (Round 3: four-wave workgroups held to
+                       // three per CU by 16 KiB of unused LDS -- 1 536 workgroups = exactly two rounds instead of 1.5 -- measured 51.1 against 48.5 us
+                       // at C2, 138.6 against 130.9 at C3: the kernel is bound by issue throughput, not by the half-empty second round.)
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,

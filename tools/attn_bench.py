@@ -17,8 +17,11 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--wide", type=int, default=None, help="svt_debug_set key 8 (workgroup shape / occupancy experiments of the fused attention)")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.wide is not None:
+        lib.svt_debug_set(8, a.wide)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     for name, B, T, H, dh in SHAPES:
