@@ -1073,16 +1073,23 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
     if (DBG == 1) {                                                                                                 \
     } else if ((Q) < 2) {   /* A_{g+2} -> the slot W_{g-1} left */                                                  \
       _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
-          dma16_asm(asrc[i2] + (long)kc(g + 2) * BK, unit_addr((sw + 3) % NSLOT, i2));                              \
+          dma16_asm(asrc[i2] + (long)kc(g + 2) * BK, unit_addr(s3, i2));                              \
     } else {         /* W_{g+2} -> the slot of A_g */                                                               \
       _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) == 2 ? 2 : GW); ++i2)                                \
-          dma16_asm(wsrc[i2] + (long)kc(g + 2) * 64, unit_addr((sw + 4) % NSLOT, i2));                              \
+          dma16_asm(wsrc[i2] + (long)kc(g + 2) * 64, unit_addr(s4, i2));                              \
     }                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    /* The cuts run BEHIND the slot's LDS reads and ring requests, under the LDS latency: while the partner wave issues its MFMAs \
+       this wave's vector instructions get every other issue slot, so the 18 instructions of a cut take ~300 cycles (slot stamps \
+       of gemm_x3p_kernel, tools/gemm_trace.py --x3-slots).  The cut pieces are "used" HERE: their only real use is the copy at the \
+       end of the slab, and LLVM sinks a computation to its use -- both cuts ended up in the loop latch, behind the slab's last    \
+       barrier, in front of the next LOAD slot 0 */                                                                      \
+    if ((Q) == 1) { cut(raw[0][0], raw[0][1], nh[0], nl[0]); asm volatile("" : "+v"(nh[0]), "+v"(nl[0])); }         \
+    if ((Q) == 2) { cut(raw[1][0], raw[1][1], nh[1], nl[1]); asm volatile("" : "+v"(nh[1]), "+v"(nl[1])); }         \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
     if ((Q) == 0) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]));            \
     _Pragma("unroll") for (int i = 0; i < NBS; ++i) asm volatile("" : "+v"(wh[i]), "+v"(wl[i]));                    \
-    if ((Q) == 1) cut(raw[0][0], raw[0][1], nh[0], nl[0]);                                                          \
-    if ((Q) == 2) cut(raw[1][0], raw[1][1], nh[1], nl[1]);                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 #define X3S_MMA(Q)                                                                                                  \
@@ -1098,10 +1105,12 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   }
 #define X3S_VARS()                                                                                                  \
   const x3_u32x4* wa = ldsv + sw * SLOT;                                                                            \
-  const x3_u32x4* xn = ldsv + ((sw + 1) % NSLOT) * SLOT + (wave * 2) * 128;
+  const int s1 = sw + 1 >= NSLOT ? sw + 1 - NSLOT : sw + 1, s3 = sw + 3 >= NSLOT ? sw + 3 - NSLOT : sw + 3,         \
+            s4 = sw + 4 >= NSLOT ? sw + 4 - NSLOT : sw + 4;                                                         \
+  const x3_u32x4* xn = ldsv + s1 * SLOT + (wave * 2) * 128;
 #define X3S_END()                                                                                                   \
   _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { xh[mb] = nh[mb]; xl[mb] = nl[mb]; }                            \
-  sw = (sw + 2) % NSLOT;
+  sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;
   if (grp == 0) {
     for (int g = 0; g < nk; ++g) {
       X3S_VARS()
@@ -1267,6 +1276,11 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   GemmArgs g = a;
   g.out_f32 = 1;
   g.planes_f16 = kind == 3;
+  if (g_gemm_dbg == 9 && a.resid) {   // diagnostics (tools/gemm_trace.py --x3-slots): the trace buffer travels in `resid`
+    g.trace = (long long*)a.resid;
+    g.resid = nullptr;
+    g.stamp_ends = g_stamp_ends;
+  }
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
   // tile width: 192 columns when that fills the chip better (N = 768: 252 tiles against 189); g_gemm_variant 30 = the lockstep kernel (A/B)
@@ -1282,7 +1296,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   // several tiles per CU (conv 1-4, FFN-1: GELU over fp32 outputs), the one-tile kernel on the plain projections (QKV, out-proj, FFN-2).
   const bool x3p_ok = gemm_x3p_eligible(g) && g_gemm_variant != 30 && g_gemm_variant != 31 && g_gemm_variant != 32 && g_gemm_variant != 33;
   if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256))) {
-    g.dbg = g_gemm_dbg;
+    g.dbg = g_gemm_dbg == 9 ? 0 : g_gemm_dbg;
     if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
   } else if ((g_gemm_variant == 31 || g_gemm_variant == 33) && kind == 3) {
     if (g_gemm_variant == 31) {

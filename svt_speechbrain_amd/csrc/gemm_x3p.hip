@@ -74,7 +74,8 @@ template <bool F16> __device__ __forceinline__ void cut1(float x, unsigned short
 
 // (the activation is a run-time flag, not a template parameter: the instantiation WITHOUT GELU was the one hipcc could not keep
 // inside 256 registers -- seven spilled dwords whose reloads put s_waitcnt vmcnt(0) between the MFMAs of every slab)
-template <bool F16, bool PLANES>
+// STAMP 1..4 (tools/gemm_trace.py --x3-slots): s_memtime at both ends of slots 2 (STAMP - 1), 2 (STAMP - 1) + 1 of one slab, per wave
+template <bool F16, bool PLANES, int STAMP = 0>
 __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* wsplit, int tiles_n, int ntiles) {
   constexpr int BM = 256, BN = 256, BK = 32, NSLOT = 5, SLOT = 2048, GA = 4, GW = 4, NB = 16;
   constexpr int NST = PLANES ? 64 : 32;   // stores per wave and tile
@@ -161,6 +162,22 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
   __builtin_amdgcn_s_barrier();   // every wave holds its pieces of A_0 before slab 0's W_2 request reuses that slot
   int sw = 1, kt = 0, ti = 0;     // slot of W_g (A_{g+1} sits in the next one)
   const int grp = wave >> 2;
+  // slot stamps of slab gs (the middle of the second tile): stamp k = 2 * slot (start) / 2 * slot + 1 (arrival at the barrier)
+  unsigned sraw[5], st[5];
+  const int gs = my_tiles > 1 ? nk + nk / 2 : nk / 2;
+  if constexpr (STAMP != 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0;
+  }
+#define X3P_S(k)                                                                                                    \
+  if constexpr (STAMP != 0 && (k) >= 4 * (STAMP - 1) && (k) <= 4 * (STAMP - 1) + 4 && (k) < 16)                     \
+    sraw[((k) - 4 * (STAMP - 1)) % 5] = (unsigned)__builtin_amdgcn_s_memtime();                                      \
+  if constexpr (STAMP == 4 && (k) == 0) sraw[4] = (unsigned)__builtin_amdgcn_s_memtime();
+#define X3P_COMMIT()                                                                                                \
+  if constexpr (STAMP != 0) {                                                                                       \
+    if (g == gs) { _Pragma("unroll") for (int i = 0; i < (STAMP == 4 ? 4 : 5); ++i) st[i] = sraw[i]; }               \
+    if (STAMP == 4 && g == gs + 1) st[4] = sraw[4];                                                                  \
+  }
 
   auto epilogue = [&]() {
     const int logical = ti * nblk + lbase;
@@ -240,31 +257,38 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
     if (ti + 1 < my_tiles) setup((ti + 1) * nblk + lbase, abase2, aof2, wof2);   // else: keeps the last tile's rows (surplus requests)
   };
 
-  // LOAD slot Q of slab g: W pieces of blocks 4 Q .. 4 Q + 3 of W_g; slot 0 also reads this wave's fp32 rows of A_{g+1}, slots 1 and 2
-  // cut them (one 16-row block each); requests: A_{g+2} in slots 0 - 1, W_{g+2} in slots 2 - 3 (two instructions each)
+  // LOAD slot Q of slab g: W pieces of blocks 4 Q .. 4 Q + 3 of W_g; slots 0 / 2 also read this wave's fp32 rows of A_{g+1} (one 16-row
+  // block each), slots 1 / 3 cut them; requests: A_{g+2} in slots 0 - 1, W_{g+2} in slots 2 - 3 (two instructions each)
 #define X3P_LOAD(Q)                                                                                                 \
   {                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
       wh[i] = wa[((Q) * 4 + i) * 128 + fwh];                                                                        \
       wl[i] = wa[((Q) * 4 + i) * 128 + fwl];                                                                        \
     }                                                                                                               \
-    /* the fp32 rows of block 0 / 1 of A_{g+1} are read in slots 0 / 1 and cut one slot later, under this slot's LDS latency; one   \
-       8-register staging set: the cut consumes it before the next read is issued */                                  \
-    if ((Q) == 1) cut8<F16>(raw[0], raw[1], nh[0], nl[0]);                                                          \
-    if ((Q) == 2) cut8<F16>(raw[0], raw[1], nh[1], nl[1]);                                                          \
-    if ((Q) < 2) { raw[0] = xn[(Q) * 128 + fa0]; raw[1] = xn[(Q) * 128 + fa1]; }                                    \
+    /* the fp32 rows of block 0 / 1 of A_{g+1} are read in slots 0 / 2 and cut in slots 1 / 3 (one 8-register staging set).  Inside \
+       a slot EVERY LDS read and both ring requests are issued first and the cut runs behind them, under the LDS latency: while   \
+       the partner wave issues its 24 MFMAs this wave's vector instructions get every other issue slot, so the 18 instructions   \
+       of a cut take ~300 cycles -- in front of the reads (where hipcc's scheduler had put them) they made the slot 640 cycles   \
+       long against the partner's 384 (tools/gemm_trace.py --x3-slots) */                                                    \
+    if ((Q) == 0 || (Q) == 2) { raw[0] = xn[((Q) >> 1) * 128 + fa0]; raw[1] = xn[((Q) >> 1) * 128 + fa1]; }         \
     if ((Q) < 2) {                                                                                                  \
       const char* ab = (a_cur ? abase : abase2) + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 4);                  \
       _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
-          dma_sv(a_cur ? aof[i2] : aof2[i2], ab, lds_unit((sw + 3) % NSLOT, i2));                                   \
+          dma_sv(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(s3, i2));                                   \
     } else {                                                                                                        \
       const char* wb = gW + (long)(a_cur ? kt + 2 : kt + 2 - nk) * 128;                                             \
       _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) - 2) * 2 + 2; ++i2)                                  \
-          dma_sv(a_cur ? wof[i2] : wof2[i2], wb, lds_unit((sw + 4) % NSLOT, i2));                                   \
+          dma_sv(a_cur ? wof[i2] : wof2[i2], wb, lds_unit(s4, i2));                                   \
     }                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    /* (the pieces are "used" here by an empty asm: LLVM otherwise sinks both cuts to their only real use, the copy in the loop  \
+       latch -- behind the slab's last barrier, on the critical path of every slab: gemm_x3s_kernel, gemm_dma.hip) */     \
+    if ((Q) == 1) { cut8<F16>(raw[0], raw[1], nh[0], nl[0]); asm volatile("" : "+v"(nh[0]), "+v"(nl[0])); }         \
+    if ((Q) == 3) { cut8<F16>(raw[0], raw[1], nh[1], nl[1]); asm volatile("" : "+v"(nh[1]), "+v"(nl[1])); }         \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
     asm volatile("" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(wl[0]), "+v"(wl[1]), "+v"(wl[2]), "+v"(wl[3])); \
-    if ((Q) < 2) asm volatile("" : "+v"(raw[0]), "+v"(raw[1]));                                                     \
+    if ((Q) == 0 || (Q) == 2) asm volatile("" : "+v"(raw[0]), "+v"(raw[1]));                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 #define X3P_MMA(Q)                                                                                                  \
@@ -280,7 +304,9 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
   }
 #define X3P_VARS()                                                                                                  \
   const u32x4v* wa = ldsv + sw * SLOT;                                                                              \
-  const u32x4v* xn = ldsv + ((sw + 1) % NSLOT) * SLOT + xoff;                                                       \
+  const int s1 = sw + 1 >= NSLOT ? sw + 1 - NSLOT : sw + 1, s3 = sw + 3 >= NSLOT ? sw + 3 - NSLOT : sw + 3,         \
+            s4 = sw + 4 >= NSLOT ? sw + 4 - NSLOT : sw + 4;   /* (% NSLOT costs an s_mul_hi sequence per use, per slab) */ \
+  const u32x4v* xn = ldsv + s1 * SLOT + xoff;                                                                       \
   const bool a_cur = kt + 2 < nk, last_k = kt + 1 == nk;
   // everything but W_{g+2} (the four youngest requests) has landed: W_{g+1}, A_{g+2}, and the previous tile's stores
 #define X3P_RETIRE()                                                                                                \
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
   }
 #define X3P_ADVANCE()                                                                                               \
   _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { xh[mb] = nh[mb]; xl[mb] = nl[mb]; }                            \
-  sw = (sw + 2) % NSLOT;                                                                                            \
+  sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;                                                                   \
   if (++kt == nk) kt = 0;
 
   if (grp == 0) {
@@ -299,12 +325,14 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
       if (pending) epilogue();
       if (g == G) break;
       X3P_VARS()
-      X3P_LOAD(0) __builtin_amdgcn_s_barrier(); X3P_MMA(0) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(1) __builtin_amdgcn_s_barrier(); X3P_MMA(1) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(2) __builtin_amdgcn_s_barrier(); X3P_MMA(2) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(3) __builtin_amdgcn_s_barrier(); X3P_MMA(3)
+      X3P_S(0) X3P_LOAD(0) X3P_S(1) __builtin_amdgcn_s_barrier(); X3P_S(2) X3P_MMA(0) X3P_S(3) __builtin_amdgcn_s_barrier();
+      X3P_S(4) X3P_LOAD(1) X3P_S(5) __builtin_amdgcn_s_barrier(); X3P_S(6) X3P_MMA(1) X3P_S(7) __builtin_amdgcn_s_barrier();
+      X3P_S(8) X3P_LOAD(2) X3P_S(9) __builtin_amdgcn_s_barrier(); X3P_S(10) X3P_MMA(2) X3P_S(11) __builtin_amdgcn_s_barrier();
+      X3P_S(12) X3P_LOAD(3) X3P_S(13) __builtin_amdgcn_s_barrier(); X3P_S(14) X3P_MMA(3)
       X3P_RETIRE()
+      X3P_S(15)
       __builtin_amdgcn_s_barrier();
+      X3P_COMMIT()
       pending = last_k;
       X3P_ADVANCE()
     }
@@ -312,21 +340,34 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
     __builtin_amdgcn_s_barrier();  // one slot behind
     for (int g = 0; g < G; ++g) {
       X3P_VARS()
-      X3P_LOAD(0) __builtin_amdgcn_s_barrier(); X3P_MMA(0) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(1) __builtin_amdgcn_s_barrier(); X3P_MMA(1) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(2) __builtin_amdgcn_s_barrier(); X3P_MMA(2) __builtin_amdgcn_s_barrier();
-      X3P_LOAD(3)
+      X3P_S(0) X3P_LOAD(0) X3P_S(1) __builtin_amdgcn_s_barrier(); X3P_S(2) X3P_MMA(0) X3P_S(3) __builtin_amdgcn_s_barrier();
+      X3P_S(4) X3P_LOAD(1) X3P_S(5) __builtin_amdgcn_s_barrier(); X3P_S(6) X3P_MMA(1) X3P_S(7) __builtin_amdgcn_s_barrier();
+      X3P_S(8) X3P_LOAD(2) X3P_S(9) __builtin_amdgcn_s_barrier(); X3P_S(10) X3P_MMA(2) X3P_S(11) __builtin_amdgcn_s_barrier();
+      X3P_S(12) X3P_LOAD(3)
       X3P_RETIRE()
+      X3P_S(13)
       __builtin_amdgcn_s_barrier();
-      X3P_MMA(3)
+      X3P_S(14) X3P_MMA(3)
       if (last_k) epilogue();
+      X3P_S(15)
       if (g + 1 < G) __builtin_amdgcn_s_barrier();
+      X3P_COMMIT()
       X3P_ADVANCE()
     }
   }
   // the surplus requests of the stream's tail must have landed before the workgroup gives its LDS back; they are older than the last
   // epilogue's stores
   if constexpr (NST <= 32) wait_vm<NST>(); else wait_vm<0>();
+  if constexpr (STAMP != 0) {
+    if (p.trace && lane == 0) {
+      long long* o = p.trace + 65536 + ((long)blockIdx.x * 8 + wave) * 32;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = st[i];
+      o[9] = G; o[10] = gs; o[11] = STAMP;
+    }
+  }
+#undef X3P_S
+#undef X3P_COMMIT
 #undef X3P_LOAD
 #undef X3P_MMA
 #undef X3P_VARS
@@ -334,14 +375,14 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
 #undef X3P_ADVANCE
 }
 
-template <bool F16, bool PLANES>
+template <bool F16, bool PLANES, int STAMP = 0>
 int launch_x3p_t(const GemmArgs& a, const void* packed, hipStream_t s) {
   const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_x3p_kernel<F16, PLANES>, (int)lds_bytes)) return r_;
-  hipLaunchKernelGGL((gemm_x3p_kernel<F16, PLANES>), dim3(nblk), dim3(512), lds_bytes, s, a, packed, tiles_n, ntiles);
+  if (int r_ = ensure_dyn_lds((const void*)gemm_x3p_kernel<F16, PLANES, STAMP>, (int)lds_bytes)) return r_;
+  hipLaunchKernelGGL((gemm_x3p_kernel<F16, PLANES, STAMP>), dim3(nblk), dim3(512), lds_bytes, s, a, packed, tiles_n, ntiles);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -362,6 +403,15 @@ bool gemm_x3p_eligible(const GemmArgs& a) {
 // kind = svt_precision (2 = bf16 pieces, 3 = fp16 pieces); `packed` = the registered (hi, lo) image of the weight rows (launch_gemm_x3)
 int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t s) {
   const bool f16 = kind == 3;
+  if (a.trace && f16 && !a.planes) {   // slot stamps (diagnostics)
+    switch (a.stamp_ends) {
+      case 1: return launch_x3p_t<true, false, 1>(a, packed, s);
+      case 2: return launch_x3p_t<true, false, 2>(a, packed, s);
+      case 3: return launch_x3p_t<true, false, 3>(a, packed, s);
+      case 4: return launch_x3p_t<true, false, 4>(a, packed, s);
+      default: break;
+    }
+  }
   if (a.planes) return f16 ? launch_x3p_t<true, true>(a, packed, s) : launch_x3p_t<false, true>(a, packed, s);
   return f16 ? launch_x3p_t<true, false>(a, packed, s) : launch_x3p_t<false, false>(a, packed, s);
 }

@@ -13,6 +13,83 @@ from svt_speechbrain_amd import _lib  # noqa: E402
 from gemm_bench import SHAPES  # noqa: E402
 
 
+def x3_slots(a):
+    lib = _lib.load()
+    lib.svt_debug_set(12, 1)   # keep the registered split weights between calls
+    lib.svt_debug_set(3, 34)   # always the persistent form
+    dev = torch.device("cuda:0")
+    for name, M, N, K, conv, act, out_f32, resid in SHAPES:
+        if a.only != name:
+            continue
+        g = torch.Generator().manual_seed(1)
+        if conv:
+            T_in, T_out, st, cin = conv
+            B = M // T_out
+            A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(dev)
+            rpb, bstr, rstr = T_out, T_in * cin, st * cin
+        else:
+            A = (torch.rand(M, K, generator=g) * 2 - 1).to(dev)
+            rpb, bstr, rstr = M, 0, K
+        W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        C = torch.empty(M, N, device=dev, dtype=torch.float32)
+        trace = torch.zeros(65536 * 16, dtype=torch.int64, device=dev)
+        st_ = torch.cuda.current_stream().cuda_stream
+
+        def call(dbg):
+            lib.svt_debug_set(0, dbg)
+            _lib.check(lib.svt_debug_gemm(3, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(),
+                                          trace.data_ptr() if dbg == 9 else None, M, N, K, rpb, bstr, rstr, W.shape[1], act,
+                                          1, 0, st_), "svt_debug_gemm")
+        import time
+        for _ in range(3):
+            call(0)
+        torch.cuda.synchronize()
+        t_end = time.time() + max(a.load_seconds, 0.5)
+        while time.time() < t_end:
+            for _ in range(20):
+                call(0)
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call(0)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{name}: fp16x3 persistent kernel {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+        recs = []
+        for mode in (1, 2, 3, 4):
+            lib.svt_debug_set(15, mode)
+            trace.zero_()
+            for _ in range(5):
+                call(0)
+            call(9)
+            torch.cuda.synchronize()
+            r = trace[65536:65536 + 256 * 8 * 32].view(256, 8, 32).cpu()
+            recs.append(r[r[:, 0, 9] > 0])
+        lib.svt_debug_set(15, 0)
+        lib.svt_debug_set(0, 0)
+
+        def d(x, y):
+            return ((y - x) & 0xFFFFFFFF).double()
+        names0 = ["LOAD0", "MMA0", "LOAD1", "MMA1", "LOAD2", "MMA2", "LOAD3", "MMA3+retire"]
+        names1 = ["LOAD0", "MMA0", "LOAD1", "MMA1", "LOAD2", "MMA2", "LOAD3+retire", "MMA3(+epi)"]
+        print(f"  slab {int(recs[0][0,0,10])} of {int(recs[0][0,0,9])}: core cycles per slot (work = start .. arrival at the barrier, wait = arrival .. "
+              f"release), median over {recs[0].shape[0]} workgroups x 4 waves; 24 MFMAs = 384 cycles per MMA slot")
+        for grp, names in ((0, names0), (1, names1)):
+            w = slice(4 * grp, 4 * grp + 4)
+            tot = 0.0
+            print(f"   waves {4*grp}-{4*grp+3}:")
+            for k in range(8):
+                src = recs[k // 2]
+                b = 2 * (k & 1)
+                work = d(src[:, w, b], src[:, w, b + 1]).median().item()
+                wait = d(src[:, w, b + 1], src[:, w, b + 2]).median().item()
+                tot += work + wait
+                print(f"     {names[k]:14s} work {work:6.0f}   wait {wait:6.0f}")
+            print(f"     slab total {tot:.0f} cycles (3072 = the MFMA pipe's share)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="qkv")
@@ -27,7 +104,11 @@ def main():
                     "51 / 53 / 54 = without LDS-DMA / epilogue / both)")
     ap.add_argument("--slots", type=int, default=0, help="gemm_pps_kernel slot stamps of one slab: 5 = middle of the second tile, 6 = last slab of "
                     "the first tile, 7 = first slab of the second tile (uses --force-variant 70 + this digit)")
+    ap.add_argument("--x3-slots", action="store_true", help="slot stamps of gemm_x3p_kernel (fp16x3, the persistent split-operand kernel): four "
+                    "launches, two slots each")
     a = ap.parse_args()
+    if a.x3_slots:
+        return x3_slots(a)
     if a.slots:
         a.force_variant = 70 + a.slots
     lib = _lib.load()
