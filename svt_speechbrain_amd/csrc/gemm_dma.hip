@@ -1295,7 +1295,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   // Measured per shape (profiles/r03_gemm_x3_variants.txt): the persistent form is ahead on the launches with a heavy epilogue and
   // several tiles per CU (conv 1-4, FFN-1: GELU over fp32 outputs), the one-tile kernel on the plain projections (QKV, out-proj, FFN-2).
   const bool x3p_ok = gemm_x3p_eligible(g) && g_gemm_variant != 30 && g_gemm_variant != 31 && g_gemm_variant != 32 && g_gemm_variant != 33;
-  if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256))) {
+  if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256) || t256 >= 1024)) {   // (large QKV, 1 500 tiles: 547 against 583 us)
     g.dbg = g_gemm_dbg == 9 ? 0 : g_gemm_dbg;
     if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
   } else if ((g_gemm_variant == 31 || g_gemm_variant == 33) && kind == 3) {

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
   const char* abase2;
   unsigned aof[GA], wof[GW], aof2[GA], wof2[GW];
   auto setup = [&](int logical, const char*& ab, unsigned (&ao)[GA], unsigned (&wo)[GW]) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));   // see the epilogue: keeps these addresses out of the loop-invariant set
+    int ln;   // the lane index, recomputed in place (volatile asm: not merged with an earlier copy that would then live across the slabs)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));   // see the epilogue: keeps these addresses out of the loop-invariant set
     const int r8 = ln >> 3, ch = (ln & 7) ^ r8;
     const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -190,20 +190,22 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
     // this lane: rows 4 (lane >> 4) + r of the wave's two 16-row blocks, columns 64 s + 4 (lane & 15) .. + 3 of every 64-column group s
     // (the lane index is laundered through an empty asm: hipcc otherwise hoists every lane-derived address of the epilogue and of
     // setup() out of the slab loop as loop invariants -- ~25 VGPRs that live across the MFMA slots -- and spills in exchange)
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
+    int ln;   // the lane index, recomputed in place (volatile asm: not merged with an earlier copy that would then live across the slabs)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     const unsigned off0 = (unsigned)((((long)(wave * 32 + 4 * (ln >> 4))) * p.ldc + n0 + (ln & 15) * 4) * esz);
     const unsigned row_pitch = (unsigned)(p.ldc * esz);
     // bias of this lane's 16 columns (4 per 64-column group), fetched HERE: sixteen registers that live across the whole tile were the
     // difference between 256 registers and spills in the slab loop.  The wait for these loads also covers the eight ring requests of
     // the tile's last slab (VMEM operations retire in order): they would have had the epilogue's ~1 us to land anyway.
+    const f32x4* bp = (const f32x4*)(p.bias + n0 + (ln & 15) * 4);
     f32x4 bq[4];
+    if constexpr (PLANES) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (has_bias) {
-      const f32x4* bp = (const f32x4*)(p.bias + n0 + (ln & 15) * 4);
+      for (int j = 0; j < 4; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_bias) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = bp[j * 16];
+        for (int j = 0; j < 4; ++j) bq[j] = bp[j * 16];
+      }
     }
     if constexpr (PLANES) {
       char* hbase = (char*)p.planes + (long)m0 * p.ldc * 2;
@@ -227,22 +229,28 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
     } else {
       char* cbase = (char*)p.C + (long)m0 * p.ldc * 4;
       const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);
+      // one 64-column group at a time: its four bias values are the only ones live (all sixteen at once cost the four registers
+      // that made the four-barrier loop spill -- and a spill's reload makes hipcc guard the loop's ring requests with vmcnt waits)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int s4 = 0; s4 < 4; ++s4) {
+        f32x4 bs = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_bias) bs = bp[s4 * 16];
+        asm volatile("" : "+v"(bs));   // fetched here, not hoisted in front of the first group
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
+          for (int r = 0; r < 4; ++r) {
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float x = acc[s4 * 4 + c][mb][r] + bq[s4][c];
+              const float x = acc[s4 * 4 + c][mb][r] + bs[c];
               v[c] = do_gelu ? gelu_fast(x) : x;
             }
             if (no_store) { asm volatile("" ::"v"(v)); continue; }
             // row and column group in the VECTOR offset (range check; soffset store-data hazard: gemm_pps.hip)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), crsrc, off0 + (mb * 16 + r) * row_pitch + s4 * 256, 0, 16);
           }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -259,7 +267,21 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
 
   // LOAD slot Q of slab g: W pieces of blocks 4 Q .. 4 Q + 3 of W_g; slots 0 / 2 also read this wave's fp32 rows of A_{g+1} (one 16-row
   // block each), slots 1 / 3 cut them; requests: A_{g+2} in slots 0 - 1, W_{g+2} in slots 2 - 3 (two instructions each)
-#define X3P_LOAD(Q)                                                                                                 \
+  // the ring requests of slot Q: A_{g+2} in slots 0 - 1 (into the slot W_{g-1} left), W_{g+2} in slots 2 - 3 (into the slot of A_g)
+#define X3P_DMA(Q)                                                                                                  \
+  {                                                                                                                 \
+    if ((Q) < 2) {                                                                                                  \
+      const char* ab = (a_cur ? abase : abase2) + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 4);                  \
+      _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
+          dma_sv(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(s3, i2));                                                 \
+    } else {                                                                                                        \
+      const char* wb = gW + (long)(a_cur ? kt + 2 : kt + 2 - nk) * 128;                                             \
+      _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) - 2) * 2 + 2; ++i2)                                  \
+          dma_sv(a_cur ? wof[i2] : wof2[i2], wb, lds_unit(s4, i2));                                                 \
+    }                                                                                                               \
+  }
+#define X3P_LOAD(Q) X3P_LOAD_(Q, true)
+#define X3P_LOAD_(Q, WITH_DMA)                                                                                     \
   {                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
       wh[i] = wa[((Q) * 4 + i) * 128 + fwh];                                                                        \
@@ -271,15 +293,7 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
        of a cut take ~300 cycles -- in front of the reads (where hipcc's scheduler had put them) they made the slot 640 cycles   \
        long against the partner's 384 (tools/gemm_trace.py --x3-slots) */                                                    \
     if ((Q) == 0 || (Q) == 2) { raw[0] = xn[((Q) >> 1) * 128 + fa0]; raw[1] = xn[((Q) >> 1) * 128 + fa1]; }         \
-    if ((Q) < 2) {                                                                                                  \
-      const char* ab = (a_cur ? abase : abase2) + (long)(a_cur ? kt + 2 : kt + 2 - nk) * (BK * 4);                  \
-      _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
-          dma_sv(a_cur ? aof[i2] : aof2[i2], ab, lds_unit(s3, i2));                                   \
-    } else {                                                                                                        \
-      const char* wb = gW + (long)(a_cur ? kt + 2 : kt + 2 - nk) * 128;                                             \
-      _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) - 2) * 2 + 2; ++i2)                                  \
-          dma_sv(a_cur ? wof[i2] : wof2[i2], wb, lds_unit(s4, i2));                                   \
-    }                                                                                                               \
+    if (WITH_DMA) X3P_DMA(Q)                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
     /* (the pieces are "used" here by an empty asm: LLVM otherwise sinks both cuts to their only real use, the copy in the loop  \
        latch -- behind the slab's last barrier, on the critical path of every slab: gemm_x3s_kernel, gemm_dma.hip) */     \
@@ -319,6 +333,9 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
   sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;                                                                   \
   if (++kt == nk) kt = 0;
 
+  // (A four-barrier form of this loop -- the schedule of gemm_pps_kernel, with slot 0's ring requests held back behind the next barrier
+  //  because A_{g+2} lands in the slot waves 4-7 still read W_{g-1} from -- was built and measured 1-2 % slower than the eight-barrier
+  //  form below on the same box (fp16x3 C2 2 194-2 213 against 2 231-2 243 clips/s): removed.)
   if (grp == 0) {
     bool pending = false;
     for (int g = 0;; ++g) {
@@ -369,6 +386,8 @@ __global__ __launch_bounds__(512) void gemm_x3p_kernel(GemmArgs p, const void* w
 #undef X3P_S
 #undef X3P_COMMIT
 #undef X3P_LOAD
+#undef X3P_LOAD_
+#undef X3P_DMA
 #undef X3P_MMA
 #undef X3P_VARS
 #undef X3P_RETIRE
