@@ -539,7 +539,9 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
 
 int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones.  (Round 3: four-wave workgroups held to
                        // three per CU by 16 KiB of unused LDS -- 1 536 workgroups = exactly two rounds instead of 1.5 -- measured 51.1 against 48.5 us
-                       // at C2, 138.6 against 130.9 at C3: the kernel is bound by issue throughput, not by the half-empty second round.)
+                       // at C2, 138.6 against 130.9 at C3: the kernel is bound by issue throughput, not by the half-empty second round.  A four-stage
+                       // K / V ring with three tiles in flight (asm LDS-DMA, counted vmcnt): 47.9 against 46.6-49.1 us, 131 against 125-128:
+                       // not waiting for K / V either.  Both removed.)
 // V row-major (same layout and strides as K): no transposed copy of V is needed
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
