@@ -479,7 +479,7 @@ def main():
         if os.path.exists(PMC_TRAFFIC_FILE) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
             try:
                 pm = json.load(open(PMC_TRAFFIC_FILE))
-                fam = [v for k, v in pm.items() if k.startswith(("gemm_pps_kernel", "gemm_pers_kernel", "gemm_pp8_kernel", "outproj_ln_kernel"))]
+                fam = [v for k, v in pm.items() if k.startswith(("gemm_pps_kernel", "gemm_pers_kernel", "gemm_pp8_kernel"))]
                 tot_n = sum(v["launches"] for v in fam)
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
             except Exception:
@@ -517,9 +517,8 @@ def main():
                          "kernel": ("svt::gemm_x3p_kernel / gemm_x3s_kernel (LDS-DMA split-operand products: fp32 activations cut into 16-bit (hi, lo) "
                                     "pieces in the kernel, pre-cut weight pieces, three MFMAs per 16x16x32 block; staggered 8-slot schedule, "
                                     "persistent for the GELU launches)") if split else
-                                   ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> / outproj_ln_kernel (one LDS-DMA MFMA pipeline, staggered "
-                                    "schedule: persistent stream of tiles per CU; one tile per workgroup for the batched positional conv; "
-                                    "row-complete with fused LayerNorm for the post-LN out-projection)"),
+                                   ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, staggered schedule: persistent "
+                                    "stream of tiles per CU; one tile per workgroup for the batched positional conv)"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"GB of HBM traffic per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",

@@ -266,14 +266,9 @@ int svt_softmax(const float* x_dev, int64_t rows, int32_t n, int32_t apply_log, 
 int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
                         int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
                         void* stream);
-/* Fused attention-output projection + residual + LayerNorm (hidden size 768, bf16): y = LN(a w^T + bias + rh + rl) as a
- * bf16 (hi, lo) pair [+ fp32 copy].  Replaces Wav2Vec2Attention.out_proj followed by `hidden_states = attn_residual +
- * hidden_states; hidden_states = self.layer_norm(hidden_states)` (HF modeling_wav2vec2.py:575-590); test hook. */
-int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const void* rh, const void* rl, int32_t m, int32_t k,
-                         const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yf, int device, void* stream);
 /* Diagnostics switches of the contraction kernels (tools/gemm_bench.py, tools/gemm_trace.py; never needed in production):
  * key 0 = kernel ablation variant, 1 = force the tile height (64/128/192/256), 2 = force the one-tile (2) / persistent (4)
- * scheduler, 3 = ablation variant while tracing, 5 = fused out-projection + LayerNorm on/off, 6 = small-problem kernel
+ * scheduler, 3 = ablation variant while tracing, 5 = retired (the fused out-projection + LayerNorm kernel of rounds 1-2), 6 = small-problem kernel
  * (gemm_skinny.hip) on/off, 7 = its eligibility threshold in 128x256 tiles, 8 = 8-wave fused-attention workgroups on/off,
  * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode, 10 = whole-head fused
  * attention kernel (K / V of a head resident in LDS; measured slower, off by default), 11 = LDS-DMA split-operand GEMM
@@ -288,7 +283,7 @@ int svt_debug_set(int key, int value);
 /* on = 0: off; 1: a HIP-event pair around every dense-contraction / attention launch; n > 1: around every n-th one */
 int svt_prof_enable(int on);
 int svt_prof_reset(void);
-/* kind: 0 = the dominant kernel family (svt::gemm_pers_kernel / gemm_pp8_kernel / outproj_ln_kernel: every large bf16
+/* kind: 0 = the dominant kernel family (svt::gemm_pps_kernel / gemm_pers_kernel / gemm_pp8_kernel: every large bf16
  * dense contraction; in the split-operand modes the split form of svt::gemm_kernel), 1 = the other dense contraction
  * kernels (exact-fp32 / small-shape GEMM), 2 = fused attention */
 int svt_prof_read(int kind, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);

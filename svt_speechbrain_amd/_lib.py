@@ -102,8 +102,6 @@ SYMBOLS = {
     "svt_nll_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "svt_softmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
-    "svt_debug_outproj_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                       C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "svt_debug_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),

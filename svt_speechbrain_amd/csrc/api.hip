@@ -331,7 +331,6 @@ using namespace svt;
 
 static int g_debug_keep_split = 0;  // svt_debug_set(12, 1): svt_debug_gemm keeps the split copy of its weight operand between calls
 static int g_conv_ln_bf16 = 1;     // svt_debug_set(9, 0): fp32 conv output + LayerNorm (A/B)
-static int g_fuse_outproj_ln = 1;  // svt_debug_set(5, 0) falls back to GEMM + LayerNorm kernels (A/B measurements)
 
 // =================================================================================================
 // encoder
@@ -492,16 +491,6 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
   return SVT_OK;
 }
 
-int svt_debug_outproj_ln(const void* a, const void* w, const float* bias, const void* rh, const void* rl, int32_t m, int32_t k,
-                         const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yf, int device, void* stream) {
-  if (!a || !w || !bias || !rh || !rl || !gamma || !beta || !yh || !yl) { set_error("svt_debug_outproj_ln: null argument"); return SVT_ERR_INVALID; }
-  if (!outproj_ln_eligible(768, k) || m < 1) { set_error("svt_debug_outproj_ln: the fused kernel needs hidden size 768 and K % 32 == 0"); return SVT_ERR_INVALID; }
-  if (int r = check_device(device)) return r;
-  SVT_HIP(hipSetDevice(device));
-  if (launch_outproj_ln(a, k, w, bias, rh, rl, m, k, gamma, beta, eps, yh, yl, yf, (hipStream_t)stream)) return SVT_ERR_HIP;
-  return SVT_OK;
-}
-
 int svt_debug_set(int key, int value) {
   if (key == 0) g_gemm_dbg = value;
   else if (key == 1) g_gemm_force_bm = value;
@@ -509,7 +498,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 3) g_gemm_variant = value;
   else if (key == 15) g_stamp_ends = value;
   else if (key == 16) g_pps_half_barriers = value;
-  else if (key == 5) g_fuse_outproj_ln = value;
+  else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
   else if (key == 7) g_gemm_skinny_max_tiles = value;
   else if (key == 8) g_flash_wide = value;
@@ -1202,16 +1191,12 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
       const bool last = l + 1 == c.num_layers;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
-      // (64 rows per workgroup: below ~190 workgroups the fused kernel leaves CUs idle and the two-kernel form is faster)
-      if (outproj_ln_eligible(D, D) && g_fuse_outproj_ln && rows >= 12288) {
-        // out-projection + residual + LayerNorm in one kernel (gemm_ln.hip): the projection result never leaves registers
-        if (int r = launch_outproj_ln(w.attn_o, D, Lw.wo.p, Lw.bo.as<float>(), xh, xl, (int)rows, D, Lw.ln1g.as<float>(),
-                                      Lw.ln1b.as<float>(), eps, xh, xl, nullptr, s)) return r;
-      } else {
-        if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 0, ACT_NONE, nullptr)) return r;
-        if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps,
-                                          xh, xl, nullptr, s)) return r;
-      }
+      // (rounds 1-2 fused this projection with the residual add and the LayerNorm in one row-complete kernel, 44 us against 29 + 23; with
+      //  the projection on gemm_pps_kernel the pair costs 20.6 + 23.9 us and the fused kernel -- every workgroup streaming all of W,
+      //  0.16 of the matrix pipe -- is gone: C2 6 093-6 110 against 6 066-6 074 clips/s on one box)
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 0, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps,
+                                        xh, xl, nullptr, s)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
       if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 0, ACT_NONE, nullptr)) return r;
       if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps,

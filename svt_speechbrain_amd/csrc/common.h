@@ -267,7 +267,7 @@ extern int g_guard_alloc;
 
 // ---- profiling of the dominant kernel (bench.py roofline leg) ----
 void prof_begin(hipStream_t s);
-// kind: 0 = the dominant family (gemm_pers / gemm_pp8 / outproj_ln kernels; the split form of gemm_kernel), 1 = other dense contraction kernels, 2 = flash attention
+// kind: 0 = the dominant family (gemm_pps / gemm_pers / gemm_pp8 kernels; the split form of gemm_kernel), 1 = other dense contraction kernels, 2 = flash attention
 void prof_end(hipStream_t s, double flops, double bytes, int kind = 1);
 
 // ---- elementwise / reduction kernels (kernels.hip) ----
@@ -340,9 +340,6 @@ bool layernorm_hilo_ok(int D);
 int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
                           const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s);
 // attention output projection + residual + LayerNorm in one kernel (gemm_ln.hip; hidden size 768, bf16 mode)
-bool outproj_ln_eligible(int D, int K);
-int launch_outproj_ln(const void* A, long lda, const void* W, const float* bias, const void* rh, const void* rl, int M, int K,
-                      const float* gamma, const float* beta, float eps, void* yh, void* yl, float* yF, hipStream_t s);
 // Fbank add-ons: time derivatives and context window
 int launch_deltas(const float* x, long ldx, int B, int T, int C, int n, float inv_denom, float* out, long ldo, hipStream_t s);
 int launch_context_window(const float* x, int B, int T, int C, int ctx, int lag, int pad, float* out, hipStream_t s);

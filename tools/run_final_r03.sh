@@ -15,6 +15,7 @@ python bench.py --no-cpu-baseline --model wav2vec2-large-lv60 --batch 64 --steps
 python bench.py --no-cpu-baseline --model hubert-large-ll60k --batch 64 --steps 4 --precision fp16x3 > $O/r03_bench_c3_hubert_large_b64_fp16x3.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --batch 1 --seconds 5 --steps 100 --warmup 10 > $O/r03_bench_c1_b1_5s.json 2>> $O/bench.err
 (python tools/av_bench.py; python tools/rca_bench.py) > $O/r03_c4_av_bench.txt 2>&1
+(python tools/soak.py --iters 3000; python tools/soak.py --precision fp16x3 --iters 800; python tools/soak.py --precision fp16 --iters 1000; python tools/soak.py --model hubert-large-ll60k --batch 64 --iters 400; python tools/soak.py --batch 1 --seconds 5 --iters 3000) 2>&1 | grep forwards > $O/r03_soak.txt
 python tools/gemm_yardstick.py --iters 30 > $O/r03_gemm_vendor_library_yardstick.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_s1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-legs --streams 1 > /dev/null 2>&1
