@@ -451,6 +451,8 @@ static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
       if (a.stamp_ends) return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 2>(a, s) : launch_pps_t<256, ACT_NONE, 16, 2>(a, s);
       return a.act == ACT_GELU ? launch_pps_t<256, ACT_GELU, 16, 1>(a, s) : launch_pps_t<256, ACT_NONE, 16, 1>(a, s);
     }
+    if (a.trace && bm == 192 && a.act == ACT_NONE && a.dbg >= 5 && a.dbg <= 7)
+      return a.stamp_ends ? launch_pps_t<192, ACT_NONE, 16, 2>(a, s) : launch_pps_t<192, ACT_NONE, 16, 1>(a, s);
   }
   if constexpr (STAUX == 16) {
     // four barriers per slab: FFN-1 78.9 -> 73.6 us, large FFN-1 285 -> 282, conv1 762 -> 778, the plain tiles equal; end to end
