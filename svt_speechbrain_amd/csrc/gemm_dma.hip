@@ -1061,6 +1061,23 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   __builtin_amdgcn_s_barrier();   // every wave holds its pieces of A_0 before the first slab's requests may reuse slots
   int sw = 1;                     // slot of W_g; A_{g+1} sits in the next one
   const int grp = wave >> 2;
+  // DBG 11..14: s_memtime at both ends of slots 2 (DBG - 11), 2 (DBG - 11) + 1 of slab nk / 2 (tools/gemm_trace.py --x3-slots --one-tile)
+  constexpr int STQ = DBG >= 11 && DBG <= 14 ? DBG - 10 : 0;
+  unsigned sraw[5], sst[5];
+  const int gs = nk / 2;
+  if constexpr (STQ != 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sst[i] = 0;
+  }
+#define X3S_S(k)                                                                                                    \
+  if constexpr (STQ != 0 && (k) >= 4 * (STQ - 1) && (k) <= 4 * (STQ - 1) + 4 && (k) < 16)                           \
+    sraw[((k) - 4 * (STQ - 1)) % 5] = (unsigned)__builtin_amdgcn_s_memtime();                                       \
+  if constexpr (STQ == 4 && (k) == 0) sraw[4] = (unsigned)__builtin_amdgcn_s_memtime();
+#define X3S_COMMIT()                                                                                                \
+  if constexpr (STQ != 0) {                                                                                         \
+    if (g == gs) { _Pragma("unroll") for (int i = 0; i < (STQ == 4 ? 4 : 5); ++i) sst[i] = sraw[i]; }               \
+    if (STQ == 4 && g == gs + 1) sst[4] = sraw[4];                                                                  \
+  }
 #define X3S_LOAD(Q)                                                                                                 \
   {                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < NBS; ++i) {                                                               \
@@ -1114,31 +1131,46 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   if (grp == 0) {
     for (int g = 0; g < nk; ++g) {
       X3S_VARS()
-      X3S_LOAD(0) __builtin_amdgcn_s_barrier(); X3S_MMA(0) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(3) __builtin_amdgcn_s_barrier(); X3S_MMA(3)
+      X3S_S(0) X3S_LOAD(0) X3S_S(1) __builtin_amdgcn_s_barrier(); X3S_S(2) X3S_MMA(0) X3S_S(3) __builtin_amdgcn_s_barrier();
+      X3S_S(4) X3S_LOAD(1) X3S_S(5) __builtin_amdgcn_s_barrier(); X3S_S(6) X3S_MMA(1) X3S_S(7) __builtin_amdgcn_s_barrier();
+      X3S_S(8) X3S_LOAD(2) X3S_S(9) __builtin_amdgcn_s_barrier(); X3S_S(10) X3S_MMA(2) X3S_S(11) __builtin_amdgcn_s_barrier();
+      X3S_S(12) X3S_LOAD(3) X3S_S(13) __builtin_amdgcn_s_barrier(); X3S_S(14) X3S_MMA(3)
       if (DBG != 1) wait_vm<GW>();
       __builtin_amdgcn_sched_barrier(0);
+      X3S_S(15)
       __builtin_amdgcn_s_barrier();
+      X3S_COMMIT()
       X3S_END()
     }
   } else {
     __builtin_amdgcn_s_barrier();  // one slot behind
     for (int g = 0; g < nk; ++g) {
       X3S_VARS()
-      X3S_LOAD(0) __builtin_amdgcn_s_barrier(); X3S_MMA(0) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(1) __builtin_amdgcn_s_barrier(); X3S_MMA(1) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(2) __builtin_amdgcn_s_barrier(); X3S_MMA(2) __builtin_amdgcn_s_barrier();
-      X3S_LOAD(3)
+      X3S_S(0) X3S_LOAD(0) X3S_S(1) __builtin_amdgcn_s_barrier(); X3S_S(2) X3S_MMA(0) X3S_S(3) __builtin_amdgcn_s_barrier();
+      X3S_S(4) X3S_LOAD(1) X3S_S(5) __builtin_amdgcn_s_barrier(); X3S_S(6) X3S_MMA(1) X3S_S(7) __builtin_amdgcn_s_barrier();
+      X3S_S(8) X3S_LOAD(2) X3S_S(9) __builtin_amdgcn_s_barrier(); X3S_S(10) X3S_MMA(2) X3S_S(11) __builtin_amdgcn_s_barrier();
+      X3S_S(12) X3S_LOAD(3)
       if (DBG != 1) wait_vm<GW>();
       __builtin_amdgcn_sched_barrier(0);
+      X3S_S(13)
       __builtin_amdgcn_s_barrier();
-      X3S_MMA(3)
+      X3S_S(14) X3S_MMA(3)
+      X3S_S(15)
       if (g + 1 < nk) __builtin_amdgcn_s_barrier();
+      X3S_COMMIT()
       X3S_END()
     }
   }
+  if constexpr (STQ != 0) {
+    if (p.trace && lane == 0) {
+      long long* o = p.trace + 65536 + ((long)blockIdx.x * 8 + wave) * 32;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = sst[i];
+      o[9] = nk; o[10] = gs; o[11] = STQ;
+    }
+  }
+#undef X3S_S
+#undef X3S_COMMIT
 #undef X3S_LOAD
 #undef X3S_MMA
 #undef X3S_VARS
@@ -1298,6 +1330,20 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256) || t256 >= 1024)) {   // (large QKV, 1 500 tiles: 547 against 583 us)
     g.dbg = g_gemm_dbg == 9 ? 0 : g_gemm_dbg;
     if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
+  } else if (g.trace && kind == 3 && g.stamp_ends >= 1 && g.stamp_ends <= 4) {   // slot stamps of the one-tile kernel (diagnostics)
+#define SVT_X3S_STAMP(NBS_, D_)                                                                                    \
+  {                                                                                                                 \
+    if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, NBS_, D_>, (int)lds_bytes)) return r_;           \
+    hipLaunchKernelGGL((gemm_x3s_kernel<true, NBS_, D_>), dim3((unsigned)(narrow ? t192 : t256)), dim3(512), lds_bytes, s, g, packed); \
+  }
+    if (narrow) {
+      if (g.stamp_ends == 1) SVT_X3S_STAMP(3, 11) else if (g.stamp_ends == 2) SVT_X3S_STAMP(3, 12)
+      else if (g.stamp_ends == 3) SVT_X3S_STAMP(3, 13) else SVT_X3S_STAMP(3, 14)
+    } else {
+      if (g.stamp_ends == 1) SVT_X3S_STAMP(4, 11) else if (g.stamp_ends == 2) SVT_X3S_STAMP(4, 12)
+      else if (g.stamp_ends == 3) SVT_X3S_STAMP(4, 13) else SVT_X3S_STAMP(4, 14)
+    }
+#undef SVT_X3S_STAMP
   } else if ((g_gemm_variant == 31 || g_gemm_variant == 33) && kind == 3) {
     if (g_gemm_variant == 31) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4, 1>, (int)lds_bytes)) return r_;

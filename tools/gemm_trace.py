@@ -16,7 +16,7 @@ from gemm_bench import SHAPES  # noqa: E402
 def x3_slots(a):
     lib = _lib.load()
     lib.svt_debug_set(12, 1)   # keep the registered split weights between calls
-    lib.svt_debug_set(3, 34)   # always the persistent form
+    lib.svt_debug_set(3, 32 if a.one_tile else 34)   # never / always the persistent form
     dev = torch.device("cuda:0")
     for name, M, N, K, conv, act, out_f32, resid in SHAPES:
         if a.only != name:
@@ -56,7 +56,7 @@ def x3_slots(a):
             call(0)
         e1.record()
         torch.cuda.synchronize()
-        print(f"{name}: fp16x3 persistent kernel {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+        print(f"{name}: fp16x3 {'one-tile' if a.one_tile else 'persistent'} kernel {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
         recs = []
         for mode in (1, 2, 3, 4):
             lib.svt_debug_set(15, mode)
@@ -104,6 +104,7 @@ def main():
                     "51 / 53 / 54 = without LDS-DMA / epilogue / both)")
     ap.add_argument("--slots", type=int, default=0, help="gemm_pps_kernel slot stamps of one slab: 5 = middle of the second tile, 6 = last slab of "
                     "the first tile, 7 = first slab of the second tile (uses --force-variant 70 + this digit)")
+    ap.add_argument("--one-tile", action="store_true", help="with --x3-slots: gemm_x3s_kernel (one tile per workgroup) instead of the persistent kernel")
     ap.add_argument("--x3-slots", action="store_true", help="slot stamps of gemm_x3p_kernel (fp16x3, the persistent split-operand kernel): four "
                     "launches, two slots each")
     a = ap.parse_args()
