@@ -980,13 +980,20 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   const float* A = (const float*)p.A;
   const unsigned short* W = (const unsigned short*)wsplit;  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
   const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
-  const float* asrc[GA];
-  const unsigned short* wsrc[GW];
+  // ring requests in the `voffset + SGPR base` form (as gemm_x3p_kernel): a 64-bit scalar base per operand (A: the tile's first row -- the
+  // tensor may exceed 4 GiB, a tile's span may not: gemm_x3p_eligible), one 32-bit offset per lane and request, the K advance scalar.
+  // With per-lane 64-bit pointers every request cost two vector additions in its LOAD slot, ~70 cycles per slot under the partner's
+  // MFMA issue: the slots with requests ran 356-376 cycles against 288 of MFMAs (profiles/r03_gemm_x3_slots.txt).
+  auto a_row_off = [&](int m) -> long { return ((long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride) * 4; };
+  const long a_o0 = a_row_off(m0);
+  const char* abase = (const char*)A + a_o0;
+  const char* wbase = (const char*)W;
+  unsigned aoff[GA], woff[GW];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
     int m = m0 + (wave + 8 * i) * 8 + r8;
     if (m > p.M - 1) m = p.M - 1;
-    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 4;
+    aoff[i] = (unsigned)(a_row_off(m) - a_o0) + ch * 16;
   }
 #pragma unroll
   for (int i = 0; i < GW; ++i) {
@@ -994,8 +1001,11 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
     const int i16 = rho & 15;
     int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
     if (n > p.N - 1) n = p.N - 1;
-    wsrc[i] = W + (long)n * (2 * p.K) + ch * 8;
+    woff[i] = (unsigned)((long)n * p.K * 4 + ch * 16);
   }
+  auto dma_sv = [](unsigned voff, const void* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+  };
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds);
   auto unit_addr = [&](int slot, int i) -> unsigned {
     return __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u);
@@ -1045,13 +1055,13 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   };
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2, W_1 -> slot 3; everything but W_1 landed before slab 0
 #pragma unroll
-  for (int i = 0; i < GA; ++i) dma16_asm(asrc[i], unit_addr(0, i));
+  for (int i = 0; i < GA; ++i) dma_sv(aoff[i], abase, unit_addr(0, i));
 #pragma unroll
-  for (int i = 0; i < GW; ++i) dma16_asm(wsrc[i], unit_addr(1, i));
+  for (int i = 0; i < GW; ++i) dma_sv(woff[i], wbase, unit_addr(1, i));
 #pragma unroll
-  for (int i = 0; i < GA; ++i) dma16_asm(asrc[i] + kc(1) * BK, unit_addr(2, i));
+  for (int i = 0; i < GA; ++i) dma_sv(aoff[i], abase + (long)kc(1) * (BK * 4), unit_addr(2, i));
 #pragma unroll
-  for (int i = 0; i < GW; ++i) dma16_asm(wsrc[i] + kc(1) * 64, unit_addr(3, i));
+  for (int i = 0; i < GW; ++i) dma_sv(woff[i], wbase + (long)kc(1) * 128, unit_addr(3, i));
   wait_vm<GW>();
   __builtin_amdgcn_s_barrier();
   x3_u32x4 xh[2], xl[2], nh[2], nl[2], raw[2][2], wh[NBS], wl[NBS];
@@ -1090,10 +1100,10 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
     if (DBG == 1) {                                                                                                 \
     } else if ((Q) < 2) {   /* A_{g+2} -> the slot W_{g-1} left */                                                  \
       _Pragma("unroll") for (int i2 = (Q) * 2; i2 < (Q) * 2 + 2; ++i2)                                              \
-          dma16_asm(asrc[i2] + (long)kc(g + 2) * BK, unit_addr(s3, i2));                              \
+          dma_sv(aoff[i2], abase + (long)kc(g + 2) * (BK * 4), unit_addr(s3, i2));                  \
     } else {         /* W_{g+2} -> the slot of A_g */                                                               \
       _Pragma("unroll") for (int i2 = ((Q) - 2) * 2; i2 < ((Q) == 2 ? 2 : GW); ++i2)                                \
-          dma16_asm(wsrc[i2] + (long)kc(g + 2) * 64, unit_addr(s4, i2));                              \
+          dma_sv(woff[i2], wbase + (long)kc(g + 2) * 128, unit_addr(s4, i2));                        \
     }                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
     /* The cuts run BEHIND the slot's LDS reads and ring requests, under the LDS latency: while the partner wave issues its MFMAs \
@@ -1303,6 +1313,14 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     const size_t row = off / ((size_t)a.K * 4);
     if (row + a.N > (size_t)it->second.N) return 1;
     packed = (const char*)it->second.packed + row * (size_t)a.K * 4;
+  }
+  {
+    // the kernels address a tile's rows by 32-bit offsets from its first row, and the packed weights by 32-bit offsets from their base
+    const unsigned long clips = 255 / (unsigned long)(a.a_rpb > 0 ? a.a_rpb : 1) + 1;
+    const unsigned long bs = (unsigned long)(a.a_bstride > 0 ? a.a_bstride : 0), rs = (unsigned long)(a.a_rstride > 0 ? a.a_rstride : 0);
+    if (a.a_bstride < 0 || a.a_rstride <= 0 || (clips * bs + 256ul * rs + (unsigned long)a.K) * 4 >= 0xF0000000ul ||
+        (unsigned long)a.N * a.K * 4 >= 0xF0000000ul)
+      return 1;
   }
   const size_t lds_bytes = 5 * 32768;
   GemmArgs g = a;
