@@ -19,8 +19,12 @@
 //     groups meet: waves 0-3 run it in front of the next tile's first LOAD slot, waves 4-7
 //     behind their last MFMA slot, i.e. in the same barrier interval, so the two waves of a SIMD interleave their VALU work
 //     instead of each running it alone against an idle partner; the stores drain under the next tile's MFMAs;
-//   * the bias of a tile is fetched by four asm loads one slot before the tile's last A unit is requested: the counted wait that
-//     retires that slab covers them (VMEM operations return in order), so the epilogue itself waits for nothing.
+//   * the bias is the accumulators' INITIAL value: the bias of the NEXT tile is fetched by two asm loads in the last slab of every
+//     tile (the first tile's in front of the head of the stream); the counted wait that retires that slab covers them (VMEM
+//     operations return in order), so the epilogue neither waits nor adds;
+//   * dispatched schedule: four barriers per slab (HB = true below: between two barriers every wave runs one LOAD slot and one MFMA
+//     slot, in opposite order for the two wave groups); the eight-barrier form (one barrier behind every slot) is kept for the slot
+//     stamps of tools/gemm_trace.py and as the A/B of svt_debug_set key 16.
 // Contract: bf16 (operand type) output, no residual, alpha = 1, activation none or GELU, K % 64 == 0, K >= 128, N % 256 == 0,
 // A and W spans below 4 GiB (32-bit offsets).  Everything else stays on gemm_pers_kernel / gemm_pp8_kernel.
 #include "common.h"
