@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_final
 mkdir -p $O
-(time python -m pytest tests -q -m gpu -x 2>&1 | tail -5) > $O/r03_gputests.log 2>&1
+(time python -m pytest tests -q -m gpu -x 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -6) > $O/r03_gputests.log 2>&1
 python bench.py > $O/r03_bench.json 2> $O/bench.err
 python bench.py --no-cpu-baseline --streams 1 > $O/r03_bench_streams1.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --precision fp16 > $O/r03_bench_fp16.json 2>> $O/bench.err
