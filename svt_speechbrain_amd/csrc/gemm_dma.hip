@@ -1452,7 +1452,7 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   // 52.7 -> 48.0, 4096^3 115 -> 109; large FFN-2 (500 tiles, K = 4096) equal.  Measured per shape:
   // profiles/r03_gemm_vendor_library_yardstick.txt.  Write-through (sc1) stores: the output leaves L2 while the kernel runs instead
   // of at the kernel boundary (FFN-1: 98 MB, 16 us).
-  // svt_debug_set key 3: 50 / 60 / 70 force it with default / nt / sc1 stores (53: without epilogue), 49 switches it off.
+  // svt_debug_set key 3: 50 / 70 force it with default / sc1 stores (53: without epilogue), 49 switches it off.
   if (g_gemm_variant >= 50 && g_gemm_variant < 80 && gemm_pps_eligible(a)) {
     GemmArgs b = a;
     b.dbg = g_gemm_variant % 10;

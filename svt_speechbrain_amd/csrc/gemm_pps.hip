@@ -483,7 +483,7 @@ static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
 }
 
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) {
-  if (store_policy == 1) return launch_pps_aux<2>(a, bm, s);    // nt
+  // (nt stores, aux = 2, were measured in round 3 and never won: their instantiations are gone)
   if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
   return launch_pps_aux<0>(a, bm, s);
 }
