@@ -32,7 +32,9 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 // BIAS: WavLM's gated relative position bias, scores += gate[b,h,q] * pb[h][key - q + T - 1] (pb row of 2T-1 floats kept
 // in LDS; added in the scaled log2 domain before the row max).
-template <int DH, bool BIAS = false, int NW = 4>
+// STAMP (diagnostics, svt_debug_set key 18, tools/attn_bench.py --stamps): s_memtime at seven points of key tile 4, per wave, written over the
+// head of O
+template <int DH, bool BIAS = false, int NW = 4, bool STAMP = false>
 __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
                                                          const bf16_t* __restrict__ K, long ldk, long k_bstride,
                                                          const bf16_t* __restrict__ V, int /*unused*/, bf16_t* __restrict__ O,
@@ -132,17 +134,23 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
   }
 
   constexpr long STAGE_BYTES = (long)2 * TILE16 * 16;
+  unsigned stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SVT_ATT_S(k) if constexpr (STAMP) { if (tile == 4) stp[k] = (unsigned)__builtin_amdgcn_s_memtime(); }
   SVT_STAGE_DMA(0, 0)
   for (int tile = 0; tile < ntiles; ++tile) {
     const int st = tile & 1;
+    if constexpr (STAMP) { if (tile == 5) stp[7] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    SVT_ATT_S(0)
     // own fills of this tile have landed (explicit vmcnt(0): hipcc's own placement of that wait is an alias-analysis
     // artefact, not a contract), everyone's have after the barrier, and every wave is done reading the other stage
     // (tile - 1), which the next fill overwrites
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    SVT_ATT_S(1)
     if (tile + 1 < ntiles) {
       if (st) SVT_STAGE_DMA(tile + 1, 0) else SVT_STAGE_DMA(tile + 1, 1)
     }
+    SVT_ATT_S(2)
     const uint4* Kf = KV[st];
 
     f32x16 s[2];
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
           s[kb][r] = fmaf(s[kb][r], c, gq * pbl[idx]);
         }
     }
+    SVT_ATT_S(3)
     const float cs = BIAS ? 1.0f : c;
     if (__builtin_expect(tile * 64 + 64 > T, 0)) {  // wave-uniform, last tile only
       const int kbase = tile * 64 + 4 * hh;
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
+    SVT_ATT_S(4)
     // exponent arguments and row sums on pairs (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot)
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     f32x2v sum2 = {0.f, 0.f};
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
     float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 32, 64);
     l += sum;
+    SVT_ATT_S(5)
     // P (bf16) fragments straight from the S accumulators: k-step ss of key block kb = regs 8ss..8ss+7
     bf16x8 pf[2][2];
 #pragma unroll
@@ -237,7 +248,9 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
           const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[db] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[db]);
         }
+    SVT_ATT_S(6)
   }
+#undef SVT_ATT_S
 
   // O[q][d] = o / l ; lane (q = lane&31, hh) holds d = db*32 + (r&3) + 8*(r>>2) + 4*hh
   const int q = q0 + (lane & 31);
@@ -253,6 +266,17 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
       for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][g * 4 + j] * inv);
       *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
     }
+  if constexpr (STAMP) {
+    __syncthreads();
+    if (lane == 0) {
+      const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      unsigned* o32 = (unsigned*)O + (wg * NW + wave) * 16;
+      // (the records overwrite the head of O: diagnostics only; the last workgroups' stores may land on top of some of them)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o32[i] = stp[i];
+      o32[8] = 0x5A5A0000u + (unsigned)wave;
+    }
+  }
 }
 
 #undef SVT_STAGE_DMA
@@ -537,6 +561,7 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   return 0;
 }
 
+int g_attn_stamp = 0;  // svt_debug_set key 18: tile stamps of the 8-wave head_dim-64 kernel (tools/attn_bench.py --stamps)
 int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones.  (Round 3: four-wave workgroups held to
                        // three per CU by 16 KiB of unused LDS -- 1 536 workgroups = exactly two rounds instead of 1.5 -- measured 51.1 against 48.5 us
                        // at C2, 138.6 against 130.9 at C3: the kernel is bound by issue throughput, not by the half-empty second round.  A four-stage
@@ -571,7 +596,10 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
     return 0;
   }
   prof_begin(s);
-  if (dh == 64 && wide)
+  if (dh == 64 && wide && g_attn_stamp)
+    hipLaunchKernelGGL((flash_attn_kernel<64, false, 8, true>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
+  else if (dh == 64 && wide)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else if (dh == 64)

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--wide", type=int, default=None, help="svt_debug_set key 8 (workgroup shape / occupancy experiments of the fused attention)")
+    ap.add_argument("--stamps", action="store_true", help="tile stamps of the 8-wave head_dim-64 kernel (svt_debug_set key 18): where a wave's "
+                    "time goes inside key tile 4")
     a = ap.parse_args()
     lib = _lib.load()
     if a.wide is not None:
@@ -54,6 +56,31 @@ def main():
         tf = 4.0 * B * H * T * T * dh / us / 1e6
         print(f"{name:6s} B={B:3d} T={T} H={H:2d} dh={dh:3d}: {us:8.1f} us  {tf:7.1f} TFLOP/s"
               + (f"  max|err|={err:.3e}" if err is not None else ""), flush=True)
+        if a.stamps and dh == 64 and B * H * ((T + 255) // 256) >= 512:
+            lib.svt_debug_set(18, 1)
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize()
+            lib.svt_debug_set(18, 0)
+            nwg = B * H * ((T + 255) // 256)
+            rec = out.view(-1).view(torch.int32)[: nwg * 8 * 16].view(nwg * 8, 16).cpu().to(torch.int64) & 0xFFFFFFFF
+            ok = (rec[:, 8] >> 16) == 0x5A5A
+            rec = rec[ok]
+
+            def d(i, j):
+                return ((rec[:, j] - rec[:, i]) & 0xFFFFFFFF).double()
+            names = ["wait for the tile's fills (vmcnt)  + barrier", "issue the next tile's LDS-DMA", "K fragment reads + 8 S MFMAs (issue)",
+                     "mask / row max / exchange / rescale", "exp2 + row sums", "P conversion, V transposing reads, 8 PV MFMAs (issue)",
+                     "loop back to the next tile's top"]
+            print(f"   key tile 4, core cycles per phase, median over {rec.shape[0]} waves (a tile = 512 cycles of MFMA per wave, four waves per SIMD):")
+            tot = 0.0
+            for k in range(6):
+                v = d(k, k + 1).median().item()
+                tot += v
+                print(f"     {names[k]:55s} {v:7.0f}")
+            v = d(6, 7).median().item()
+            print(f"     {names[6]:55s} {v:7.0f}")
+            print(f"     tile total {tot + v:.0f} cycles")
 
 
 if __name__ == "__main__":
