@@ -22,6 +22,8 @@ After the timed region (never part of `value`):
                       (s_memtime / s_memrealtime) on either side: the clock the chip HELD under this load;
   * notes-out leg  -- step + device-to-host copy of the decoded frames + `frames2note` of every clip
                       (`notes_out_clips_per_s`: "greedy decode" all the way to note lists on the host);
+  * parity-grade leg -- the same workload in precision "fp16x3", the fast mode that meets the north star's tolerance
+                      (`parity_grade`: clips/s, its own roofline fraction against 2.5 PF / 3, max |dlogit| vs the exact fp32 mode);
   * cpu_baseline   -- the oracle on the host cores, SURVEY.md §8(d) protocol (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -141,7 +143,7 @@ def self_launch(n):
 
 
 def cpu_worker(spec):
-    """One process of cpu_baseline.by_procs: `spec` = JSON {state, model, cpus, threads, go, passes}.  CPU only (the oracle)."""
+    """One process of cpu_baseline.by_procs: `spec` = JSON {state, model, cpus, threads, passes, ready_dir, index, nproc}.  CPU only (the oracle)."""
     sp = json.loads(spec)
     if sp.get("cpus"):
         try:
@@ -163,14 +165,25 @@ def cpu_worker(spec):
 
     one()
     one()
-    while time.time() < sp["go"]:   # all processes start their timed passes together
+    # barrier over the worker processes: every worker drops a "ready" file after its warm-ups and starts its timed passes when all
+    # `nproc` files exist (the slowest worker's warm-ups under contention decide the start, not a fixed delay)
+    t_ready = time.time()
+    open(os.path.join(sp["ready_dir"], f"ready_{sp['index']}"), "w").close()
+    deadline = t_ready + float(sp.get("barrier_timeout", 240.0))
+    released = False
+    while time.time() < deadline:
+        if len([f for f in os.listdir(sp["ready_dir"]) if f.startswith("ready_")]) >= int(sp["nproc"]):
+            released = True
+            break
         time.sleep(0.005)
+    t_start = time.time()
     ts = []
     for _ in range(int(sp["passes"])):
         t = time.perf_counter()
         one()
         ts.append(time.perf_counter() - t)
-    print(json.dumps({"median_s": statistics.median(ts), "passes": len(ts), "t_end": time.time()}), flush=True)
+    print(json.dumps({"median_s": statistics.median(ts), "passes": len(ts), "t_ready": t_ready, "t_start": t_start, "t_end": time.time(),
+                      "released": released}), flush=True)
     return 0
 
 
@@ -183,20 +196,21 @@ def cpu_by_procs(model, sd, hd, phys, sockets, logical, threads=16, passes=3):
     if nproc < 2:
         return None
     path = os.path.join(tempfile.gettempdir(), f"svt_cpu_baseline_{os.getpid()}.pt")
+    ready_dir = tempfile.mkdtemp(prefix="svt_cpu_ready_")
     torch.save({"sd": sd, "hd": hd}, path)
     try:
-        go = time.time() + 25.0   # load + two warm-ups of the slowest process
         procs = []
         for i in range(nproc):
             cpus = list(range(i * threads, (i + 1) * threads)) if logical >= phys else []
-            spec = json.dumps({"state": path, "model": model, "cpus": cpus, "threads": threads, "go": go, "passes": passes})
+            spec = json.dumps({"state": path, "model": model, "cpus": cpus, "threads": threads, "passes": passes,
+                               "ready_dir": ready_dir, "index": i, "nproc": nproc})
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], stdout=subprocess.PIPE,
                                           stderr=subprocess.DEVNULL, text=True, env=env))
         outs = []
         for pr in procs:
             try:
-                o, _ = pr.communicate(timeout=240)
+                o, _ = pr.communicate(timeout=600)
                 outs.append(json.loads(o.strip().splitlines()[-1]))
             except Exception:
                 pr.kill()
@@ -204,13 +218,21 @@ def cpu_by_procs(model, sd, hd, phys, sockets, logical, threads=16, passes=3):
         ok = [o for o in outs if o]
         if not ok:
             return None
+        # the window in which EVERY process was inside its timed passes, as a share of the longest process's timed span
+        t_all_started, t_first_done = max(o["t_start"] for o in ok), min(o["t_end"] for o in ok)
+        span = max(o["t_end"] - o["t_start"] for o in ok)
         return {"processes": nproc, "threads_per_process": threads, "completed": len(ok),
                 "clips_per_s": round(sum(8.0 / o["median_s"] for o in ok), 3),
                 "per_process_clips_per_s": [round(8.0 / o["median_s"], 3) for o in ok],
-                "late_start": bool(any(o["t_end"] - go < 0 for o in ok)),
+                "late_start": bool(len(ok) < nproc or any(not o["released"] for o in ok)),
+                "start_skew_s": round(t_all_started - min(o["t_start"] for o in ok), 3),
+                "overlap_share": round(max(0.0, t_first_done - t_all_started) / span, 3) if span > 0 else None,
                 "what": f"{nproc} oracle processes x {threads} threads, each pinned to its own {threads} physical cores, 8 x 10 s clips per pass, "
-                        f"2 warm-ups, {passes} timed passes started together; sum of 8 / median over the processes"}
+                        f"2 warm-ups, then a file barrier over the processes and {passes} timed passes; sum of 8 / median over the processes; "
+                        "late_start = a process missed the barrier; overlap_share = time all processes were in their timed passes / longest timed span"}
     finally:
+        import shutil
+        shutil.rmtree(ready_dir, ignore_errors=True)
         try:
             os.remove(path)
         except OSError:
@@ -228,6 +250,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained and notes-out legs (profiling runs)")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity-grade (fp16x3) leg of the default bf16 line")
     ap.add_argument("--sustain-seconds", type=float, default=3.2)
     ap.add_argument("--gather", default="logits", choices=["logits", "frames"],
                     help="N > 1: all-gather the fp32 logits (80 B per frame, the north star's collective) or the compact decoded "
@@ -466,6 +489,66 @@ def main():
                              "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); one step per lane stays in flight "
                              "while the host assembles the notes of the step that just finished; host_ms_per_step = the frame2note share"}
 
+    # parity-grade leg (bf16 default line only): the SAME workload in the mode that meets north_star's tolerance ("frame logits within
+    # 1e-3 fp32, bit-identical argmax / note sequences": MIR_ST500/train_audio_ssl.py:93-100 -> utils.py:110-146), precision
+    # "fp16x3" (three 16-bit MFMAs per algorithmic multiply-add, fp32 accumulate): 3 warm-up + 10 timed steps on the same two lanes
+    # and the same run_sharded loop, a one-stream replay with an event pair around every dense launch for its own roofline
+    # fraction (against 2.5 PF / 3), and the largest |logit - fp32 logit| over the batch's first two clips (the exact-fp32-MFMA
+    # mode on the whole batch: the whole-batch norms see the same clips).
+    parity_grade = None
+    if not args.no_extra_legs and not args.no_parity_leg and args.precision == "bf16":
+        pg_prec = "fp16x3"
+        pg_encs = [S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=pg_prec, normalize_wav=True, seed=1986).to(dev)]
+        pg_encs += [pg_encs[0].replica() for _ in range(ns - 1)]
+        pg_frames = [torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev) for _ in range(ns)]
+        pg_last = [None] * ns
+
+        def make_pg(i):
+            def fwd():
+                lg = pg_encs[i].forward_head(wav, head, frames=pg_frames[i])
+                if i:
+                    lg.record_stream(main_stream)
+                pg_last[i] = lg
+                return lg
+            return fwd
+
+        pg_fwds = [make_pg(i) for i in range(ns)]
+        pg_steps, pg_warm = 10, 3
+        pres = D.run_sharded(pg_fwds, n_total, rank, world, pg_steps, pg_warm, dev, lanes=lanes, sync=torch.cuda.synchronize)
+        lib.svt_prof_reset()
+        lib.svt_prof_enable(1)
+        D.run_sharded(pg_fwds[:1], n_total, rank, world, pg_steps, 0, dev, lanes=lanes[:1], sync=torch.cuda.synchronize)
+        lib.svt_prof_enable(0)
+        pg_dom, pg_attn = prof(0), prof(2)
+        pg_logits = pg_last[0].clone()
+        del pg_encs, pg_fwds
+        ref_enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision="fp32", normalize_wav=True, seed=1986).to(dev)
+        ref_frames = torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev)
+        ref_logits = ref_enc.forward_head(wav, head, frames=ref_frames)
+        torch.cuda.synchronize()
+        ncmp = min(2, hi - lo)
+        dmax = float((pg_logits[:ncmp] - ref_logits[:ncmp]).abs().max().item())
+        same_frames = bool(torch.equal(pg_frames[0][:ncmp, :, 2:], ref_frames[:ncmp, :, 2:]))
+        bf16_dmax = float((out[lo:lo + ncmp].float() - ref_logits[:ncmp]).abs().max().item()) if (not gather_frames) else None
+        del ref_enc
+        pg_peak = MFMA_PEAK_TFLOPS[pg_prec]
+        pg_ach = (pg_dom[2] / 1e12) / (pg_dom[1] / 1e3) if pg_dom[1] > 0 else 0.0
+        pg_cps = n_total * pg_steps / pres["elapsed"]
+        parity_grade = {"precision": pg_prec, "clips_per_s": round(pg_cps, 3), "ms_per_step": round(1e3 * pres["elapsed"] / pg_steps, 4),
+                        "steps": pg_steps, "warmup": pg_warm, "streams": ns,
+                        "max_abs_dlogit_vs_fp32": dmax, "clips_compared": ncmp, "tolerance": 1e-3,
+                        "octave_pitch_argmax_identical_to_fp32": same_frames,
+                        "bf16_line_max_abs_dlogit_vs_fp32": bf16_dmax,
+                        "end_to_end_mfma_frac": round(pg_cps / world * cfg.flops_per_clip(L) / (pg_peak * 1e12), 4),
+                        "roofline": {"bound": "mfma", "achieved": round(pg_ach, 2), "peak": round(pg_peak, 1), "unit": "TFLOP/s (algorithmic)",
+                                     "frac": round(pg_ach / pg_peak, 4), "launches": int(pg_dom[0]),
+                                     "avg_launch_ms": round(pg_dom[1] / max(1, pg_dom[0]), 5), "ms_per_step": round(pg_dom[1] / pg_steps, 4),
+                                     "flash_attn_ms_per_step": round(pg_attn[1] / pg_steps, 4)},
+                        "what": "the same workload in the parity-grade mode (split 16-bit operands, three MFMAs per algorithmic multiply-add, "
+                                "fp32 accumulate; peak = 2.5 PF / 3): run_sharded on the same lanes after the timed region; roofline from a "
+                                "one-stream replay with HIP events around every dense launch; max |logit - exact-fp32-mode logit| over the "
+                                "first clips of the batch"}
+
     if rank == 0:
         clips_per_s = n_total * args.steps / elapsed
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -543,6 +626,9 @@ def main():
         if notes_out is not None:
             res_json["notes_out_clips_per_s"] = notes_out["clips_per_s"]
             res_json["notes_out"] = notes_out
+        if parity_grade is not None:
+            res_json["parity_grade_clips_per_s"] = parity_grade["clips_per_s"]
+            res_json["parity_grade"] = parity_grade
         if world == 1 and not args.no_cpu_baseline:
             sd = {k[len("model."):]: v.detach().cpu() for k, v in enc.state_dict().items()}
             res_json["cpu_baseline"] = cpu_baseline(cfg, sd, hd, model=args.model)

@@ -596,10 +596,13 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
     return 0;
   }
   prof_begin(s);
-  if (dh == 64 && wide && g_attn_stamp)
+#ifdef SVT_DIAG
+  if (dh == 64 && wide && g_attn_stamp)   // tile stamps (make DIAG=1)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8, true>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
-  else if (dh == 64 && wide)
+  else
+#endif
+  if (dh == 64 && wide)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else if (dh == 64)

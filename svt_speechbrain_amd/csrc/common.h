@@ -120,8 +120,12 @@ __device__ __forceinline__ void gelu_bf16x2_xn(f32x2_t (&x)[NP]) {
 // rate) and the 1/sqrt 2 and 1/2 of the erf form folded into the coefficients: 11 issue slots per PAIR (2 med3, t^2, 6 Horner
 // steps, t q + 1/2, x *) instead of ~33 for the exp form and 17 for the degree-17 erf polynomial this replaces (the epilogue of
 // a GELU tile is VALU-bound: 5.0 -> 3.6 us per 256 x 256 tile).  |Phi error| <= 6.5e-5; |y error| <= 1.0e-4 |x| (2.4e-4 for
-// |x| <= 6, 1e-4 relative for x > 0.01): 20x below the bf16 rounding of the stored value (2^-9 relative).  Phi saturates at
-// 9.8e-6 / 1 - 9.8e-6 beyond +-3.8.  fp32 outputs keep gelu_fast.  Coefficients: weighted least-squares minimax fit on [0, 3.8].
+// |x| <= 6, 1e-4 relative for x > 0.01): 20x below the bf16 rounding of the stored value (2^-9 relative).  The additive constant is
+// 1/2 - 9.27e-6 (SVT_GELU_HALF), chosen so that the clamped polynomial is 0 at t = -3.8 (6e-9 in fp32): Phi saturates at 6e-9 /
+// 1 - 1.9e-5 beyond +-3.8, i.e. the negative tail is flushed (|y| <= 6e-9 |x| for x < -3.8 instead of 9.3e-6 |x|, which grew
+// without bound: x = -100 gave -9e-4 for a true value of 0); |Phi error| <= 7.4e-5 overall.  On (-3.8, 0) the error is absolute
+// (<= 7.4e-5 |x|), so the RELATIVE error of the tiny outputs there reaches several per cent -- of values below 5e-3.
+// fp32 outputs keep gelu_fast.  Coefficients: weighted least-squares minimax fit on [0, 3.8].
 #define SVT_GELU_C0 3.9867674568e-01f
 #define SVT_GELU_C1 (-6.5719787820e-02f)
 #define SVT_GELU_C2 9.3166354115e-03f
@@ -129,6 +133,7 @@ __device__ __forceinline__ void gelu_bf16x2_xn(f32x2_t (&x)[NP]) {
 #define SVT_GELU_C4 6.0684808363e-05f
 #define SVT_GELU_C5 (-2.2724625145e-06f)
 #define SVT_GELU_C6 3.6657791326e-08f
+#define SVT_GELU_HALF 0.4999907314777374f
 __device__ __forceinline__ f32x2_t gelu_bf16x2(f32x2_t x) {
   f32x2_t t;
   t.x = __builtin_amdgcn_fmed3f(x.x, -3.8f, 3.8f);
@@ -140,7 +145,7 @@ __device__ __forceinline__ f32x2_t gelu_bf16x2(f32x2_t x) {
   q = q * u + SVT_GELU_C2;
   q = q * u + SVT_GELU_C1;
   q = q * u + SVT_GELU_C0;
-  return x * (t * q + 0.5f);
+  return x * (t * q + SVT_GELU_HALF);
 }
 // several pairs at once, Horner steps interleaved across the pairs: hipcc otherwise emits the dependent chains one
 // after the other (a v_pk_fma every ~8 cycles behind an s_nop), i.e. latency-bound with ILP 1
@@ -163,7 +168,7 @@ __device__ __forceinline__ void gelu_bf16x2_xn(f32x2_t (&x)[NP]) {
     for (int i = 0; i < NP; ++i) q[i] = q[i] * u[i] + c[k];
   }
 #pragma unroll
-  for (int i = 0; i < NP; ++i) x[i] = x[i] * (t[i] * q[i] + 0.5f);
+  for (int i = 0; i < NP; ++i) x[i] = x[i] * (t[i] * q[i] + SVT_GELU_HALF);
 }
 #endif
 __device__ __forceinline__ void gelu_bf16x2_x4(f32x2_t (&x)[4]) { gelu_bf16x2_xn<4>(x); }

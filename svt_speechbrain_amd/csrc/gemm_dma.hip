@@ -1348,7 +1348,8 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256) || t256 >= 1024)) {   // (large QKV, 1 500 tiles: 547 against 583 us)
     g.dbg = g_gemm_dbg == 9 ? 0 : g_gemm_dbg;
     if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
-  } else if (g.trace && kind == 3 && g.stamp_ends >= 1 && g.stamp_ends <= 4) {   // slot stamps of the one-tile kernel (diagnostics)
+#ifdef SVT_DIAG
+  } else if (g.trace && kind == 3 && g.stamp_ends >= 1 && g.stamp_ends <= 4) {   // slot stamps of the one-tile kernel (diagnostics; make DIAG=1)
 #define SVT_X3S_STAMP(NBS_, D_)                                                                                    \
   {                                                                                                                 \
     if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, NBS_, D_>, (int)lds_bytes)) return r_;           \
@@ -1379,6 +1380,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<false>, (int)lds_bytes)) return r_;
       hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
     }
+#endif
   } else if (narrow) {
     if (kind == 3) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 3>, (int)lds_bytes)) return r_;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   if (has_bias) {
     const float* bp = p.bias + ((lbase % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                 : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");
+                 : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
   }
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
 #pragma unroll
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aofE[i], gA + BK * 2, lds_unit(2, i));
   wait_vm<GA>();   // the bias loads are older than every request of the head
+  asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
   __builtin_amdgcn_s_barrier();
   if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
@@ -217,7 +218,9 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
         for (int j = 0; j < MB; ++j) asm volatile("" ::"v"(acc[i][j]));
     }
-    // the next tile starts from its bias (fetched during this tile's last slab)
+    // the next tile starts from its bias (fetched during this tile's last slab: both wave groups reach this point behind the
+    // counted wait that retired that slab, and the loads are older than every request the wait leaves in flight)
+    asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -256,8 +259,11 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       }                                                                                                             \
       if (half_ == 1 && last_k && has_bias) {                                                                       \
         const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);       \
+        /* read-write operands: the loaded value stays in the registers bq already lives in, so the join behind this conditional   \
+           block needs no copy of a register whose data has not landed yet (the compiler cannot see the counted wait that covers  \
+           these loads); the epilogue re-defines bq behind that wait before its first use */                                  \
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"                 \
-                     : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(bp) : "memory");                                            \
+                     : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");                                              \
       }                                                                                                             \
     } else {                                                                                                        \
       {                                                                                                             \
@@ -448,6 +454,10 @@ bool gemm_pps_eligible(const GemmArgs& a) {
          (a.a_rstride & 7) == 0 && (a.a_bstride & 7) == 0 && (a.ldw & 7) == 0;
 }
 
+#ifdef SVT_DIAG
+// Diagnostic build (make DIAG=1): slot-stamp instantiations, the eight-barrier form and the default store policy, for
+// tools/gemm_trace.py --slots and the A/B keys of svt_debug_set (3: 50 / 70, 15, 16).  The shipped library holds the six
+// dispatched instantiations only (sc1 stores, four barriers per slab).
 template <int STAUX>
 static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
   if constexpr (STAUX == 16) {   // slot stamps: the dispatched store policy, 256-row tiles only
@@ -487,5 +497,19 @@ int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) 
   if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
   return launch_pps_aux<0>(a, bm, s);
 }
+#else
+// The dispatched form: write-through (sc1) stores, four barriers per slab (measured against the eight-barrier form and the default
+// store policy in round 3: profiles/r03_gemm_pps_slots.txt; those and the slot-stamp instantiations are built by `make DIAG=1`).
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy*/) {
+  if (a.act == ACT_GELU) {
+    if (bm == 256) return launch_pps_t<256, ACT_GELU, 16, 0, true>(a, s);
+    if (bm == 192) return launch_pps_t<192, ACT_GELU, 16, 0, true>(a, s);
+    return launch_pps_t<128, ACT_GELU, 16, 0, true>(a, s);
+  }
+  if (bm == 256) return launch_pps_t<256, ACT_NONE, 16, 0, true>(a, s);
+  if (bm == 192) return launch_pps_t<192, ACT_NONE, 16, 0, true>(a, s);
+  return launch_pps_t<128, ACT_NONE, 16, 0, true>(a, s);
+}
+#endif
 
 }  // namespace svt

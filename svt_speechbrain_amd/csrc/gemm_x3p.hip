@@ -422,7 +422,8 @@ bool gemm_x3p_eligible(const GemmArgs& a) {
 // kind = svt_precision (2 = bf16 pieces, 3 = fp16 pieces); `packed` = the registered (hi, lo) image of the weight rows (launch_gemm_x3)
 int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t s) {
   const bool f16 = kind == 3;
-  if (a.trace && f16 && !a.planes) {   // slot stamps (diagnostics)
+#ifdef SVT_DIAG
+  if (a.trace && f16 && !a.planes) {   // slot stamps (diagnostics; make DIAG=1)
     switch (a.stamp_ends) {
       case 1: return launch_x3p_t<true, false, 1>(a, packed, s);
       case 2: return launch_x3p_t<true, false, 2>(a, packed, s);
@@ -431,6 +432,7 @@ int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t
       default: break;
     }
   }
+#endif
   if (a.planes) return f16 ? launch_x3p_t<true, true>(a, packed, s) : launch_x3p_t<false, true>(a, packed, s);
   return f16 ? launch_x3p_t<true, false>(a, packed, s) : launch_x3p_t<false, false>(a, packed, s);
 }

@@ -26,7 +26,9 @@ class Linear(ReplicaAware, nn.Module):
         self.w = nn.Linear(input_size, n_neurons, bias=bias)
         # one C object per device AND per build of the library ("" = libsvt_mi355.so, "f16" = the IEEE-half build): a handle is
         # only ever handed to the library that created it (each build has its own allocator state, registries and last_error)
-        self._devs = {"": DeviceObjects("svt_linear_destroy")}
+        # Both registries exist from the start: DataParallel replicas share this dict by reference and run `_sync` from threads, so
+        # a lazy "create the entry on first use" would let two threads each build an entry and drop one that already owns a handle.
+        self._devs = {"": DeviceObjects("svt_linear_destroy"), "f16": DeviceObjects("svt_linear_destroy", "f16")}
         self._dev = self._devs[""]
 
     def _upload_items(self):
@@ -40,7 +42,7 @@ class Linear(ReplicaAware, nn.Module):
         idx = _lib.dev_index(device)
         key = lib_variant or ""
         if key not in self._devs:
-            self._devs[key] = DeviceObjects("svt_linear_destroy", lib_variant)
+            raise _lib.SvtError(f"Linear: unknown library build {lib_variant!r}")
         slot = self._devs[key].slot(idx, (self.w.in_features, self.w.out_features, self.w.bias is not None))
         weight, bias = self._param_owner()._upload_items()
         sig = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version))
