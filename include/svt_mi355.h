@@ -218,6 +218,17 @@ int svt_debug_gemm(int32_t precision, const void* a_dev, const void* w_dev, void
                    const float* resid_dev, int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride,
                    int64_t a_rstride, int64_t ldw, int32_t act, int32_t out_f32, int device, void* stream);
 
+/* The same hook for the split-operand modes' PAIR-ROW products (csrc/gemm_x3q.hip: both operands pre-cut into 16-bit (hi, lo) pieces,
+ * 32 elements per 128-byte line): `a_dev` is the fp32 tensor (a_elems elements, a multiple of 32; rows addressed as above with strides
+ * in multiples of 32 elements), converted to pair rows inside the hook; the product runs with the pair-row operand and writes
+ * out_kind 0 = fp32 rows, 1 = pair rows, 2 = separate (hi, lo) planes -- 1 and 2 are converted back to fp32 (hi + lo) into c_dev, so
+ * the caller always compares an fp32 (M, N) result.  precision = SVT_PREC_BF16X3 / SVT_PREC_FP16X3; act 0 / 1 (exact-erf GELU). */
+int svt_debug_gemm_pairs(int32_t precision, const float* a_dev, int64_t a_elems, const float* w_dev, float* c_dev, const float* bias_dev,
+                         int32_t m, int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int32_t act,
+                         int32_t out_kind, int device, void* stream, int32_t time_iters, float* ms_out);
+/* (time_iters > 0 with ms_out: after the checked launch the product alone is launched time_iters more times between two HIP events;
+ *  *ms_out = milliseconds per launch -- tools/x3q_bench.py) */
+
 /* ---- AV-HuBERT lip front-end: replaces SubModel / ResEncoder of N20EMv2/video_only/resnet.py:134-187 (the
  * `feature_extractor_video` of the AV-HuBERT model, hubert.py:344-346): 3-D stem + ResNet-18 trunk (PReLU) + Linear(512,
  * embed_dim), eval mode.  Parameter keys are SubModel.state_dict() keys ("resnet.frontend3D.0.weight", "resnet.trunk.layer1.0.
@@ -273,7 +284,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * 9 = bf16 (1) or fp32 (0) convolution output in front of the conv-stack LayerNorm in bf16 mode, 10 = whole-head fused
  * attention kernel (K / V of a head resident in LDS; measured slower, off by default), 11 = LDS-DMA split-operand GEMM
  * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls,
- * 13 = page-guarded device allocations (see svt_debug_alloc).
+ * 13 = page-guarded device allocations (see svt_debug_alloc), 19 = split-operand modes keep product operands as pair rows written by
+ * their producers (1, default) or as fp32 cut inside the product kernels (0: the round-2/3 path, A/B).
  * Returns 0. */
 int svt_debug_set(int key, int value);
 

@@ -88,6 +88,8 @@ SYMBOLS = {
                             C.c_float, C.c_float, C.c_float, _P, _P, C.c_size_t, C.c_int, _P]),
     "svt_debug_gemm": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                  C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P]),
+    "svt_debug_gemm_pairs": (C.c_int, [C.c_int32, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                       C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32, C.POINTER(C.c_float)]),
     "svt_video_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),
     "svt_video_destroy": (None, [C.c_void_p]),
     "svt_video_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),

@@ -268,7 +268,7 @@ static int attn_tp(int prec, int dh, int T, bool bias = false) {
 static int attention_scores_path(int prec, const void* Q, long ldq, const void* K, const void* V, long ldkv, int B,
                                  int T, int H, int dh, float scale, const AttnBufs& ab, bool vt_ready, void* out,
                                  long ldo, hipStream_t s, const float* gate = nullptr, const float* relpb = nullptr,
-                                 int gp = -1) {
+                                 int gp = -1, int o_pairs = 0) {
   if (gp < 0) gp = prec;
   if (gp >= 2 && !gate && flash_attention_x3_ok(dh) && ab.pl_qkv && ldkv == 3L * H * dh &&
       (const float*)V == (const float*)K + (long)H * dh) {
@@ -289,8 +289,9 @@ static int attention_scores_path(int prec, const void* Q, long ldq, const void* 
       qp = (const unsigned short*)ab.pl_q; qld = D; qpl = rows * D;
     }
     return launch_flash_attention_x3(gp, qp, qld, (long)T * qld, qpl, p3 + D, p3 + 2 * D, 3 * D, (long)T * 3 * D, pl3, (float*)out, ldo,
-                                     (long)T * ldo, B, T, H, dh, scale, s);
+                                     (long)T * ldo, B, T, H, dh, scale, s, o_pairs);
   }
+  if (o_pairs) { set_error("attention: pair-row output is served by the fused split attention only"); return -1; }
   if (use_flash(prec, dh, gate != nullptr, T)) {
     (void)vt_ready;
     return launch_flash_attention(Q, ldq, (long)T * ldq, K, V, ldkv, (long)T * ldkv, out, ldo, (long)T * ldo, B, T, H, dh,
@@ -463,6 +464,49 @@ int svt_debug_gemm(int32_t precision, const void* a, const void* w, void* c, con
   return rc ? SVT_ERR_INVALID : SVT_OK;
 }
 
+int svt_debug_gemm_pairs(int32_t precision, const float* a, int64_t a_elems, const float* w, float* c, const float* bias, int32_t m,
+                         int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int32_t act, int32_t out_kind,
+                         int device, void* stream, int32_t time_iters, float* ms_out) {
+  if (!a || !w || !c) { set_error("svt_debug_gemm_pairs: null argument"); return SVT_ERR_INVALID; }
+  if (precision != SVT_PREC_BF16X3 && precision != SVT_PREC_FP16X3) { set_error("svt_debug_gemm_pairs: split-operand precisions only"); return SVT_ERR_INVALID; }
+  if (out_kind < 0 || out_kind > 2 || a_elems % 32 || ((int64_t)m * n) % 32) { set_error("svt_debug_gemm_pairs: out_kind / sizes"); return SVT_ERR_INVALID; }
+  SVT_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  void *ap = nullptr, *cp = nullptr;
+  if (dev_alloc(&ap, (size_t)a_elems * 4)) return SVT_ERR_HIP;
+  if (out_kind && dev_alloc(&cp, (size_t)m * n * 4)) { dev_free(ap); return SVT_ERR_HIP; }
+  int rc = launch_f32_to_pairs(precision, a, ap, a_elems, s);
+  static const void* s_kept = nullptr;
+  if (!rc && !(g_debug_keep_split && s_kept == w)) { rc = split_weights_register(w, n, k, precision, s); s_kept = w; }
+  if (!rc) {
+    GemmArgs g;
+    g.A = ap; g.W = w; g.C = out_kind == 1 ? cp : (void*)c; g.bias = bias;
+    g.M = m; g.N = n; g.K = k; g.a_rpb = a_rpb; g.a_bstride = a_bstride; g.a_rstride = a_rstride;
+    g.ldw = k; g.ldc = n; g.act = act; g.out_f32 = 1; g.a_pairs = 1; g.c_pairs = out_kind == 1;
+    if (out_kind == 2) { g.planes = (unsigned short*)cp; g.plane_stride = (long)m * n; }
+    rc = launch_gemm(precision, g, s);
+    if (!rc && time_iters > 0 && ms_out) {   // micro-benchmark: HIP events around `time_iters` more launches of the product alone
+      hipEvent_t e0, e1;
+      SVT_HIP(hipEventCreate(&e0)); SVT_HIP(hipEventCreate(&e1));
+      SVT_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < time_iters && !rc; ++i) rc = launch_gemm(precision, g, s);
+      SVT_HIP(hipEventRecord(e1, s));
+      SVT_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      SVT_HIP(hipEventElapsedTime(&ms, e0, e1));
+      *ms_out = ms / (float)time_iters;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+  }
+  if (!rc && out_kind == 1) rc = launch_pairs_to_f32(precision, cp, nullptr, c, (int64_t)m * n, s);
+  if (!rc && out_kind == 2) rc = launch_pairs_to_f32(precision, cp, (const unsigned short*)cp + (size_t)m * n, c, (int64_t)m * n, s);
+  (void)hipStreamSynchronize(s);
+  if (!g_debug_keep_split) { split_weights_forget(w); s_kept = nullptr; }
+  dev_free(ap);
+  if (cp) dev_free(cp);
+  return rc ? SVT_ERR_INVALID : SVT_OK;
+}
+
 int svt_debug_attention(int32_t precision, const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t t,
                         int32_t heads, int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, float scale, int device,
                         void* stream) {
@@ -508,6 +552,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 11) g_gemm_x3 = value;
   else if (key == 12) g_debug_keep_split = value;
   else if (key == 13) g_guard_alloc = value;
+  else if (key == 19) g_x3_pairs = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -873,7 +918,8 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.hF = (float*)cv.take(rows * D * 4);
   w.preF = (float*)cv.take(rows * D * 4);
   w.xb = cv.take(rows * D * es);
-  w.xF = sp ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
+  // split modes: xb holds the layer input as pair rows (the products' operand) and xF the fp32 residual stream beside it
+  w.xF = (sp || c.precision >= 2) ? (float*)cv.take(rows * D * 4) : (float*)w.xb;
   w.xlo = sp ? cv.take(rows * D * 2) : nullptr;  // low half of the (hi, lo) bf16 residual stream (post-LN, bf16 mode)
   {
     const int Pf = e->pos_P;
@@ -1009,6 +1055,34 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     }
   }
 
+  // ---- split modes: which products take PAIR ROWS (gemm_x3q.hip: operands cut by their producers) ----
+  // front = conv 1..n-1 and the feature projection, enc = the four products of every encoder layer; a section switches as a whole,
+  // and only when every product in it fits gemm_x3q_kernel's contract (otherwise its activations stay fp32 and the products cut them)
+  const int pk_mode = (gp >= 2 && g_x3_pairs && g_gemm_x3) ? gp : 0;
+  auto x3q_fits = [&](const void* A, int M, int N, int K, int a_rpb, long a_bstride, long a_rstride, const void* Wp, int c_pairs, long ldc) -> bool {
+    GemmArgs g;
+    g.A = A; g.W = Wp; g.C = const_cast<void*>(A); g.M = M; g.N = N; g.K = K; g.a_rpb = a_rpb; g.a_bstride = a_bstride; g.a_rstride = a_rstride;
+    g.ldw = K; g.ldc = ldc; g.a_pairs = 1; g.c_pairs = c_pairs;
+    return gemm_x3q_eligible(g);
+  };
+  bool pk_front_ok = pk_mode != 0 && c.num_conv_layers >= 2 && c.conv_dim[0] % 32 == 0 && c.conv_dim[0] <= 512 && c.conv_stride[0] <= 5;
+  if (pk_front_ok) {
+    int64_t ti_ = (L - c.conv_kernel[0]) / c.conv_stride[0] + 1;
+    for (int i = 1; i < c.num_conv_layers && pk_front_ok; ++i) {
+      const int cin = c.conv_dim[i - 1], co = c.conv_dim[i], k = c.conv_kernel[i], st = c.conv_stride[i];
+      const int64_t to_ = (ti_ - k) / st + 1;
+      if ((int64_t)B * to_ > 2147483647LL) { pk_front_ok = false; break; }
+      pk_front_ok = x3q_fits(w.act[0], (int)((int64_t)B * to_), co, k * cin, (int)to_, ti_ * cin, (long)st * cin, e->conv[i].w.p, 1, co) &&
+                    (c.feat_extract_norm != SVT_NORM_LAYER || co == 512 || co == 768 || co == 1024);
+      ti_ = to_;
+    }
+    const int Cl = c.conv_dim[c.num_conv_layers - 1];
+    const int64_t rows_ = (int64_t)B * T;
+    pk_front_ok = pk_front_ok && x3q_fits(w.xln, (int)rows_, c.hidden_size, Cl, (int)rows_, 0, Cl, e->proj_w.p, 0, c.hidden_size) &&
+                  (!c.feat_proj_layer_norm || Cl == 512 || Cl == 768 || Cl == 1024);
+  }
+  const int pk_front = pk_front_ok ? pk_mode : 0;
+
   // ---- conv feature extractor (channels-last activations) ----
   int64_t tin = L;
   int cur = 0;
@@ -1026,11 +1100,11 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
                                         c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
                                         c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s, cpg)) return r;
     if (int r = launch_conv0_group_apply(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], w.coef,
-                                         w.act[0], s)) return r;
+                                         w.act[0], s, pk_front)) return r;
   } else {
     if (int r = launch_conv0_layer(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], wav_mom, n_wav,
                                    1e-5f, c0.w.as<float>(), c.conv_bias ? c0.bias.as<float>() : nullptr,
-                                   c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s, cpg)) return r;
+                                   c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s, cpg, pk_front)) return r;
   }
   tin = t1;
   }
@@ -1045,6 +1119,19 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     g.ldw = g.K; g.ldc = co;
     g.bias = c.conv_bias ? Lw.bias.as<float>() : nullptr;
     if ((int64_t)B * tout > 2147483647LL) { set_error("encoder_forward: batch*frames exceeds 2^31"); return SVT_ERR_INVALID; }
+    // pair rows: this layer reads them; it writes them too unless the feature projection's LayerNorm (an fp32 reader) comes next
+    g.a_pairs = pk_front ? 1 : 0;
+    const bool pairs_out = pk_front && !(i + 1 == c.num_conv_layers && c.feat_proj_layer_norm);
+    if (pk_front && c.feat_extract_norm == SVT_NORM_LAYER) {
+      g.C = w.convF; g.out_f32 = 1; g.act = ACT_NONE;
+      if (int r = launch_gemm(gp, g, s)) return r;
+      if (int r = launch_layernorm(prec, w.convF, 1, (int64_t)B * tout, co, Lw.gamma.as<float>(), Lw.beta.as<float>(), 1e-5f, 1,
+                                   pairs_out ? nullptr : w.act[cur ^ 1], nullptr, s, nullptr, nullptr, pairs_out ? w.act[cur ^ 1] : nullptr,
+                                   pk_front)) return r;
+    } else if (pk_front) {
+      g.C = w.act[cur ^ 1]; g.act = ACT_GELU; g.out_f32 = 1; g.c_pairs = pairs_out ? 1 : 0;
+      if (int r = launch_gemm(gp, g, s)) return r;
+    } else
     if (c.feat_extract_norm == SVT_NORM_LAYER && prec && co == 512 && g_conv_ln_bf16) {
       // throughput mode: the conv output goes to HBM once, in the operand type, and is normalised in place (a wave owns a
       // row: it reads all of it before it writes) -- the fp32 round trip below moves 3x the bytes (conv1 at 64 x 10 s:
@@ -1074,13 +1161,14 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   const void* proj_in = w.act[cur];
   if (c.feat_proj_layer_norm) {
     if (int r = launch_layernorm(prec, w.act[cur], prec ? 0 : 1, rows, C, e->fp_g.as<float>(), e->fp_b.as<float>(), eps, 0,
-                                 w.xln, nullptr, s)) return r;
+                                 pk_front ? nullptr : w.xln, nullptr, s, nullptr, nullptr, pk_front ? w.xln : nullptr, pk_front)) return r;
     proj_in = w.xln;
   }
   {
     GemmArgs g;
     g.A = proj_in; g.W = e->proj_w.p; g.C = w.hF; g.bias = e->proj_b.as<float>();
     g.M = (int)rows; g.N = D; g.K = C; g.a_rpb = (int)rows; g.a_rstride = C; g.ldw = C; g.ldc = D; g.out_f32 = 1;
+    g.a_pairs = pk_front ? 1 : 0;
     if (int r = launch_gemm(gp, g, s)) return r;
   }
   // ---- positional conv embedding: pre = h + gelu(grouped_conv(h) + b) ----
@@ -1145,6 +1233,15 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   // split-operand modes with the fused attention: the QKV projection's epilogue writes the planes the attention reads
   const bool qkv_planes = gp >= 2 && !c.rel_pos_buckets && flash_attention_x3_ok(dh) && w.ab.pl_qkv != nullptr;
   unsigned short* const qkv_pl = qkv_planes ? (unsigned short*)w.ab.pl_qkv : nullptr;
+  // encoder layers on pair rows: the layer input (LayerNorm output), the attention output and the FFN intermediate are written as
+  // pair rows by their producers; the residual stream stays fp32 beside them (w.xF)
+  const bool pk_enc_ok = pk_mode != 0 && qkv_planes && c.num_layers > 0 && (D == 512 || D == 768 || D == 1024) && dh % 32 == 0 &&
+                         x3q_fits(w.xb, (int)rows, 3 * D, D, (int)rows, 0, D, e->layers[0].wqkv.p, 0, 3 * D) &&
+                         x3q_fits(w.attn_o, (int)rows, D, D, (int)rows, 0, D, e->layers[0].wo.p, 0, D) &&
+                         x3q_fits(w.xb, (int)rows, F, D, (int)rows, 0, D, e->layers[0].w1.p, 1, F) &&
+                         x3q_fits(w.ffn, (int)rows, D, F, (int)rows, 0, F, e->layers[0].w2.p, 0, D);
+  const int pk_enc = pk_enc_ok ? pk_mode : 0;
+  if (!prec && !pk_enc) w.xF = (float*)w.xb;   // fp32 storage without pair rows: the layer input IS the residual stream (one buffer)
   int cur_layer = 0;
   auto attention = [&](void) -> int {
     const float* gate = nullptr;
@@ -1158,16 +1255,17 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     ++cur_layer;
     return attention_scores_path(prec, w.qkv, 3L * D, (const char*)w.qkv + (size_t)D * esize(prec),
                                  (const char*)w.qkv + (size_t)2 * D * esize(prec), 3L * D, B, (int)T, H, dh, scale, w.ab,
-                                 qkv_planes, w.attn_o, D, s, gate, w.relpb, gp);
+                                 qkv_planes, w.attn_o, D, s, gate, w.relpb, gp, pk_enc ? 1 : 0);
   };
   // planes: the product additionally / instead leaves as 16-bit (hi, lo) planes for the fused split attention (QKV projection)
   auto gemm_rows = [&](const void* A, int K, const DevBuf& W, const DevBuf& bias, int N, void* Cout, int out_f32, int act,
-                       const float* resid, unsigned short* planes = nullptr) -> int {
+                       const float* resid, unsigned short* planes = nullptr, int c_pairs = 0) -> int {
     GemmArgs g;
     g.A = A; g.W = W.p; g.C = Cout; g.bias = bias.as<float>(); g.resid = resid;
     g.M = (int)rows; g.N = N; g.K = K; g.a_rpb = (int)rows; g.a_rstride = K; g.ldw = K; g.ldc = N;
     g.out_f32 = out_f32; g.act = act;
     g.planes = planes; g.plane_stride = (long)rows * N;
+    g.a_pairs = pk_enc ? 1 : 0; g.c_pairs = c_pairs;
     return launch_gemm(gp, g, s);
   };
 
@@ -1204,6 +1302,23 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
                                         xh, xl, last ? w.xF : nullptr, s)) return r;
     }
     final_x = w.xF;
+  } else if (!c.stable_layer_norm && pk_enc) {
+    // split modes on pair rows: LN -> (fp32 residual w.xF, pair rows w.xb); the four products read pair rows
+    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, w.xF, s, nullptr,
+                                 nullptr, w.xb, pk_enc)) return r;
+    for (int l = 0; l < c.num_layers; ++l) {
+      const EncLayerW& Lw = e->layers[l];
+      if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
+      if (int r = attention()) return r;
+      if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, nullptr, w.xF, s, w.xF,
+                                   nullptr, w.xb, pk_enc)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 1, ACT_GELU, nullptr, nullptr, 1)) return r;
+      if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, nullptr, w.xF, s, w.xF,
+                                   nullptr, w.xb, pk_enc)) return r;
+    }
+    final_x = w.xF;
   } else if (!c.stable_layer_norm) {
     if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, w.xb,
                                  prec ? w.xF : nullptr, s)) return r;
@@ -1226,6 +1341,8 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     // branch outputs in the operand type in throughput mode (bf16: half the GEMM store burst and 2 of the 14 bytes per
     // element the LayerNorm moves); the fp32 residual stream h is updated in place by the LayerNorm kernel (sumF)
     auto ln_add = [&](const float* g_, const float* b_, const void* branch, void* y_op, float* y_f32) -> int {
+      if (pk_enc && y_op)   // pair rows for the products; h (fp32) += branch in place
+        return launch_layernorm(prec, h, 1, rows, D, g_, b_, eps, 0, nullptr, nullptr, s, (const float*)branch, branch ? h : nullptr, y_op, pk_enc);
       if (!branch) return launch_layernorm(prec, h, 1, rows, D, g_, b_, eps, 0, y_op, y_f32, s, nullptr, nullptr);
       if (!tmp_f32)  // x = bf16 branch, add = fp32 residual, sumF = residual updated in place
         return launch_layernorm(prec, branch, 0, rows, D, g_, b_, eps, 0, y_op, y_f32, s, h, y_op ? h : nullptr);
@@ -1239,7 +1356,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
       if (int r = attention()) return r;
       if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
       if (int r = ln_add(Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), tmp, w.xb, nullptr)) return r;
-      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
+      if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr, nullptr, pk_enc ? 1 : 0)) return r;
       if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, tmp_f32, ACT_NONE, nullptr)) return r;
       pending = tmp;
     }

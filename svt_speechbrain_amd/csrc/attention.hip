@@ -324,7 +324,7 @@ template <int DH, bool F16, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void flash_attn_x3_kernel(const unsigned short* __restrict__ Q, long ldq, long q_bstride, long q_plane,
                                                             const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
                                                             long ldk, long k_bstride, long k_plane, float* __restrict__ O, long ldo,
-                                                            long o_bstride, int T, int H, float c) {
+                                                            long o_bstride, int T, int H, float c, int o_pairs) {
   typedef X3T<F16> X;
   typedef typename X::v8 v8;
   constexpr int KSD = DH / 16, DB = DH / 32, CPR = DH / 8, RB = 2 * DH;
@@ -496,6 +496,23 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_x3_kernel(const unsigned s
   if (q >= T) return;
   const float inv = 1.f / l;
   float* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+  if (o_pairs) {
+    // the output projection's operand as pair rows (gemm_x3q.hip): [32 hi | 32 lo] per 32 elements, in the bytes of the fp32 slab
+    // (ldo, o_bstride and h * DH are multiples of 32 elements: the launcher checks)
+    char* pp = (char*)op;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        unsigned short ph_[4], pl_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X::cut(o[db][g * 4 + j] * inv, ph_[j], pl_[j]);
+        char* d = pp + db * 128 + (8 * g + 4 * hh) * 2;
+        *(uint2*)d = uint2{(unsigned)ph_[0] | ((unsigned)ph_[1] << 16), (unsigned)ph_[2] | ((unsigned)ph_[3] << 16)};
+        *(uint2*)(d + 64) = uint2{(unsigned)pl_[0] | ((unsigned)pl_[1] << 16), (unsigned)pl_[2] | ((unsigned)pl_[3] << 16)};
+      }
+    return;
+  }
 #pragma unroll
   for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -541,8 +558,9 @@ bool flash_attention_x3_ok(int dh) { return dh == 64 || dh == 128; }
 // Q / K / V: 16-bit (hi, lo) planes (launch_split_planes); O fp32
 int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride, long q_plane, const void* K, const void* V, long ldk,
                               long k_bstride, long k_plane, float* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale,
-                              hipStream_t s) {
+                              hipStream_t s, int o_pairs) {
   if ((ldq | ldk | q_bstride | k_bstride | q_plane | k_plane) % 8 || (ldo | o_bstride) % 4) { set_error("flash_attention_x3: strides"); return -1; }
+  if (o_pairs && ((ldo | o_bstride | dh) % 32 || ((uintptr_t)O & 127))) { set_error("flash_attention_x3: pair-row output needs strides in multiples of 32 elements"); return -1; }
   const float c = scale * 1.44269504088896340736f;
   dim3 grid((T + 127) / 128, H, B);
   const bool wide = dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512;
@@ -550,7 +568,7 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   const double flops = 4.0 * B * H * (double)T * T * dh;
   const unsigned short *q = (const unsigned short*)Q, *k = (const unsigned short*)K, *v = (const unsigned short*)V;
   prof_begin(s);
-#define SVT_X3_LAUNCH(DH_, F16_, NW_) hipLaunchKernelGGL((flash_attn_x3_kernel<DH_, F16_, NW_>), grid, dim3(64 * NW_), 0, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O, ldo, o_bstride, T, H, c)
+#define SVT_X3_LAUNCH(DH_, F16_, NW_) hipLaunchKernelGGL((flash_attn_x3_kernel<DH_, F16_, NW_>), grid, dim3(64 * NW_), 0, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O, ldo, o_bstride, T, H, c, o_pairs)
   if (dh == 64 && wide) { if (kind == 3) SVT_X3_LAUNCH(64, true, 8); else SVT_X3_LAUNCH(64, false, 8); }
   else if (dh == 64) { if (kind == 3) SVT_X3_LAUNCH(64, true, 4); else SVT_X3_LAUNCH(64, false, 4); }
   else if (dh == 128) { if (kind == 3) SVT_X3_LAUNCH(128, true, 4); else SVT_X3_LAUNCH(128, false, 4); }

@@ -226,6 +226,10 @@ struct GemmArgs {
   unsigned short* planes = nullptr;
   long plane_stride = 0;
   int planes_f16 = 0;          // piece type: 1 = IEEE half, 0 = bf16
+  // split-operand modes, "pair rows": every 32 consecutive elements of a row stored as [32 hi pieces | 32 lo pieces] (16-bit), i.e. in
+  // the 128 bytes of the fp32 slab they replace -- element strides / offsets are those of the fp32 tensor (multiples of 32 elements).
+  int a_pairs = 0;             // A holds pair rows (written by a producer kernel): served by gemm_x3q_kernel only
+  int c_pairs = 0;             // C is written as pair rows (the next product's operand) instead of fp32
   int stamp_ends = 0;           // diagnostics (gemm_pps_kernel slot stamps): 0 = slot starts, 1 = slot ends
   long long* trace = nullptr;  // diagnostics (dbg == 9): per-workgroup phase clock stamps, 16 x int64 per workgroup
 };
@@ -250,6 +254,10 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s);  // 0 = launched
 // persistent staggered form of the LDS-DMA split kernel (gemm_x3p.hip); `packed` = the registered (hi, lo) image of the weight rows
 bool gemm_x3p_eligible(const GemmArgs& a);
 int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t s);
+// both operands pre-cut (pair rows): the schedule of gemm_pps_kernel with three MFMAs per block (gemm_x3q.hip)
+bool gemm_x3q_eligible(const GemmArgs& a);
+int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);
+extern int g_x3_pairs;  // 1 (default): the split modes keep product operands as pair rows; 0: fp32 activations cut inside the product kernels (svt_debug_set key 19)
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
@@ -278,6 +286,9 @@ void prof_end(hipStream_t s, double flops, double bytes, int kind = 1);
 
 // ---- elementwise / reduction kernels (kernels.hip) ----
 int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// fp32 <-> pair rows (GemmArgs::a_pairs); lo_plane != nullptr: `in` / `lo_plane` are separate (hi, lo) planes instead
+int launch_f32_to_pairs(int kind, const float* x, void* out, int64_t n, hipStream_t s);
+int launch_pairs_to_f32(int kind, const void* in, const void* lo_plane, float* y, int64_t n, hipStream_t s);
 // moments[0] += sum(x), moments[1] += sum(x^2) over n fp32 values (fp64 accumulation); caller zeroes moments
 int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
 // y = (x - mean) * rsqrt(var + eps) from global moments over n elements (no affine)
@@ -289,7 +300,8 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 // `sumF` (optional) receives x + add (the updated residual stream of the pre-LN encoder)
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s,
-                     const float* add = nullptr, float* sumF = nullptr);
+                     const float* add = nullptr, float* sumF = nullptr,
+                     void* yP = nullptr, int pair_kind = 0);   // yP: the result as pair rows (split modes; kind 2 = bf16 / 3 = fp16 pieces)
 
 // conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
 int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,
@@ -299,11 +311,12 @@ int launch_conv0_group_coef(const double* wav_moments /*2, or null*/, int64_t n_
                             const float* gamma, const float* beta, float eps_wav, float eps_gn,
                             float* coef /*B x C x (k+1)*/, hipStream_t s, int clips_per_norm_group);  // wav_moments: 2 per group
 int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
-                             const float* coef, void* out /*B x T1 x C*/, hipStream_t s);
+                             const float* coef, void* out /*B x T1 x C*/, hipStream_t s, int pair_kind = 0);   // pair_kind 2 / 3: out as pair rows
 // conv layer 0 in "layer" mode: conv + bias + LayerNorm over channels + GELU
 int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
                        const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
-                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int clips_per_norm_group);
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int clips_per_norm_group,
+                       int pair_kind = 0);
 
 // positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front
 int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s,
@@ -329,7 +342,7 @@ int launch_split_planes(int kind, const float* src, long ld_src, long rows, int 
 bool flash_attention_x3_ok(int dh);
 int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride, long q_plane, const void* K, const void* V, long ldk,
                               long k_bstride, long k_plane, float* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale,
-                              hipStream_t s);
+                              hipStream_t s, int o_pairs = 0);   // o_pairs: O written as pair rows (the output projection's operand)
 // out = a*x + b*y (fp32 or operand type)
 int launch_axpby(int prec, const void* x, const void* y, float a, float b, void* out, int64_t n, hipStream_t s);
 // RCA: s = x + pe[t] (x f32 (B,T,D); x2 may be shorter in T: rows >= T2 read as zero) -> fp32 + operand type

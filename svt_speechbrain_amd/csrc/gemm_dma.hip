@@ -1296,7 +1296,43 @@ void split_weights_forget(const void* w_f32) {
 }
 // launches the LDS-DMA split kernel when `a` is a plain (un-batched) product against a registered weight matrix; returns
 // 1 when the caller has to use the register-staged split kernel instead, 0 on success, < 0 on error
+int g_x3_pairs = 1;
 int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
+  if (a.a_pairs) {
+    // pair-row operand: only gemm_x3q_kernel reads it (the callers in api.hip ask gemm_x3q_eligible before they choose the layout)
+    if (!gemm_x3q_eligible(a) || a.ldw != a.K) { set_error("gemm: pair-row operand outside the contract of gemm_x3q_kernel"); return -1; }
+    const void* packed = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_split_mu);
+      auto it = g_split_w.upper_bound(a.W);
+      if (it != g_split_w.begin()) {
+        --it;
+        const size_t off = (const char*)a.W - (const char*)it->first;
+        if (it->second.kind == kind && it->second.K == a.K && off % ((size_t)a.K * 4) == 0 && off / ((size_t)a.K * 4) + a.N <= (size_t)it->second.N)
+          packed = (const char*)it->second.packed + off;
+      }
+    }
+    if (!packed) { set_error("gemm: pair-row product against a weight matrix that was not registered as split"); return -1; }
+    // tile height: rounds of 256 CUs x measured slab time of that height (the table of launch_gemm_dma)
+    const int cands[3] = {256, 192, 128};
+    const int slab_cost[3] = {167, 137, 105};
+    long best_cost = -1;
+    int best = 256;
+    for (int i = 0; i < 3; ++i) {
+      const long blocks = (long)((a.M + cands[i] - 1) / cands[i]) * (a.N / 256);
+      const long cost = ((blocks + 255) / 256) * slab_cost[i];
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[i]; }
+    }
+    if (g_gemm_force_bm == 256 || g_gemm_force_bm == 192 || g_gemm_force_bm == 128) best = g_gemm_force_bm;
+    GemmArgs g = a;
+    g.planes_f16 = kind == 3;
+    const double flops = 2.0 * a.M * (double)a.N * a.K;
+    const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
+    prof_begin(s);
+    if (int r_ = launch_gemm_x3q(kind, g, packed, best, s)) return r_;
+    prof_end(s, flops, bytes, 0);
+    return 0;
+  }
   if (a.gen || a.nz != 1 || a.K % 32 || a.N < 128 || a.M < 128 || !a.c_vec || a.ldw != a.K || a.alpha != 1.f || a.w_z1 || a.w_z2 ||
       a.a_z1 || a.a_z2 || a.c_z1 || a.c_z2 || (a.a_rstride & 3) || (a.a_bstride & 3) || ((uintptr_t)a.A & 15))
     return 1;

@@ -27,6 +27,34 @@ template <typename T> __device__ __forceinline__ void st(T* p, long i, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, long i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, long i, float v) { p[i] = (bf16_t)v; }
 
+// ---- "pair rows" of the split-operand modes (GemmArgs::a_pairs): every 32 consecutive elements of a row are stored as
+// [32 hi pieces | 32 lo pieces] (16-bit, IEEE half for kind 3 / bf16 for kind 2) in the 128 bytes of the fp32 slab they replace, so
+// element offsets are those of the fp32 tensor.  PK = 0: no pair output, 2 = bf16 pieces, 3 = fp16 pieces (= svt_precision).
+template <int PK> __device__ __forceinline__ void cut_piece(float x, unsigned short& hi, unsigned short& lo) {
+  if constexpr (PK == 3) {
+    const _Float16 a = (_Float16)x, b = (_Float16)(x - (float)a);
+    hi = __builtin_bit_cast(unsigned short, a); lo = __builtin_bit_cast(unsigned short, b);
+  } else {
+    const __bf16 a = (__bf16)x, b = (__bf16)(x - (float)a);
+    hi = __builtin_bit_cast(unsigned short, a); lo = __builtin_bit_cast(unsigned short, b);
+  }
+}
+// N (4 or 8) consecutive elements starting at element index e (a multiple of N) of a pair-row tensor whose fp32 image starts at `base`
+template <int PK, int N> __device__ __forceinline__ void store_pairs(void* base, int64_t e, const float (&v)[N]) {
+  static_assert(N == 4 || N == 8, "pieces of 4 or 8 elements");
+  unsigned short h[N], l[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) cut_piece<PK>(v[i], h[i], l[i]);
+  char* d = (char*)base + (e >> 5) * 128 + (e & 31) * 2;
+  if constexpr (N == 8) {
+    *(uint4*)d = uint4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+    *(uint4*)(d + 64) = uint4{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16), (unsigned)l[4] | ((unsigned)l[5] << 16), (unsigned)l[6] | ((unsigned)l[7] << 16)};
+  } else {
+    *(uint2*)d = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    *(uint2*)(d + 64) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,10 +145,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const float
 
 // Register-resident variant for D = 64*VPT (512 / 768 / 1024): the row is read ONCE with 16-byte loads
 // (fp32 in) and kept in VPT registers per lane; statistics by two in-register passes + wave shuffles.
-template <int VPT, typename TO, typename TI = float>
+// PK != 0: additionally (or only) writes the result as pair rows into yP (the next split-operand product's operand)
+template <int VPT, typename TO, typename TI = float, int PK = 0>
 __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const TI* x, const float* add, float* sumF,
                                                                 int64_t rows, const float* gamma, const float* beta,
-                                                                float eps, int gelu, TO* yT, float* yF) {
+                                                                float eps, int gelu, TO* yT, float* yF, void* yP = nullptr) {
   constexpr int D = 64 * VPT, NV = VPT / 4;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -166,6 +195,10 @@ __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const TI* x, con
       }
     }
     if (yF) *(float4*)(yF + row * D + c) = float4{o0, o1, o2, o3};
+    if constexpr (PK != 0) {
+      const float ov[4] = {o0, o1, o2, o3};
+      store_pairs<PK, 4>(yP, row * D + c, ov);
+    }
   }
 }
 
@@ -338,7 +371,7 @@ __global__ void conv0_group_coef_kernel(const double* wav_mom, int64_t n_wav, co
 
 // out[b,t,c] = gelu( sum_j coef[b,c,j] * wav[b, t*stride + j] + coef[b,c,K0] ), channels-last.
 // One wave writes whole (b,t) rows: lane = 8 consecutive channels -> 16 B (bf16) / 32 B (fp32) per lane.
-template <typename TO>
+template <typename TO, int PK = 0>   // PK != 0 (TO = float): the output is written as pair rows
 __global__ __launch_bounds__(256) void conv0_group_apply_kernel(const float* wav, int64_t L, int stride, int64_t T1,
                                                                 int C, const float* coef, TO* out) {
   constexpr int FPW = 32;  // frames per wave
@@ -386,7 +419,9 @@ __global__ __launch_bounds__(256) void conv0_group_apply_kernel(const float* wav
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[2 * i] = a4[i].x; o[2 * i + 1] = a4[i].y; }
     TO* dst = out + ((int64_t)b * T1 + t0 + f) * C + c0;
-    if constexpr (sizeof(TO) == 2) {
+    if constexpr (PK != 0) {
+      store_pairs<PK, 8>(out, ((int64_t)b * T1 + t0 + f) * C + c0, o);
+    } else if constexpr (sizeof(TO) == 2) {
       bf16x8 v;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
@@ -399,7 +434,7 @@ __global__ __launch_bounds__(256) void conv0_group_apply_kernel(const float* wav
 }
 
 // conv layer 0, "layer" mode: conv (+bias) -> LayerNorm over C -> GELU, one wave per frame.
-template <typename TO>
+template <typename TO, int PK = 0>
 __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int64_t L, int stride, int64_t T1, int C,
                                                           const double* wav_mom, int64_t n_wav, float eps_wav,
                                                           const float* w0, const float* b0, const float* gamma,
@@ -488,7 +523,9 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(const float* wav, int6
         for (int i = 0; i < 8; ++i) o[i] = gelu_erf((y[u][i] - mean[u]) * rstd[u] * g[i] + be[i]);
       }
       TO* dst = out + ((int64_t)b * T1 + t0 + fr[u]) * C + c0;
-      if constexpr (sizeof(TO) == 2) {
+      if constexpr (PK != 0) {
+        store_pairs<PK, 8>(out, ((int64_t)b * T1 + t0 + fr[u]) * C + c0, o);
+      } else if constexpr (sizeof(TO) == 2) {
         bf16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
@@ -1213,6 +1250,36 @@ __global__ __launch_bounds__(256) void fbank_db_kernel(float* fb, int64_t per_se
   for (int64_t i = threadIdx.x; i < per_seq; i += blockDim.x) x[i] = fmaxf(x[i], floor_db);
 }
 
+// fp32 <-> pair rows (test / debug hooks and re-layouts outside the hot path): one thread per 8 consecutive elements
+template <int PK>
+__global__ void f32_to_pairs_kernel(const float* __restrict__ x, void* __restrict__ out, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  store_pairs<PK, 8>(out, i * 8, v);
+}
+template <int PK>
+__global__ void pairs_to_f32_kernel(const void* __restrict__ in, float* __restrict__ y, int64_t n8, const void* lo_plane) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int64_t e = i * 8;
+  // lo_plane == nullptr: pair rows; else `in` / `lo_plane` are separate (hi, lo) planes with the element layout of y
+  const char* ph = lo_plane ? (const char*)in + e * 2 : (const char*)in + (e >> 5) * 128 + (e & 31) * 2;
+  const char* pl = lo_plane ? (const char*)lo_plane + e * 2 : ph + 64;
+  const uint4 h = *(const uint4*)ph, l = *(const uint4*)pl;
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned short hs = (unsigned short)(hw[j >> 1] >> (16 * (j & 1))), ls = (unsigned short)(lw[j >> 1] >> (16 * (j & 1)));
+    if constexpr (PK == 3) o[j] = (float)__builtin_bit_cast(_Float16, hs) + (float)__builtin_bit_cast(_Float16, ls);
+    else o[j] = (float)__builtin_bit_cast(__bf16, hs) + (float)__builtin_bit_cast(__bf16, ls);
+  }
+  ((float4*)y)[2 * i] = float4{o[0], o[1], o[2], o[3]};
+  ((float4*)y)[2 * i + 1] = float4{o[4], o[5], o[6], o[7]};
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
   int64_t g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -1223,6 +1290,23 @@ inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
 }  // namespace
 
 // ================================================================================================
+int launch_f32_to_pairs(int kind, const float* x, void* out, int64_t n, hipStream_t s) {
+  if (n % 32 || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || (kind != 2 && kind != 3)) { set_error("f32_to_pairs: n % 32, alignment or kind"); return -1; }
+  const int64_t n8 = n / 8;
+  if (kind == 3) hipLaunchKernelGGL((f32_to_pairs_kernel<3>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, out, n8);
+  else hipLaunchKernelGGL((f32_to_pairs_kernel<2>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, out, n8);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_pairs_to_f32(int kind, const void* in, const void* lo_plane, float* y, int64_t n, hipStream_t s) {
+  if (n % 32 || ((uintptr_t)y & 15) || ((uintptr_t)in & 15) || ((uintptr_t)lo_plane & 15) || (kind != 2 && kind != 3)) { set_error("pairs_to_f32: n % 32, alignment or kind"); return -1; }
+  const int64_t n8 = n / 8;
+  if (kind == 3) hipLaunchKernelGGL((pairs_to_f32_kernel<3>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, y, n8, lo_plane);
+  else hipLaunchKernelGGL((pairs_to_f32_kernel<2>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, y, n8, lo_plane);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
   SVT_LAUNCH_CHECK();
@@ -1247,7 +1331,32 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s, const float* add,
-                     float* sumF) {
+                     float* sumF, void* yP, int pair_kind) {
+  if (yP) {
+    // split-operand modes: the result leaves as pair rows (and optionally as fp32: yF / sumF) -- fp32 input, D in {512, 768, 1024}
+    if (prec || !x_is_f32 || yT || !(D == 512 || D == 768 || D == 1024) || (pair_kind != 2 && pair_kind != 3) || ((uintptr_t)x & 15) ||
+        ((uintptr_t)yF & 15) || ((uintptr_t)add & 15) || ((uintptr_t)sumF & 15) || ((uintptr_t)yP & 127) || ((uintptr_t)gamma & 15) ||
+        ((uintptr_t)beta & 15)) {
+      set_error("layernorm: the pair-row output needs an fp32 input, D in {512, 768, 1024} and aligned buffers");
+      return -1;
+    }
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define SVT_LN_PAIRS(VPT)                                                                                                  \
+  do {                                                                                                                     \
+    if (pair_kind == 3)                                                                                                    \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, float, float, 3>), grid, block, 0, s, (const float*)x, add, sumF, rows, gamma, \
+                         beta, eps, gelu, (float*)nullptr, yF, yP);                                                        \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((layernorm_f32_vec_kernel<VPT, float, float, 2>), grid, block, 0, s, (const float*)x, add, sumF, rows, gamma, \
+                         beta, eps, gelu, (float*)nullptr, yF, yP);                                                        \
+  } while (0)
+    if (D == 512) SVT_LN_PAIRS(8);
+    else if (D == 768) SVT_LN_PAIRS(12);
+    else SVT_LN_PAIRS(16);
+#undef SVT_LN_PAIRS
+    SVT_LAUNCH_CHECK();
+    return 0;
+  }
   if (prec && !x_is_f32 && (D == 512 || D == 768 || D == 1024) && !((uintptr_t)x & 7) && !((uintptr_t)yT & 15) &&
       !((uintptr_t)yF & 15) && !((uintptr_t)add & 15) && !((uintptr_t)sumF & 15)) {
     // bf16 branch output + fp32 residual (throughput mode)
@@ -1339,10 +1448,14 @@ int launch_conv0_group_coef(const double* wav_moments, int64_t n_wav, const doub
 }
 
 int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
-                             const float* coef, void* out, hipStream_t s) {
+                             const float* coef, void* out, hipStream_t s, int pair_kind) {
   if (k != K0 || stride > 5 || C > 512 || C % 8) { set_error("conv0: unsupported geometry"); return -1; }
   dim3 grid((unsigned)((T1 + 127) / 128), B);
-  if (prec)
+  if (pair_kind) {
+    if (prec || C % 32 || ((uintptr_t)out & 127) || (pair_kind != 2 && pair_kind != 3)) { set_error("conv0: pair-row output needs fp32 storage and C % 32 == 0"); return -1; }
+    if (pair_kind == 3) hipLaunchKernelGGL((conv0_group_apply_kernel<float, 3>), grid, dim3(256), 0, s, wav, L, stride, T1, C, coef, (float*)out);
+    else hipLaunchKernelGGL((conv0_group_apply_kernel<float, 2>), grid, dim3(256), 0, s, wav, L, stride, T1, C, coef, (float*)out);
+  } else if (prec)
     hipLaunchKernelGGL((conv0_group_apply_kernel<bf16_t>), grid, dim3(256), 0, s, wav, L, stride, T1, C, coef,
                        (bf16_t*)out);
   else
@@ -1354,10 +1467,16 @@ int launch_conv0_group_apply(int prec, const float* wav, int B, int64_t L, int k
 
 int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int stride, int64_t T1, int C,
                        const double* wav_moments, int64_t n_wav, float eps_wav, const float* w0, const float* b0,
-                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int cpg) {
+                       const float* gamma, const float* beta, float eps, void* out, hipStream_t s, int cpg, int pair_kind) {
   if (k != K0 || C > 512 || C % 8) { set_error("conv0: unsupported geometry"); return -1; }
   dim3 grid((unsigned)((T1 + 63) / 64), B);
-  if (prec)
+  if (pair_kind) {
+    if (prec || C % 32 || ((uintptr_t)out & 127) || (pair_kind != 2 && pair_kind != 3)) { set_error("conv0: pair-row output needs fp32 storage and C % 32 == 0"); return -1; }
+    if (pair_kind == 3)
+      hipLaunchKernelGGL((conv0_layer_kernel<float, 3>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav, eps_wav, w0, b0, gamma, beta, eps, (float*)out, cpg);
+    else
+      hipLaunchKernelGGL((conv0_layer_kernel<float, 2>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav, eps_wav, w0, b0, gamma, beta, eps, (float*)out, cpg);
+  } else if (prec)
     hipLaunchKernelGGL((conv0_layer_kernel<bf16_t>), grid, dim3(256), 0, s, wav, L, stride, T1, C, wav_moments, n_wav,
                        eps_wav, w0, b0, gamma, beta, eps, (bf16_t*)out, cpg);
   else

@@ -177,6 +177,74 @@ def test_split_operand_persistent_kernel(variant, name, prec, M, N, K, conv, act
     assert err < {2: 3e-5, 3: 4e-6}[prec] * max(1.0, (K / 768) ** 0.5), (name, variant, err)
 
 
+def run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=True, seed=0):
+    """gemm_x3q_kernel through svt_debug_gemm_pairs: the fp32 A is converted to pair rows inside the hook, the result comes back as fp32."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(seed)
+    if conv:
+        T_in, T_out, st, cin = conv
+        B = M // T_out
+        A = (torch.rand(B, T_in, cin, generator=g) * 2 - 1).to(DEV)
+        rpb, bstr, rstr = T_out, T_in * cin, st * cin
+        k = K // cin
+        idx = (torch.arange(T_out) * st)[:, None] + torch.arange(k)[None, :]
+        A_rows = A.cpu()[:, idx].reshape(M, K)
+    else:
+        A = (torch.rand(M, K, generator=g) * 2 - 1).to(DEV)
+        rpb, bstr, rstr = M, 0, K
+        A_rows = A.cpu()
+    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    C = torch.full((M, N), float("nan"), device=DEV)
+    _lib.check(lib.svt_debug_gemm_pairs(prec, A.data_ptr(), A.numel(), W.data_ptr(), C.data_ptr(), b.data_ptr() if bias else None, M, N, K,
+                                        rpb, bstr, rstr, act, out_kind, 0, torch.cuda.current_stream().cuda_stream, 0, None), "svt_debug_gemm_pairs")
+    torch.cuda.synchronize()
+    ref = A_rows.double() @ W.cpu().double().t()
+    if bias:
+        ref = ref + b.cpu().double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    return C.cpu(), ref.float()
+
+
+X3Q_CASES = [
+    # name, prec, M, N, K, conv, act, bias -- gemm_x3q_kernel: pair-row operands, N % 256 == 0, K % 32 == 0, K >= 64, M >= 128
+    ("fp16_conv_gelu_mtail", 3, 8 * 1999, 512, 1536, (3999, 1999, 2, 512), 1, True),
+    ("bf16_conv_k1024", 2, 4 * 999, 512, 1024, (1999, 999, 2, 512), 1, True),
+    ("fp16_qkv_3_tiles_per_cu", 3, 15968, 2304, 768, None, 0, True),
+    ("fp16_ffn1_gelu", 3, 15968, 3072, 768, None, 1, True),
+    ("bf16_two_slabs_no_bias", 2, 70000, 512, 64, None, 0, False),
+    ("fp16_one_tile_ragged", 3, 864, 512, 256, None, 0, True),
+    ("fp16_n768_single_round", 3, 15968, 768, 3072, None, 0, True),
+    ("fp16_three_slabs", 3, 4096, 256, 96, None, 0, True),
+]
+
+
+@pytest.mark.parametrize("bm", [0, 256, 192, 128])
+@pytest.mark.parametrize("out_kind", [0, 1, 2])
+@pytest.mark.parametrize("name,prec,M,N,K,conv,act,bias", X3Q_CASES, ids=[c[0] for c in X3Q_CASES])
+def test_pair_row_split_kernel(bm, out_kind, name, prec, M, N, K, conv, act, bias):
+    """gemm_x3q_kernel (both operands pre-cut into pair rows; the schedule of gemm_pps_kernel with hi*hi + hi*lo + lo*hi per block)
+    against an fp64 reference, for its three outputs (fp32 rows / pair rows / separate planes: the last two read back as hi + lo,
+    which carries 22 of fp32's 24 mantissa bits), every tile height, tile boundaries inside a workgroup's stream, M tails, conv
+    rows, GELU, bias as the accumulators' initial value."""
+    if out_kind == 2 and act:
+        pytest.skip("the plane output (QKV projection) has no activation")
+    lib = _lib.load()
+    lib.svt_debug_set(1, bm)
+    try:
+        got, ref = run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=bias)
+    finally:
+        lib.svt_debug_set(1, 0)
+    assert torch.isfinite(got).all(), "unwritten (NaN-poisoned) outputs"
+    err = (got - ref).abs().max().item()
+    # (the bias is the accumulators' initial value: the fp32 partial sums round at the magnitude of bias + sum, not of the sum alone)
+    tol = {2: 3e-5, 3: 1e-5}[prec] * max(1.0, (K / 768) ** 0.5)
+    if out_kind:   # the stored value itself is cut: 2^-16 (bf16 pieces) / 2^-22 (fp16 pieces) relative
+        tol += {2: 2.0 ** -15, 3: 2.0 ** -21}[prec] * ref.abs().max().item()
+    assert err < tol, (name, bm, out_kind, err, tol)
+
+
 def test_gemm_rejects_unaligned():
     lib = _lib.load()
     A = torch.zeros(64, 36, device=DEV, dtype=torch.bfloat16)
