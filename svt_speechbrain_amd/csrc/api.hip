@@ -767,7 +767,9 @@ int svt_encoder_finalize(svt_encoder* e) {
     // shifted by j taps.  That runs on the LDS-DMA kernel instead of the 64-wide register-staged one.
     e->pos_P = 0;
     const int Pf = cg > 0 ? 256 / cg : 0;
-    if (prec && Pf >= 2 && cg % 8 == 0 && ((kp + Pf - 1) * cg) % 64 == 0) {
+    // (split modes, round 4: the same form in fp32 storage -- the batched one-tile split kernel, gemm_x3s_kernel with blockIdx.y = group,
+    //  replaces 512 register-staged (clip, group) products of 48 columns: 963 us of a 14.8 ms fp16x3 step)
+    if ((prec || c.precision >= 2) && Pf >= 2 && cg % 8 == 0 && ((kp + Pf - 1) * cg) % 64 == 0) {
       const size_t Np = (size_t)Pf * cg, Kp = (size_t)(kp + Pf - 1) * cg;
       std::vector<float> wp((size_t)G * Np * Kp, 0.f), bp((size_t)G * Np);
       for (int g = 0; g < G; ++g)
@@ -779,7 +781,8 @@ int svt_encoder_finalize(svt_encoder* e) {
             for (int k = 0; k < kp; ++k)
               for (int ci = 0; ci < cg; ++ci) row[(size_t)(k + j) * cg + ci] = w[((size_t)o * cg + ci) * kp + k];
           }
-      if (int r = upload_operand(1, e->pos_wP, wp.data(), wp.size())) return r;
+      if (prec) { if (int r = upload_operand(1, e->pos_wP, wp.data(), wp.size())) return r; }
+      else { if (int r = upload_weight(c.precision, e->pos_wP, wp.data(), (size_t)G * Np, Kp)) return r; }
       if (int r = upload_f32(e->pos_bP, bp.data(), bp.size())) return r;
       e->pos_P = Pf;
     }
@@ -926,7 +929,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
     const size_t Tq = Pf ? (T + Pf - 1) / Pf : 0;
     const size_t Tp = Pf ? Tq * Pf + c.pos_conv_kernel : (size_t)(T + c.pos_conv_kernel);
     w.posg = cv.take((size_t)B * Tp * D * es);
-    w.posy = Pf ? cv.take((size_t)B * Tq * Pf * D * 2) : nullptr;
+    w.posy = Pf ? cv.take((size_t)B * Tq * Pf * D * es) : nullptr;
   }
   w.qkv = cv.take(rows * 3 * D * es);
   const bool flash3 = c.precision >= 2 && flash_attention_x3_ok(dh) && !c.rel_pos_buckets;
@@ -1211,7 +1214,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
       g.a_z2 = (long)Tp * cg; g.w_z2 = (long)g.N * g.K; g.c_z2 = (long)B * Tq * g.N; g.bias_z2 = g.N;
       g.act = ACT_GELU; g.out_f32 = 0;
       if (int r = launch_gemm(gp, g, s)) return r;
-      if (int r = launch_posconv_scatter_add(w.hF, w.posy, B, (int)T, D, G, Pf, Tq, w.preF, s)) return r;
+      if (int r = launch_posconv_scatter_add(w.hF, w.posy, B, (int)T, D, G, Pf, Tq, w.preF, s, prec ? 0 : 1)) return r;
     } else {
     if (int r = launch_posconv_gather(prec, w.hF, B, (int)T, D, G, kp, (int)T + kp, w.posg, s, bn_sc, bn_sh)) return r;
     GemmArgs g;

@@ -500,16 +500,32 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_x3_kernel(const unsigned s
     // the output projection's operand as pair rows (gemm_x3q.hip): [32 hi | 32 lo] per 32 elements, in the bytes of the fp32 slab
     // (ldo, o_bstride and h * DH are multiples of 32 elements: the launcher checks)
     char* pp = (char*)op;
+    // a lane holds 4 consecutive d per (db, g) -- 8 bytes per plane -- and its partner lane ^ 32 the other 4 of the same 8: two half
+    // exchanges (v_permlane32_swap) per plane and pair of groups give lanes 0-31 the 8 pieces of group g and lanes 32-63 those of group
+    // g + 1, i.e. one 16-byte store per plane instead of two 8-byte ones (the 8-byte form cost 14 us of a 113 us launch: store issue)
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        unsigned short ph_[4], pl_[4];
+      for (int g = 0; g < 4; g += 2) {
+        unsigned hx[2][2], lx[2][2];   // [group g / g + 1][dword]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) X::cut(o[db][g * 4 + j] * inv, ph_[j], pl_[j]);
-        char* d = pp + db * 128 + (8 * g + 4 * hh) * 2;
-        *(uint2*)d = uint2{(unsigned)ph_[0] | ((unsigned)ph_[1] << 16), (unsigned)ph_[2] | ((unsigned)ph_[3] << 16)};
-        *(uint2*)(d + 64) = uint2{(unsigned)pl_[0] | ((unsigned)pl_[1] << 16), (unsigned)pl_[2] | ((unsigned)pl_[3] << 16)};
+        for (int u = 0; u < 2; ++u) {
+          unsigned short ph_[4], pl_[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) X::cut(o[db][(g + u) * 4 + j] * inv, ph_[j], pl_[j]);
+          hx[u][0] = (unsigned)ph_[0] | ((unsigned)ph_[1] << 16); hx[u][1] = (unsigned)ph_[2] | ((unsigned)ph_[3] << 16);
+          lx[u][0] = (unsigned)pl_[0] | ((unsigned)pl_[1] << 16); lx[u][1] = (unsigned)pl_[2] | ((unsigned)pl_[3] << 16);
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const auto rh = __builtin_amdgcn_permlane32_swap(hx[0][w], hx[1][w], false, false);
+          hx[0][w] = rh[0]; hx[1][w] = rh[1];
+          const auto rl = __builtin_amdgcn_permlane32_swap(lx[0][w], lx[1][w], false, false);
+          lx[0][w] = rl[0]; lx[1][w] = rl[1];
+        }
+        char* d = pp + db * 128 + (8 * (g + hh)) * 2;
+        *(uint4*)d = uint4{hx[0][0], hx[0][1], hx[1][0], hx[1][1]};
+        *(uint4*)(d + 64) = uint4{lx[0][0], lx[0][1], lx[1][0], lx[1][1]};
       }
     return;
   }

@@ -321,7 +321,8 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
 // positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front
 int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, int kp, int Tp, void* out, hipStream_t s,
                           const float* sc = nullptr, const float* sh = nullptr);  // sc/sh: per-channel affine on the valid frames
-int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s);
+int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s,
+                               int y_f32 = 0);   // y in the operand type, or fp32 (split modes)
 
 // attention helpers for the materialised-score path
 int launch_softmax_rows(int prec, const float* S, int64_t rows, int T, int Tp, void* P, hipStream_t s);

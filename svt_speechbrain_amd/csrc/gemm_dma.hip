@@ -795,159 +795,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmArgs p, int tiles_n,
 // tracks the LDS-DMA it emits itself for a builtin and puts an s_waitcnt vmcnt(0) in front of a later LDS read whose
 // address it cannot prove distinct from the DMA's destination -- here the W fragment reads of every slab, i.e. the ring
 // would be drained once per slab.  Through asm the compiler sees no LDS write; the counted vmcnt + barrier below order it.
-__device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-
-template <bool F16>
-__global__ __launch_bounds__(512) void gemm_x3_kernel(GemmArgs p, const void* wsplit) {
-  constexpr int BM = 256, BN = 256, BK = 32, NSLOT = 5, SLOT = 2048, G = 4;  // G: DMA instructions per wave per unit
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const float* A = (const float*)p.A;
-  const unsigned short* W = (const unsigned short*)wsplit;  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
-  const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
-  const float* asrc[G];
-  const unsigned short* wsrc[G];
-#pragma unroll
-  for (int i = 0; i < G; ++i) {
-    int m = m0 + (wave + 8 * i) * 8 + r8;
-    if (m > p.M - 1) m = p.M - 1;
-    asrc[i] = A + (long)(m / p.a_rpb) * p.a_bstride + (long)(m % p.a_rpb) * p.a_rstride + ch * 4;
-    const int rho = (wave + 8 * i) * 8 + r8;
-    const int i16 = rho & 15;
-    int n = n0 + (rho >> 6) * 64 + (i16 >> 2) * 16 + ((rho >> 4) & 3) * 4 + (i16 & 3);
-    if (n > p.N - 1) n = p.N - 1;
-    wsrc[i] = W + (long)n * (2 * p.K) + ch * 8;
-  }
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds);
-  auto issue_a = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-      dma16_asm(asrc[i] + kt * BK, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u));
-  };
-  auto issue_w = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-      dma16_asm(wsrc[i] + kt * 64, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + (wave + 8 * i) * 64) * 16u));
-  };
-  f32x4 acc[16][2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int cq = lane >> 4, r16 = lane & 15, rr8 = r16 & 7;
-  // 16-row block b of a unit starts at uint4 index b * 128; row r16 of it: group r16 >> 3, row rr8, chunk c at slot c ^ rr8
-  const int rowb = (r16 >> 3) * 64 + rr8 * 8;
-  const int fa0 = rowb + ((2 * cq) ^ rr8), fa1 = rowb + ((2 * cq + 1) ^ rr8);   // A: fp32 k = 8 cq .. 8 cq + 7 = chunks 2cq, 2cq+1
-  const int fwh = rowb + (cq ^ rr8), fwl = rowb + ((4 + cq) ^ rr8);             // W: hi pieces chunk cq, lo pieces chunk 4 + cq
-  const int nk = p.K / BK;
-  auto mma = [&](const uint4& a, const uint4& b, const f32x4& c) -> f32x4 {
-    if constexpr (F16) {
-      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
-    } else {
-      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(real_bf16x8, a), __builtin_bit_cast(real_bf16x8, b), c, 0, 0, 0);
-    }
-  };
-  // 8 fp32 of one lane (two 16-byte chunks) -> (hi, lo) pieces
-  auto cut = [&](const uint4& r0, const uint4& r1, uint4& hi, uint4& lo) {
-    const f32x4 v0 = __builtin_bit_cast(f32x4, r0), v1 = __builtin_bit_cast(f32x4, r1);
-    if constexpr (F16) {
-      typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-      f16x8v h, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h[j] = (_Float16)v0[j]; l[j] = (_Float16)(v0[j] - (float)h[j]);
-        h[4 + j] = (_Float16)v1[j]; l[4 + j] = (_Float16)(v1[j] - (float)h[4 + j]);
-      }
-      hi = __builtin_bit_cast(uint4, h);
-      lo = __builtin_bit_cast(uint4, l);
-    } else {
-      bf16x8 h, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h[j] = (bf16_t)v0[j]; l[j] = (bf16_t)(v0[j] - (float)h[j]);
-        h[4 + j] = (bf16_t)v1[j]; l[4 + j] = (bf16_t)(v1[j] - (float)h[4 + j]);
-      }
-      hi = __builtin_bit_cast(uint4, h);
-      lo = __builtin_bit_cast(uint4, l);
-    }
-  };
-  // Software pipeline over slabs.  At the top of iteration kt every unit issued so far has landed (vmcnt(0) + barrier):
-  // W_kt, which this iteration multiplies, and A_{kt+1}, which it only cuts into pieces for the next one -- the A pieces of
-  // slab kt are already in registers.  The two units of the ring that nobody reads any more (those of slab kt - 1) are
-  // refilled with W_{kt+1} and A_{kt+2} right after the barrier, and the fp32 reads + cuts of A_{kt+1} sit in the middle of
-  // the 96 MFMAs, so the matrix pipe is never waiting for the wave's own DMA issue or conversion work.
-  issue_a(0, 0);
-  issue_w(0, 1);
-  if (nk > 1) issue_a(1, 2);
-  if (nk > 1) wait_vm<G>(); else wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
-  uint4 xh[2], xl[2];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) cut(lds[(wave * 2 + mb) * 128 + fa0], lds[(wave * 2 + mb) * 128 + fa1], xh[mb], xl[mb]);
-  int sw = 1;       // slot of W_kt; A_{kt+1} is in the next slot
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt > 0) {
-      wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-    } else if (nk > 1) {
-      wait_vm<0>();                  // A_1 (issued in the prologue): needed by this iteration's cut
-      __builtin_amdgcn_s_barrier();
-    }
-    if (kt + 1 < nk) issue_w(kt + 1, (2 * kt + 3) % NSLOT);
-    if (kt + 2 < nk) issue_a(kt + 2, (2 * kt + 4) % NSLOT);
-    const uint4* wa = lds + sw * SLOT;
-    const uint4* xn = lds + ((sw + 1) % NSLOT) * SLOT + (wave * 2) * 128;   // A_{kt+1}
-    uint4 raw[2][2], nh[2], nl[2];
-    const bool more = kt + 1 < nk;
-    if (more) {
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) { raw[mb][0] = xn[mb * 128 + fa0]; raw[mb][1] = xn[mb * 128 + fa1]; }
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nb = 0; nb < 16; ++nb) {
-      const uint4 wh = wa[nb * 128 + fwh], wl = wa[nb * 128 + fwl];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wl, xh[mb], acc[nb][mb]);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wh, xl[mb], acc[nb][mb]);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mma(wh, xh[mb], acc[nb][mb]);
-      if (nb == 5 && more) cut(raw[0][0], raw[0][1], nh[0], nl[0]);
-      if (nb == 10 && more) cut(raw[1][0], raw[1][1], nh[1], nl[1]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (more) {
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) { xh[mb] = nh[mb]; xl[mb] = nl[mb]; }
-    }
-    sw = (sw + 2) % NSLOT;
-  }
-  // ---- epilogue: LDS-transposed coalesced fp32 stores (epilogue_block reads its row / column base as
-  //      m0 + wm * (BM_/2) + mb * 16 and n0 + wn * 64: with BM_ = 64, wm = wave and wn = the 64-column group) ----
-  const float* bias = p.bias;
-  __syncthreads();
-  float* patch = (float*)lds + wave * (16 * 68);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const BiasRegs br = load_bias_regs<true>(p, bias, lane, g, n0);
-    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, br);
-    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, br);
-  }
-}
+// (the lockstep kernel built on this plan in round 2, gemm_x3_kernel, is gone: git history; its staggered successor follows)
 
 // ---------------------------------------------------------------------------------------------
 // Staggered form of gemm_x3_kernel (round 3).  The lockstep kernel above kept the matrix pipe busy for 0.43 of its cycles: all eight
@@ -977,8 +825,12 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int tile_n = wg % tiles_n, tile_m = wg / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const float* A = (const float*)p.A;
-  const unsigned short* W = (const unsigned short*)wsplit;  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
+  // batch (blockIdx.y = z = z1 * nz2 + z2, the grouped positional conv): element offsets of the fp32 problem; a packed weight row
+  // takes the bytes of its fp32 row
+  const int zb = blockIdx.y, z1 = zb / p.nz2, z2 = zb - z1 * p.nz2;
+  const float* A = (const float*)p.A + ((long)z1 * p.a_z1 + (long)z2 * p.a_z2);
+  const unsigned short* W = (const unsigned short*)wsplit + 2 * ((long)z1 * p.w_z1 + (long)z2 * p.w_z2);  // [N][K / 32][64]: 32 hi pieces, 32 lo pieces
+  const long czoff = (long)z1 * p.c_z1 + (long)z2 * p.c_z2;
   const int r8 = lane >> 3, ch = (lane & 7) ^ (lane >> 3);
   // ring requests in the `voffset + SGPR base` form (as gemm_x3p_kernel): a 64-bit scalar base per operand (A: the tile's first row -- the
   // tensor may exceed 4 GiB, a tile's span may not: gemm_x3p_eligible), one 32-bit offset per lane and request, the K advance scalar.
@@ -1189,7 +1041,7 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
   //      column base n0 + wn * 64 with wn = the 64-column group) ----
   wait_vm<0>();   // the surplus requests of the last two slabs: the ring becomes transpose patches
   __syncthreads();
-  const float* bias = p.bias;
+  const float* bias = p.bias ? p.bias + (long)z2 * p.bias_z2 : nullptr;
   float* patch = (float*)lds + wave * (16 * 68);
   if constexpr (DBG == 3) {   // every accumulator stays live: a check of two of them lets hipcc delete the MFMAs of all the others
 #pragma unroll
@@ -1199,8 +1051,8 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(GemmArgs p, const void* w
 #pragma unroll
   for (int g = 0; g < NBS; ++g) {
     const BiasRegs br = load_bias_regs<true>(p, bias, lane, g, n0);
-    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, 0L, br);
-    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, 0L, br);
+    epilogue_block<2, 64, true>(p, acc[4 * g][0], acc[4 * g + 1][0], acc[4 * g + 2][0], acc[4 * g + 3][0], 0, patch, lane, wave, g, m0, n0, czoff, br);
+    epilogue_block<2, 64, true>(p, acc[4 * g][1], acc[4 * g + 1][1], acc[4 * g + 2][1], acc[4 * g + 3][1], 1, patch, lane, wave, g, m0, n0, czoff, br);
   }
 }
 
@@ -1333,8 +1185,15 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     prof_end(s, flops, bytes, 0);
     return 0;
   }
-  if (a.gen || a.nz != 1 || a.K % 32 || a.N < 128 || a.M < 128 || !a.c_vec || a.ldw != a.K || a.alpha != 1.f || a.w_z1 || a.w_z2 ||
-      a.a_z1 || a.a_z2 || a.c_z1 || a.c_z2 || (a.a_rstride & 3) || (a.a_bstride & 3) || ((uintptr_t)a.A & 15))
+  // batched problems (nz > 1: the grouped positional conv, one z per group): the one-tile kernel with blockIdx.y = z; the registered
+  // matrix holds the groups' rows one after the other
+  const bool batched = a.nz > 1;
+  if (a.gen || a.nz < 1 || a.K % 32 || a.N < 128 || a.M < 128 || !a.c_vec || a.ldw != a.K || a.alpha != 1.f || (a.a_rstride & 3) ||
+      (a.a_bstride & 3) || ((uintptr_t)a.A & 15))
+    return 1;
+  if (!batched && (a.w_z1 || a.w_z2 || a.a_z1 || a.a_z2 || a.c_z1 || a.c_z2)) return 1;
+  if (batched && (a.planes || a.resid || a.nz2 < 1 || a.nz % a.nz2 || (a.a_z1 & 3) || (a.a_z2 & 3) || (a.c_z1 & 3) || (a.c_z2 & 3) || (a.bias_z2 & 3) ||
+                  a.w_z1 % a.K || a.w_z2 % a.K || a.nz > 65535))
     return 1;
   const void* packed = nullptr;
   {
@@ -1347,7 +1206,8 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     const size_t off = (const char*)a.W - base;
     if (it->second.kind != kind || it->second.K != a.K || off % ((size_t)a.K * 4) != 0) return 1;
     const size_t row = off / ((size_t)a.K * 4);
-    if (row + a.N > (size_t)it->second.N) return 1;
+    const size_t last_z_row = batched ? ((size_t)(a.nz / a.nz2 - 1) * a.w_z1 + (size_t)(a.nz2 - 1) * a.w_z2) / (size_t)a.K : 0;
+    if (row + last_z_row + a.N > (size_t)it->second.N) return 1;
     packed = (const char*)it->second.packed + row * (size_t)a.K * 4;
   }
   {
@@ -1367,8 +1227,8 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     g.resid = nullptr;
     g.stamp_ends = g_stamp_ends;
   }
-  const double flops = 2.0 * a.M * (double)a.N * a.K;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
+  const double flops = 2.0 * a.M * (double)a.N * a.K * a.nz;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4 * a.nz;
   // tile width: 192 columns when that fills the chip better (N = 768: 252 tiles against 189); g_gemm_variant 30 = the lockstep kernel (A/B)
   const long tm = (a.M + 255) / 256;
   const long t256 = tm * ((a.N + 255) / 256), t192 = tm * ((a.N + 191) / 192);
@@ -1380,7 +1240,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   // persistent form, 34 = always when eligible -- A/B)
   // Measured per shape (profiles/r03_gemm_x3_variants.txt): the persistent form is ahead on the launches with a heavy epilogue and
   // several tiles per CU (conv 1-4, FFN-1: GELU over fp32 outputs), the one-tile kernel on the plain projections (QKV, out-proj, FFN-2).
-  const bool x3p_ok = gemm_x3p_eligible(g) && g_gemm_variant != 30 && g_gemm_variant != 31 && g_gemm_variant != 32 && g_gemm_variant != 33;
+  const bool x3p_ok = !batched && gemm_x3p_eligible(g) && g_gemm_variant != 30 && g_gemm_variant != 31 && g_gemm_variant != 32 && g_gemm_variant != 33;
   if (x3p_ok && (g_gemm_variant == 34 || (a.act == ACT_GELU && t256 > 256) || t256 >= 1024)) {   // (large QKV, 1 500 tiles: 547 against 583 us)
     g.dbg = g_gemm_dbg == 9 ? 0 : g_gemm_dbg;
     if (int r_ = launch_gemm_x3p(kind, g, packed, s)) return r_;
@@ -1407,31 +1267,22 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4, 3>, (int)lds_bytes)) return r_;
       hipLaunchKernelGGL((gemm_x3s_kernel<true, 4, 3>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
     }
-  } else if (g_gemm_variant == 30) {
-    const int tiles = (int)t256;
-    if (kind == 3) {
-      if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<true>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3_kernel<true>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
-    } else {
-      if (int r_ = ensure_dyn_lds((const void*)gemm_x3_kernel<false>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3_kernel<false>), dim3(tiles), dim3(512), lds_bytes, s, g, packed);
-    }
 #endif
   } else if (narrow) {
     if (kind == 3) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 3>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3s_kernel<true, 3>), dim3((unsigned)t192), dim3(512), lds_bytes, s, g, packed);
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 3>), dim3((unsigned)t192, (unsigned)a.nz), dim3(512), lds_bytes, s, g, packed);
     } else {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<false, 3>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3s_kernel<false, 3>), dim3((unsigned)t192), dim3(512), lds_bytes, s, g, packed);
+      hipLaunchKernelGGL((gemm_x3s_kernel<false, 3>), dim3((unsigned)t192, (unsigned)a.nz), dim3(512), lds_bytes, s, g, packed);
     }
   } else {
     if (kind == 3) {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<true, 4>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3s_kernel<true, 4>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+      hipLaunchKernelGGL((gemm_x3s_kernel<true, 4>), dim3((unsigned)t256, (unsigned)a.nz), dim3(512), lds_bytes, s, g, packed);
     } else {
       if (int r_ = ensure_dyn_lds((const void*)gemm_x3s_kernel<false, 4>, (int)lds_bytes)) return r_;
-      hipLaunchKernelGGL((gemm_x3s_kernel<false, 4>), dim3((unsigned)t256), dim3(512), lds_bytes, s, g, packed);
+      hipLaunchKernelGGL((gemm_x3s_kernel<false, 4>), dim3((unsigned)t256, (unsigned)a.nz), dim3(512), lds_bytes, s, g, packed);
     }
   }
   prof_end(s, flops, bytes, 0);

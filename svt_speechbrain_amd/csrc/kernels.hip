@@ -1503,7 +1503,8 @@ int launch_posconv_gather(int prec, const float* h, int B, int T, int D, int G, 
 
 // multi-frame positional conv: y[g][b*Tq + q][j*cg + c] (bf16, GELU applied) holds frame t = q*P + j of group g;
 // pre[b][t][g*cg + c] = h[b][t][g*cg + c] + y[...]  (8 channels per thread)
-__global__ void posconv_scatter_add_kernel(const float* h, const bf16_t* y, int B, int T, int D, int G, int P, int Tq, float* pre) {
+template <typename TY>
+__global__ void posconv_scatter_add_kernel(const float* h, const TY* y, int B, int T, int D, int G, int P, int Tq, float* pre) {
   const int cg = D / G, c8n = D / 8;
   const int64_t n = (int64_t)B * T * c8n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1512,17 +1513,27 @@ __global__ void posconv_scatter_add_kernel(const float* h, const bf16_t* y, int 
     const int t = (int)(r % T), b = (int)(r / T);
     const int g = ch / cg, c = ch - g * cg;
     const int q = t / P, j = t - q * P;
-    const bf16x8 v = *(const bf16x8*)(y + (((int64_t)g * B + b) * Tq + q) * (P * cg) + j * cg + c);
+    const TY* yp = y + (((int64_t)g * B + b) * Tq + q) * (P * cg) + j * cg + c;
+    float v[8];
+    if constexpr (sizeof(TY) == 2) {
+      const bf16x8 vb = *(const bf16x8*)yp;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (float)vb[i];
+    } else {
+      const float4 a0 = *(const float4*)yp, a1 = *(const float4*)(yp + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    }
     const float* hp = h + r * D + ch;
     const float4 h0 = *(const float4*)hp, h1 = *(const float4*)(hp + 4);
     float* op = pre + r * D + ch;
-    *(float4*)op = float4{h0.x + (float)v[0], h0.y + (float)v[1], h0.z + (float)v[2], h0.w + (float)v[3]};
-    *(float4*)(op + 4) = float4{h1.x + (float)v[4], h1.y + (float)v[5], h1.z + (float)v[6], h1.w + (float)v[7]};
+    *(float4*)op = float4{h0.x + v[0], h0.y + v[1], h0.z + v[2], h0.w + v[3]};
+    *(float4*)(op + 4) = float4{h1.x + v[4], h1.y + v[5], h1.z + v[6], h1.w + v[7]};
   }
 }
-int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s) {
+int launch_posconv_scatter_add(const float* h, const void* y, int B, int T, int D, int G, int P, int Tq, float* pre, hipStream_t s, int y_f32) {
   const int64_t n = (int64_t)B * T * (D / 8);
-  hipLaunchKernelGGL(posconv_scatter_add_kernel, dim3(grid_for(n)), dim3(256), 0, s, h, (const bf16_t*)y, B, T, D, G, P, Tq, pre);
+  if (y_f32) hipLaunchKernelGGL((posconv_scatter_add_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, h, (const float*)y, B, T, D, G, P, Tq, pre);
+  else hipLaunchKernelGGL((posconv_scatter_add_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, h, (const bf16_t*)y, B, T, D, G, P, Tq, pre);
   SVT_LAUNCH_CHECK();
   return 0;
 }
