@@ -285,7 +285,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * attention kernel (K / V of a head resident in LDS; measured slower, off by default), 11 = LDS-DMA split-operand GEMM
  * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls,
  * 13 = page-guarded device allocations (see svt_debug_alloc), 19 = split-operand modes keep product operands as pair rows written by
- * their producers (1, default) or as fp32 cut inside the product kernels (0: the round-2/3 path, A/B).
+ * their producers (1, default) or as fp32 cut inside the product kernels (0: the round-2/3 path, A/B), 20 = (hi, lo) LayerNorm with two
+ * rows per wave (1, default) or one (0).
  * Returns 0. */
 int svt_debug_set(int key, int value);
 

@@ -553,6 +553,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 12) g_debug_keep_split = value;
   else if (key == 13) g_guard_alloc = value;
   else if (key == 19) g_x3_pairs = value;
+  else if (key == 20) g_ln_two_rows = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -1306,20 +1307,23 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     }
     final_x = w.xF;
   } else if (!c.stable_layer_norm && pk_enc) {
-    // split modes on pair rows: LN -> (fp32 residual w.xF, pair rows w.xb); the four products read pair rows
-    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, w.xF, s, nullptr,
+    // split modes on pair rows: the layer input w.xb (pair rows) IS the residual stream -- LN(branch + (hi + lo)) -> (hi', lo') in place,
+    // 12 bytes per element and pass instead of 16 with an fp32 copy beside it (hi + lo carries 22 of fp32's 24 mantissa bits; the
+    // products see exactly these pieces either way); the last layer also writes the fp32 result for the whole-batch output norm
+    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, nullptr, s, nullptr,
                                  nullptr, w.xb, pk_enc)) return r;
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
+      const bool last = l + 1 == c.num_layers;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
       if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, nullptr, w.xF, s, w.xF,
-                                   nullptr, w.xb, pk_enc)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, nullptr, nullptr, s, nullptr,
+                                   nullptr, w.xb, pk_enc, w.xb)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 1, ACT_GELU, nullptr, nullptr, 1)) return r;
       if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, nullptr, w.xF, s, w.xF,
-                                   nullptr, w.xb, pk_enc)) return r;
+      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, nullptr, last ? w.xF : nullptr, s,
+                                   nullptr, nullptr, w.xb, pk_enc, w.xb)) return r;
     }
     final_x = w.xF;
   } else if (!c.stable_layer_norm) {

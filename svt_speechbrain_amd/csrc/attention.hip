@@ -257,14 +257,28 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
   if (q >= T) return;
   const float inv = 1.f / l;
   bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+  // a lane holds 4 consecutive d per (db, g) and its partner lane ^ 32 (same query) the other 4 of the same 8: a half exchange
+  // (v_permlane32_swap) per dword gives lanes 0-31 the 8 values of group g and lanes 32-63 those of group g + 1 -- one 16-byte store
+  // per pair of groups instead of two 8-byte ones (the store tail of a row-per-lane epilogue is bound by store ISSUE, not bytes)
 #pragma unroll
   for (int db = 0; db < DB; ++db)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
+    for (int g = 0; g < 4; g += 2) {
+      unsigned w[2][2];   // [group g / g + 1][dword]
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][g * 4 + j] * inv);
-      *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
+      for (int u = 0; u < 2; ++u) {
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][(g + u) * 4 + j] * inv);
+        const uint2 pk = __builtin_bit_cast(uint2, v);
+        w[u][0] = pk.x; w[u][1] = pk.y;
+      }
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2) {
+        const auto r = __builtin_amdgcn_permlane32_swap(w[0][d2], w[1][d2], false, false);
+        w[0][d2] = r[0]; w[1][d2] = r[1];
+      }
+      *(uint4*)(op + db * 32 + 8 * (g + hh)) = uint4{w[0][0], w[0][1], w[1][0], w[1][1]};
     }
   if constexpr (STAMP) {
     __syncthreads();
@@ -605,7 +619,8 @@ int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups
 int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* K, const void* V, long ldk, long k_bstride,
                            void* O, long ldo, long o_bstride, int B, int T, int H, int dh, float scale, hipStream_t s,
                            const float* gate, const float* pb) {
-  if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8) { set_error("flash_attention: strides must be multiples of 8"); return -1; }
+  if ((ldq | ldk | ldo | q_bstride | k_bstride | o_bstride) % 8 || ((uintptr_t)O & 15) || ((uintptr_t)Q & 15)) {
+    set_error("flash_attention: strides must be multiples of 8 elements and Q / O 16-byte aligned"); return -1; }
   const float c = scale * 1.44269504088896340736f;
   dim3 grid((T + 127) / 128, H, B);
   // eight-wave workgroups (256 queries) halve the K / V traffic per query; used when a head has more than 128 queries

@@ -258,6 +258,7 @@ int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t
 bool gemm_x3q_eligible(const GemmArgs& a);
 int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);
 extern int g_x3_pairs;  // 1 (default): the split modes keep product operands as pair rows; 0: fp32 activations cut inside the product kernels (svt_debug_set key 19)
+extern int g_ln_two_rows;  // (hi, lo) LayerNorm: half a wave per row, 16-byte accesses (1, default) or a wave per row (0)
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
@@ -301,7 +302,8 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s,
                      const float* add = nullptr, float* sumF = nullptr,
-                     void* yP = nullptr, int pair_kind = 0);   // yP: the result as pair rows (split modes; kind 2 = bf16 / 3 = fp16 pieces)
+                     void* yP = nullptr, int pair_kind = 0,    // yP: the result as pair rows (split modes; kind 2 = bf16 / 3 = fp16 pieces)
+                     const void* addP = nullptr);              // addP: a second addend given as pair rows (may alias yP: in place)
 
 // conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
 int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,

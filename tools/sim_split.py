@@ -6,12 +6,15 @@ v_mfma_f32_16x16x32_bf16 -- and the result is compared with the reference golden
 
     python tools/sim_split.py base_c1 bf16x1 bf16x3 bf16x6 f16x1 f16x3
 """
+import os
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 from oracle import svt_oracle as O  # noqa: E402
 from svt_speechbrain_amd import weights as W  # noqa: E402
 from svt_speechbrain_amd.config import PRESETS  # noqa: E402
@@ -53,30 +56,39 @@ def make_ops(mode):
     return linear, conv1d, matmul
 
 
-def main():
-    name = sys.argv[1]
-    fx = torch.load(f"tests/golden/{name}.pt", weights_only=False)
+def simulate(fx, mode):
+    """One golden case `fx` (tests/golden/<name>.pt, loaded) through the oracle with every dense product replaced by `mode`'s
+    sum of piece products -> (max |dlogit|, mean |dlogit|, frames whose octave / pitch-class argmax differs from the reference,
+    over all clips, frames in total).  CPU; a few seconds per case."""
     cfg = PRESETS[fx["cfg"]]
     sd = W.seeded_encoder_state_dict(cfg, seed=fx["weight_seed"])
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=fx["head_seed"])
     g = torch.Generator().manual_seed(fx["wav_seed"])
     wav = (0.1 * torch.randn(fx["B"], fx["L"], generator=g)).clamp_(-1, 1)
-    torch.set_num_threads(8)
     keep = (F.linear, F.conv1d, torch.matmul)
-    for mode in sys.argv[2:]:
-        F.linear, F.conv1d, torch.matmul = make_ops(mode)
-        try:
-            with torch.no_grad():
-                feats = O.encoder_forward(sd, cfg, wav)
-        finally:
-            F.linear, F.conv1d, torch.matmul = keep
+    F.linear, F.conv1d, torch.matmul = make_ops(mode)
+    try:
         with torch.no_grad():
-            logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
-        err = (logits - fx["logits"]).abs()
-        _, _, octv, pc = O.decode_frames(logits)
-        d = fx["decode"][0]
-        mism = int(((octv[0] != d["oct"]) | (pc[0] != d["pc"])).sum())
-        print(f"{name} {mode}: max|dlogit| {err.max():.3e} mean {err.mean():.3e} argmax mismatches {mism}/{octv.shape[1]}", flush=True)
+            feats = O.encoder_forward(sd, cfg, wav)
+    finally:
+        F.linear, F.conv1d, torch.matmul = keep
+    with torch.no_grad():
+        logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
+    err = (logits - fx["logits"]).abs()
+    _, _, octv, pc = O.decode_frames(logits)
+    mism = 0
+    for b, d in enumerate(fx["decode"]):
+        mism += int(((octv[b] != d["oct"]) | (pc[b] != d["pc"])).sum())
+    return float(err.max()), float(err.mean()), mism, int(octv.shape[0] * octv.shape[1])
+
+
+def main():
+    name = sys.argv[1]
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
+    torch.set_num_threads(8)
+    for mode in sys.argv[2:]:
+        mx, mn, mism, total = simulate(fx, mode)
+        print(f"{name} {mode}: max|dlogit| {mx:.3e} mean {mn:.3e} argmax mismatches {mism}/{total}", flush=True)
 
 
 if __name__ == "__main__":
