@@ -554,6 +554,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 13) g_guard_alloc = value;
   else if (key == 19) g_x3_pairs = value;
   else if (key == 20) g_ln_two_rows = value;
+  else if (key == 21) g_attn_variant = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }

@@ -296,6 +296,230 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const bf16_t* __res
 #undef SVT_STAGE_DMA
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Staggered form of flash_attn_kernel<64, false, 8> (round 4).  What the counters said about that kernel at 32 x 12 heads x 499 frames
+// (profiles/r04_attention_pmc.txt): 16 MFMAs (512 cycles of the matrix pipe) and ~150 vector instructions (~550 cycles of the vector
+// pipe: 32 quarter-rate exponentials are half of it) per wave and 64-key tile -- the two pipes are BALANCED -- yet a SIMD retires a
+// wave-tile only every ~1 340 cycles (matrix pipe busy 0.24 of the kernel, waves parked at waits and barriers for 43 % of their
+// cycles): the workgroup's barrier per tile keeps its eight waves in the same phase, so the two waves a workgroup has on a SIMD
+// multiply at the same time and exponentiate at the same time, and only the other workgroup of the CU ever fills the idle pipe.
+// Here waves 4-7 run HALF A TILE behind waves 0-3, the way the GEMM kernels stagger their wave groups: every wave executes the
+// same per-tile sequence S = K Q^T -> softmax -> O += V P, but waves 0-3 pass the tile's barrier in front of S and waves 4-7 between
+// the softmax and the P V product of the previous tile -- when one group is in its MFMA phases the SIMD partner is in its softmax.
+// The barrier of tile j still means "tile j has landed, and tile j + 1 may be requested": with the late group still reading V of tile
+// j - 1 at that point the request needs a third stage (tile j + 1 overwrites tile j - 2): 48 KiB per workgroup, two workgroups per CU.
+// The LDS-DMA is issued from inline asm (the compiler tracks the DMA it emits for the builtin and guards later LDS reads it cannot
+// prove distinct from the destination with s_waitcnt vmcnt(0) -- here the late group's V reads right behind its requests); the
+// explicit vmcnt(0) in front of every barrier is the only wait on it.
+__device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void flash_attn_stag_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
+                                                              const bf16_t* __restrict__ K, long ldk, long k_bstride,
+                                                              const bf16_t* __restrict__ V, bf16_t* __restrict__ O, long ldo,
+                                                              long o_bstride, int T, int H, float c, int nqb) {
+  static_assert(DH == 64, "built for head_dim 64");
+  constexpr int NW = 8, NST = 3;
+  constexpr int KSD = DH / 16, DB = DH / 32, CPR = DH / 8, RB = 2 * DH;
+  constexpr int TILE16 = 64 * CPR;                   // uint4 per tile
+  constexpr int STAGE16 = 2 * TILE16;                // K tile + V tile
+  constexpr long STAGE_BYTES = (long)STAGE16 * 16;
+  __shared__ __attribute__((aligned(16))) uint4 KV[NST * STAGE16];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // 1-D grid of NQB x (B * H) workgroups, mapped so that the NQB query blocks of one (clip, head) are blocks L, L + 8, L + 16, ...:
+  // consecutive blocks are dealt round-robin over the 8 XCDs, so those land on ONE XCD and the K / V of the head are fetched into
+  // one L2 instead of NQB (speed only: profiles/r04_attention_pmc.txt, 147 MB of HBM-side traffic per launch against 98 MB algorithmic)
+  const int L = blockIdx.x, BH = (int)gridDim.x / nqb;
+  int bh, qblk;
+  {
+    const int full = (BH / 8) * 8 * nqb;   // blocks covered by whole groups of 8 heads
+    if (L < full) { bh = (L & 7) + 8 * (L / (8 * nqb)); qblk = (L >> 3) % nqb; }
+    else { const int r = L - full; bh = (BH / 8) * 8 + r / nqb; qblk = r % nqb; }
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = qblk * (32 * NW) + wave * 32;
+  const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
+  const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
+  const bf16_t* Vb = V + (long)b * k_bstride + (long)h * DH;
+
+  bf16x8 qf[KSD];
+  {
+    int q = q0 + (lane & 31);
+    if (q > T - 1) q = T - 1;
+    const bf16_t* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  // LDS-DMA source mapping of flash_attn_kernel: one instruction per wave, tile and operand (8 rows x 128 B)
+  const int dkey = wave * 8 + lane / CPR;
+  const int slot = lane % CPR;
+  const int kch = (slot ^ ((dkey >> 1) & 7)) * 8;
+  const int vch = (slot ^ (((dkey >> 1) & 1) << 2)) * 8;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(void __attribute__((address_space(3)))*)KV);
+  auto stage_dma = [&](int tile, int stage) {
+    int key = tile * 64 + dkey;
+    if (key > T - 1) key = T - 1;
+    const bf16_t* kp = Kb + (long)key * ldk;
+    const unsigned dst = lds0 + (unsigned)((stage * STAGE16 + wave * 64) * 16);
+    attn_dma16(kp + kch, dst);
+    attn_dma16(kp + (Vb - Kb) + vch, dst + TILE16 * 16);
+  };
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+  const int hh = lane >> 5;
+  const int kl = lane & 31;
+  const int kg = (kl >> 1) & 7;
+  const int ntiles = (T + 63) / 64;
+  const char* vbase[DB];
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int key0 = 4 * (g >> 1) + q;
+    const int sw = ((q >> 1) & 1) << 2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+      vbase[db] = (const char*)&KV[TILE16] + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
+    }
+  }
+  f32x16 s[2];
+  bf16x8 pf[2][2];
+
+  // the barrier of tile j: this wave's share of tile j has landed; behind the barrier everyone's has, and every wave is done with
+  // tile j - 2, whose stage the request for tile j + 1 overwrites
+#define SVT_AT_BAR(J)                                                                                   \
+  {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_s_barrier();                                                                       \
+    if ((J) + 1 < ntiles) stage_dma((J) + 1, st_next);                                                  \
+  }
+#define SVT_AT_S(ST)                                                                                    \
+  {                                                                                                     \
+    const uint4* Kf = KV + (ST) * STAGE16;                                                              \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;                                    \
+      _Pragma("unroll") for (int ks = 0; ks < KSD; ++ks)                                                \
+        s[kb] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, Kf[(kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]), qf[ks], s[kb]); \
+    }                                                                                                   \
+  }
+  // softmax in the scaled log2 domain (flash_attn_kernel): row max on the raw scores, deferred rescale, P = exp2(s c - m) -> bf16
+#define SVT_AT_SM(TILE)                                                                                 \
+  {                                                                                                     \
+    if (__builtin_expect((TILE) * 64 + 64 > T, 0)) {                                                    \
+      const int kbase = (TILE) * 64 + 4 * hh;                                                           \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);                                     \
+          asm volatile("" : "+v"(s[kb][r]));                                                            \
+          if (key >= T) s[kb][r] = -3e38f;                                                              \
+        }                                                                                               \
+    }                                                                                                   \
+    float mx = fmaxf(s[0][0], s[1][0]);                                                                 \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);             \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;                                                         \
+    if (!__all(mx - m <= 8.0f)) {                                                                       \
+      const float mnew = fmaxf(m, mx);                                                                  \
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);                                             \
+      l *= alpha;                                                                                       \
+      m = mnew;                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < DB; ++i)                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) o[i][r] *= alpha;                                \
+    }                                                                                                   \
+    float sa = 0.f, sb = 0.f;                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                               \
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m));                                 \
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], c, -m));                             \
+        s[kb][r] = p0; s[kb][r + 1] = p1;                                                               \
+        sa += p0; sb += p1;                                                                             \
+      }                                                                                                 \
+    float sum = sa + sb;                                                                                \
+    sum += __shfl_xor(sum, 32, 64);                                                                     \
+    l += sum;                                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                    \
+      _Pragma("unroll") for (int ss = 0; ss < 2; ++ss)                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[kb][ss][j] = (bf16_t)s[kb][ss * 8 + j];        \
+  }
+#define SVT_AT_PV(ST)                                                                                   \
+  {                                                                                                     \
+    _Pragma("unroll") for (int db = 0; db < DB; ++db)                                                   \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
+        _Pragma("unroll") for (int ss = 0; ss < 2; ++ss) {                                              \
+          const char* vp = vbase[db] + (ST) * STAGE_BYTES + (kb * 32 + ss * 16) * RB;                   \
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));                  \
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));         \
+          const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+          o[db] = SVT_MFMA_32x32x16(__builtin_bit_cast(bf16x8, vv), pf[kb][ss], o[db]);                 \
+        }                                                                                               \
+  }
+
+  stage_dma(0, 0);
+  int st = 0;   // stage of the tile being multiplied
+  if (wave < 4) {
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int st_next = st + 1 == NST ? 0 : st + 1;
+      SVT_AT_BAR(tile)
+      SVT_AT_S(st)
+      SVT_AT_SM(tile)
+      SVT_AT_PV(st)
+      st = st_next;
+    }
+  } else {
+    {
+      const int st_next = 1;
+      SVT_AT_BAR(0)
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int st1 = st + 1 == NST ? 0 : st + 1;
+      SVT_AT_S(st)
+      SVT_AT_SM(tile)
+      if (tile + 1 < ntiles) {
+        const int st_next = st1 + 1 == NST ? 0 : st1 + 1;   // stage of tile + 2
+        SVT_AT_BAR(tile + 1)
+      }
+      SVT_AT_PV(st)
+      st = st1;
+    }
+  }
+#undef SVT_AT_BAR
+#undef SVT_AT_S
+#undef SVT_AT_SM
+#undef SVT_AT_PV
+
+  const int q = q0 + (lane & 31);
+  if (q >= T) return;
+  const float inv = 1.f / l;
+  bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      unsigned w[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[db][(g + u) * 4 + j] * inv);
+        const uint2 pk = __builtin_bit_cast(uint2, v);
+        w[u][0] = pk.x; w[u][1] = pk.y;
+      }
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2) {
+        const auto r = __builtin_amdgcn_permlane32_swap(w[0][d2], w[1][d2], false, false);
+        w[0][d2] = r[0]; w[1][d2] = r[1];
+      }
+      *(uint4*)(op + db * 32 + 8 * (g + hh)) = uint4{w[0][0], w[0][1], w[1][0], w[1][1]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Split-operand fused attention (precision "bf16x3" / "fp16x3").  Q, K, V arrive as 16-bit (hi, lo) PLANES of the fp32
 // projections (split_planes_kernel below; plane = same (rows, ld) layout, lo plane `plane` elements after the hi plane);
 // every product is three MFMAs accumulated in fp32:
@@ -553,6 +777,238 @@ __global__ __launch_bounds__(64 * NW) void flash_attn_x3_kernel(const unsigned s
 }
 #undef SVT_STAGE_X3
 
+// Staggered form of flash_attn_x3_kernel<64, F16, 8> (round 4; see flash_attn_stag_kernel): three stages of { K hi, K lo, V hi, V lo }
+// (96 KiB: one workgroup per CU, as before -- 172 registers), waves 4-7 half a tile behind waves 0-3, LDS-DMA from inline asm, 1-D
+// grid with the query blocks of a (clip, head) on one XCD.  With ONE workgroup per CU the lockstep form had nobody to fill the matrix
+// pipe during the softmax of its eight waves.
+template <bool F16>
+__global__ __launch_bounds__(512) void flash_attn_x3_stag_kernel(const unsigned short* __restrict__ Q, long ldq, long q_bstride, long q_plane,
+                                                                 const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
+                                                                 long ldk, long k_bstride, long k_plane, float* __restrict__ O, long ldo,
+                                                                 long o_bstride, int T, int H, float c, int o_pairs, int nqb) {
+  typedef X3T<F16> X;
+  typedef typename X::v8 v8;
+  constexpr int DH = 64, NW = 8, NST = 3;
+  constexpr int KSD = DH / 16, DB = DH / 32, CPR = DH / 8, RB = 2 * DH;
+  constexpr int TILE16 = 64 * CPR;           // uint4 per tile
+  constexpr int STAGE16 = 4 * TILE16;        // K hi, K lo, V hi, V lo
+  constexpr long STAGE_BYTES = (long)STAGE16 * 16;
+  constexpr long PLANE_BYTES = (long)TILE16 * 16;
+  extern __shared__ __attribute__((aligned(16))) uint4 KV[];   // NST * STAGE16 (96 KiB: dynamic)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = blockIdx.x, BH = (int)gridDim.x / nqb;
+  int bh, qblk;
+  {
+    const int full = (BH / 8) * 8 * nqb;
+    if (L < full) { bh = (L & 7) + 8 * (L / (8 * nqb)); qblk = (L >> 3) % nqb; }
+    else { const int r = L - full; bh = (BH / 8) * 8 + r / nqb; qblk = r % nqb; }
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = qblk * (32 * NW) + wave * 32;
+  const unsigned short* Qb = Q + (long)b * q_bstride + (long)h * DH;
+  const unsigned short* Kb = K + (long)b * k_bstride + (long)h * DH;
+  const unsigned short* Vb = V + (long)b * k_bstride + (long)h * DH;
+  v8 qh[KSD], ql[KSD];
+  {
+    int q = q0 + (lane & 31);
+    if (q > T - 1) q = T - 1;
+    const unsigned short* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {
+      qh[ks] = *(const v8*)(qp + ks * 16);
+      ql[ks] = *(const v8*)(qp + q_plane + ks * 16);
+    }
+  }
+  const int dkey = wave * 8 + lane / CPR;
+  const int slot = lane % CPR;
+  const int kch = (slot ^ ((dkey >> 1) & 7)) * 8;
+  const int vch = (slot ^ (((dkey >> 1) & 1) << 2)) * 8;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(void __attribute__((address_space(3)))*)KV);
+  auto stage_dma = [&](int tile, int stage) {
+    int key = tile * 64 + dkey;
+    if (key > T - 1) key = T - 1;
+    const unsigned short* kp = Kb + (long)key * ldk;
+    const unsigned short* vp = Vb + (long)key * ldk;
+    const unsigned dst = lds0 + (unsigned)((stage * STAGE16 + wave * 64) * 16);
+    attn_dma16(kp + kch, dst);
+    attn_dma16(kp + k_plane + kch, dst + TILE16 * 16);
+    attn_dma16(vp + vch, dst + 2 * TILE16 * 16);
+    attn_dma16(vp + k_plane + vch, dst + 3 * TILE16 * 16);
+  };
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+  const int hh = lane >> 5, kl = lane & 31;
+  const int kg = (kl >> 1) & 7;
+  const int ntiles = (T + 63) / 64;
+  const char* vbase[DB];
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int key0 = 4 * (g >> 1) + q;
+    const int sw = ((q >> 1) & 1) << 2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+      vbase[db] = (const char*)&KV[2 * TILE16] + key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1);
+    }
+  }
+  f32x16 s[2];
+  v8 pfh[2][2], pfl[2][2];
+#define SVT_X3_BAR(J)                                                                                   \
+  {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_s_barrier();                                                                       \
+    if ((J) + 1 < ntiles) stage_dma((J) + 1, st_next);                                                  \
+  }
+#define SVT_X3_S(ST)                                                                                    \
+  {                                                                                                     \
+    const uint4* Kh = KV + (ST) * STAGE16;                                                              \
+    const uint4* Kl = Kh + TILE16;                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;                                    \
+      _Pragma("unroll") for (int ks = 0; ks < KSD; ++ks) {                                              \
+        const int idx = (kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg);                                    \
+        const uint4 kh = Kh[idx], klo = Kl[idx];                                                        \
+        s[kb] = X::mma(klo, qh[ks], s[kb]);                                                             \
+        s[kb] = X::mma(kh, ql[ks], s[kb]);                                                              \
+        s[kb] = X::mma(kh, qh[ks], s[kb]);                                                              \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+#define SVT_X3_SM(TILE)                                                                                 \
+  {                                                                                                     \
+    if (__builtin_expect((TILE) * 64 + 64 > T, 0)) {                                                    \
+      const int kbase = (TILE) * 64 + 4 * hh;                                                           \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);                                     \
+          asm volatile("" : "+v"(s[kb][r]));                                                            \
+          if (key >= T) s[kb][r] = -3e38f;                                                              \
+        }                                                                                               \
+    }                                                                                                   \
+    float mx = fmaxf(s[0][0], s[1][0]);                                                                 \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);             \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;                                                         \
+    if (!__all(mx - m <= 8.0f)) {                                                                       \
+      const float mnew = fmaxf(m, mx);                                                                  \
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);                                             \
+      l *= alpha;                                                                                       \
+      m = mnew;                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < DB; ++i)                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) o[i][r] *= alpha;                                \
+    }                                                                                                   \
+    float sum = 0.f;                                                                                    \
+    unsigned short ph[2][16], pl[2][16];                                                                \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m));                                 \
+        sum += pv;                                                                                      \
+        X::cut(pv, ph[kb][r], pl[kb][r]);                                                               \
+      }                                                                                                 \
+    sum += __shfl_xor(sum, 32, 64);                                                                     \
+    l += sum;                                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                    \
+      _Pragma("unroll") for (int ss = 0; ss < 2; ++ss) {                                                \
+        s16x8 th, tl;                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { th[j] = (short)ph[kb][ss * 8 + j]; tl[j] = (short)pl[kb][ss * 8 + j]; } \
+        pfh[kb][ss] = __builtin_bit_cast(v8, th);                                                       \
+        pfl[kb][ss] = __builtin_bit_cast(v8, tl);                                                       \
+      }                                                                                                 \
+  }
+#define SVT_X3_PV(ST)                                                                                   \
+  {                                                                                                     \
+    _Pragma("unroll") for (int db = 0; db < DB; ++db)                                                   \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                  \
+        _Pragma("unroll") for (int ss = 0; ss < 2; ++ss) {                                              \
+          const char* vp = vbase[db] + (ST) * STAGE_BYTES + (kb * 32 + ss * 16) * RB;                   \
+          const s16x4 hlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));                 \
+          const s16x4 hhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));        \
+          const s16x4 llo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + PLANE_BYTES));   \
+          const s16x4 lhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + PLANE_BYTES + 8 * RB)); \
+          const s16x8 vh = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);                   \
+          const s16x8 vl = __builtin_shufflevector(llo, lhi, 0, 1, 2, 3, 4, 5, 6, 7);                   \
+          o[db] = X::mma(vl, pfh[kb][ss], o[db]);                                                       \
+          o[db] = X::mma(vh, pfl[kb][ss], o[db]);                                                       \
+          o[db] = X::mma(vh, pfh[kb][ss], o[db]);                                                       \
+        }                                                                                               \
+  }
+  stage_dma(0, 0);
+  int st = 0;
+  if (wave < 4) {
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int st_next = st + 1 == NST ? 0 : st + 1;
+      SVT_X3_BAR(tile)
+      SVT_X3_S(st)
+      SVT_X3_SM(tile)
+      SVT_X3_PV(st)
+      st = st_next;
+    }
+  } else {
+    {
+      const int st_next = 1;
+      SVT_X3_BAR(0)
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int st1 = st + 1 == NST ? 0 : st + 1;
+      SVT_X3_S(st)
+      SVT_X3_SM(tile)
+      if (tile + 1 < ntiles) {
+        const int st_next = st1 + 1 == NST ? 0 : st1 + 1;
+        SVT_X3_BAR(tile + 1)
+      }
+      SVT_X3_PV(st)
+      st = st1;
+    }
+  }
+#undef SVT_X3_BAR
+#undef SVT_X3_S
+#undef SVT_X3_SM
+#undef SVT_X3_PV
+  const int q = q0 + (lane & 31);
+  if (q >= T) return;
+  const float inv = 1.f / l;
+  float* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+  if (o_pairs) {
+    char* pp = (char*)op;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned hx[2][2], lx[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          unsigned short ph_[4], pl_[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) X::cut(o[db][(g + u) * 4 + j] * inv, ph_[j], pl_[j]);
+          hx[u][0] = (unsigned)ph_[0] | ((unsigned)ph_[1] << 16); hx[u][1] = (unsigned)ph_[2] | ((unsigned)ph_[3] << 16);
+          lx[u][0] = (unsigned)pl_[0] | ((unsigned)pl_[1] << 16); lx[u][1] = (unsigned)pl_[2] | ((unsigned)pl_[3] << 16);
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const auto rh = __builtin_amdgcn_permlane32_swap(hx[0][w], hx[1][w], false, false);
+          hx[0][w] = rh[0]; hx[1][w] = rh[1];
+          const auto rl = __builtin_amdgcn_permlane32_swap(lx[0][w], lx[1][w], false, false);
+          lx[0][w] = rl[0]; lx[1][w] = rl[1];
+        }
+        char* d = pp + db * 128 + (8 * (g + hh)) * 2;
+        *(uint4*)d = uint4{hx[0][0], hx[0][1], hx[1][0], hx[1][1]};
+        *(uint4*)(d + 64) = uint4{lx[0][0], lx[0][1], lx[1][0], lx[1][1]};
+      }
+    return;
+  }
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+      *(float4*)(op + db * 32 + 8 * g + 4 * hh) = v;
+    }
+}
+
 // fp32 (rows, cols) with row pitch ld_src -> 16-bit (hi, lo) planes (rows, cols) with row pitch ld_dst, lo plane `plane`
 // elements after the hi plane; cols % 4 == 0
 template <bool F16>
@@ -599,7 +1055,21 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   const unsigned short *q = (const unsigned short*)Q, *k = (const unsigned short*)K, *v = (const unsigned short*)V;
   prof_begin(s);
 #define SVT_X3_LAUNCH(DH_, F16_, NW_) hipLaunchKernelGGL((flash_attn_x3_kernel<DH_, F16_, NW_>), grid, dim3(64 * NW_), 0, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O, ldo, o_bstride, T, H, c, o_pairs)
-  if (dh == 64 && wide) { if (kind == 3) SVT_X3_LAUNCH(64, true, 8); else SVT_X3_LAUNCH(64, false, 8); }
+  if (dh == 64 && wide && g_attn_variant == 0) {
+    const int nqb = (T + 255) / 256;
+    const int lds_bytes = 3 * 4 * 512 * 16;   // three stages of four 8 KiB tiles
+    const dim3 g1((unsigned)(nqb * B * H));
+    if (kind == 3) {
+      if (int r_ = ensure_dyn_lds((const void*)flash_attn_x3_stag_kernel<true>, lds_bytes)) return r_;
+      hipLaunchKernelGGL((flash_attn_x3_stag_kernel<true>), g1, dim3(512), lds_bytes, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O,
+                         ldo, o_bstride, T, H, c, o_pairs, nqb);
+    } else {
+      if (int r_ = ensure_dyn_lds((const void*)flash_attn_x3_stag_kernel<false>, lds_bytes)) return r_;
+      hipLaunchKernelGGL((flash_attn_x3_stag_kernel<false>), g1, dim3(512), lds_bytes, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O,
+                         ldo, o_bstride, T, H, c, o_pairs, nqb);
+    }
+  }
+  else if (dh == 64 && wide) { if (kind == 3) SVT_X3_LAUNCH(64, true, 8); else SVT_X3_LAUNCH(64, false, 8); }
   else if (dh == 64) { if (kind == 3) SVT_X3_LAUNCH(64, true, 4); else SVT_X3_LAUNCH(64, false, 4); }
   else if (dh == 128) { if (kind == 3) SVT_X3_LAUNCH(128, true, 4); else SVT_X3_LAUNCH(128, false, 4); }
   else { set_error("flash_attention_x3: head_dim must be 64 or 128"); return -1; }
@@ -609,6 +1079,7 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   return 0;
 }
 
+int g_attn_variant = 0;   // svt_debug_set key 21 (A/B of the softmax arithmetic of the 8-wave head_dim-64 kernel)
 int g_attn_stamp = 0;  // svt_debug_set key 18: tile stamps of the 8-wave head_dim-64 kernel (tools/attn_bench.py --stamps)
 int g_flash_wide = 1;  // svt_debug_set key 8: 1 = 8-wave (256-query) workgroups where they pay, 0 = 4-wave ones.  (Round 3: four-wave workgroups held to
                        // three per CU by 16 KiB of unused LDS -- 1 536 workgroups = exactly two rounds instead of 1.5 -- measured 51.1 against 48.5 us
@@ -651,7 +1122,13 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else
 #endif
-  if (dh == 64 && wide)
+  if (dh == 64 && wide && g_attn_variant == 0) {
+    // staggered form (flash_attn_stag_kernel): three K / V stages, waves 4-7 half a tile behind waves 0-3
+    const int nqb = (T + 255) / 256;
+    hipLaunchKernelGGL((flash_attn_stag_kernel<64>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
+  }
+  else if (dh == 64 && wide)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else if (dh == 64)

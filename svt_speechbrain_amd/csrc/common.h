@@ -266,6 +266,7 @@ extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diag
 extern int g_stamp_ends;
 extern int g_pps_half_barriers;
 extern int g_attn_stamp;
+extern int g_attn_variant;
 extern int g_gemm_dbg;   // diagnostic variant applied to every launch (svt_debug_set)
 extern int g_gemm_force_bm;
 extern int g_gemm_ring;

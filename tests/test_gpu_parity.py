@@ -3,6 +3,8 @@
 reference.  Tolerances: fp32 parity mode — logits within 1e-3 (north star) and identical per-frame
 argmax / note sequences; bf16 throughput mode — reported error bound + decode agreement rate."""
 import hashlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -110,8 +112,9 @@ def simulated_error(name, fx, mode):
     measured figures: a change of summation order inside a kernel moves near-tie frames without being a regression."""
     key = (name, mode)
     if key not in _SIM_CACHE:
-        import sys
-        sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+        tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+        if tools not in sys.path:
+            sys.path.insert(0, tools)
         import sim_split
         _SIM_CACHE[key] = sim_split.simulate(fx, mode)
     return _SIM_CACHE[key]

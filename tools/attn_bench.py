@@ -18,17 +18,26 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--wide", type=int, default=None, help="svt_debug_set key 8 (workgroup shape / occupancy experiments of the fused attention)")
+    ap.add_argument("--H", type=int, default=None, help="override the number of heads (workgroups per launch: occupancy / rounds experiments)")
+    ap.add_argument("--T", type=int, default=None, help="override the sequence length of every shape (fixed cost vs per-key-tile cost)")
+    ap.add_argument("--variant", type=int, default=None, help="svt_debug_set key 21 (A/B of the softmax arithmetic of the 8-wave head_dim-64 kernel)")
     ap.add_argument("--stamps", action="store_true", help="tile stamps of the 8-wave head_dim-64 kernel (svt_debug_set key 18): where a wave's "
                     "time goes inside key tile 4")
     a = ap.parse_args()
     lib = _lib.load()
     if a.wide is not None:
         lib.svt_debug_set(8, a.wide)
+    if a.variant is not None:
+        lib.svt_debug_set(21, a.variant)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     for name, B, T, H, dh in SHAPES:
         if a.only and a.only not in name:
             continue
+        if a.T:
+            T = a.T
+        if a.H:
+            H = a.H
         D = H * dh
         g = torch.Generator().manual_seed(3)
         qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.5).to(dev, torch.bfloat16)
