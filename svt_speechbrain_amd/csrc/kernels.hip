@@ -201,7 +201,17 @@ __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const TI* x, con
     const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
     float o0 = fmaf(v[4 * j] * rstd, g.x, b.x), o1 = fmaf(v[4 * j + 1] * rstd, g.y, b.y);
     float o2 = fmaf(v[4 * j + 2] * rstd, g.z, b.z), o3 = fmaf(v[4 * j + 3] * rstd, g.w, b.w);
-    if (gelu) { o0 = gelu_erf(o0); o1 = gelu_erf(o1); o2 = gelu_erf(o2); o3 = gelu_erf(o3); }
+    if (gelu) {
+      if (sizeof(TO) == 2 && PK == 0 && !yF) {
+        // results stored ONLY in 16 bits (the conv stack of the layer-norm extractor in the throughput modes): the polynomial GELU of the GEMM
+        // epilogues (common.h) -- with the exact-erf form (rcp + exp: quarter-rate instructions) this pass ran at 3.7 TB/s, VALU-bound
+        f32x2_t ga = {o0, o1}, gb = {o2, o3};
+        ga = gelu_bf16x2(ga); gb = gelu_bf16x2(gb);
+        o0 = ga.x; o1 = ga.y; o2 = gb.x; o3 = gb.y;
+      } else {
+        o0 = gelu_erf(o0); o1 = gelu_erf(o1); o2 = gelu_erf(o2); o3 = gelu_erf(o3);
+      }
+    }
     if (yT) {
       if constexpr (sizeof(TO) == 2) {
         bf16x4 o;
@@ -266,6 +276,53 @@ __global__ __launch_bounds__(256) void layernorm_hilo_kernel(const bf16_t* branc
 }
 
 // fp32 -> (hi, lo) bf16 pair with a LayerNorm in front (first LN of the post-LN encoder): x fp32 in
+// LayerNorm (+ GELU) over rows stored in the 16-bit operand type, half a wave per row, 16-byte accesses: the conv stack of the
+// layer-norm extractor in the throughput modes normalises the conv GEMM's output in place (2 bytes read + 2 written per element; with
+// a wave per row and 8-byte accesses the pass ran at 3.8 TB/s).
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_op16_rows2_kernel(const bf16_t* x, int64_t rows, const float* gamma, const float* beta,
+                                                                   float eps, int gelu, bf16_t* y) {
+  constexpr int NC = D / 256;
+  const int lane = threadIdx.x & 63, sub = lane & 31;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
+  if (row >= rows) return;
+  float v[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const bf16x8 h = *(const bf16x8*)(x + row * D + (sub + 32 * j) * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[j][i] = (float)h[i];
+    s += ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) + ((v[j][4] + v[j][5]) + (v[j][6] + v[j][7]));
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[j][i] -= mean; q = fmaf(v[j][i], v[j][i], q); }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q * (1.f / D) + eps);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = (sub + 32 * j) * 8;
+    const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
+    const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    f32x2_t o2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o2[i] = f32x2_t{fmaf(v[j][2 * i] * rstd, gg[2 * i], bb[2 * i]), fmaf(v[j][2 * i + 1] * rstd, gg[2 * i + 1], bb[2 * i + 1])};
+    if (gelu) gelu_bf16x2_x4(o2);
+    bf16x8 ob;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ob[2 * i] = (bf16_t)o2[i].x; ob[2 * i + 1] = (bf16_t)o2[i].y; }
+    *(bf16x8*)(y + row * D + c) = ob;
+  }
+}
+
 // Two rows per wave (round 4): a HALF-wave owns a row and every access is 16 bytes (8 bf16 per lane), so a 768-wide row is three
 // accesses per stream and lane instead of three 8-byte ones over twice the lanes, and the two reductions run over five exchange steps
 // instead of six: 23.2 -> 20.5 us per pass at 32 x 10 s (HBM-bound: the same bytes at a higher achieved rate).  The sums are taken in a
@@ -1407,6 +1464,7 @@ int launch_global_norm(const float* x, float* y, int64_t n, const double* moment
   return 0;
 }
 
+int g_ln_two_rows = 1;   // svt_debug_set key 20: 0 = one row per wave in the (hi, lo) and 16-bit-row LayerNorms (A/B)
 int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D, const float* gamma,
                      const float* beta, float eps, int gelu, void* yT, float* yF, hipStream_t s, const float* add,
                      float* sumF, void* yP, int pair_kind, const void* addP) {
@@ -1433,6 +1491,16 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
     else if (D == 768) SVT_LN_PAIRS(12);
     else SVT_LN_PAIRS(16);
 #undef SVT_LN_PAIRS
+    SVT_LAUNCH_CHECK();
+    return 0;
+  }
+  if (prec && !x_is_f32 && (D == 512 || D == 768 || D == 1024) && yT && !yF && !add && !sumF && g_ln_two_rows && !((uintptr_t)x & 15) &&
+      !((uintptr_t)yT & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15)) {
+    // 16-bit rows in, 16-bit rows out (in place for the conv stack of the layer-norm extractor): half a wave per row
+    const dim3 grid2((unsigned)((rows + 7) / 8)), block(256);
+    if (D == 512) hipLaunchKernelGGL((layernorm_op16_rows2_kernel<512>), grid2, block, 0, s, (const bf16_t*)x, rows, gamma, beta, eps, gelu, (bf16_t*)yT);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_op16_rows2_kernel<768>), grid2, block, 0, s, (const bf16_t*)x, rows, gamma, beta, eps, gelu, (bf16_t*)yT);
+    else hipLaunchKernelGGL((layernorm_op16_rows2_kernel<1024>), grid2, block, 0, s, (const bf16_t*)x, rows, gamma, beta, eps, gelu, (bf16_t*)yT);
     SVT_LAUNCH_CHECK();
     return 0;
   }
@@ -1489,7 +1557,6 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
 
 bool layernorm_hilo_ok(int D) { return D == 512 || D == 768 || D == 1024; }
 // branch == nullptr && x32 != nullptr: y = LN(x32);  otherwise y = LN(branch + rh + rl)
-int g_ln_two_rows = 1;   // svt_debug_set key 20: 0 = the one-row-per-wave (hi, lo) LayerNorm (A/B)
 int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
                           const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);

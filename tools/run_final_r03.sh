@@ -1,5 +1,9 @@
+#!/bin/bash
+# (historical: how profiles/r03_* were produced; the round-4 set is tools/run_final_r04.sh)
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?run under gpurun}"
 # round-3 measurement set -> gpurun_out/r03_final (copied into profiles/ afterwards)
-cd $GRAFT_REPO_ROOT
+cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03_final
 mkdir -p $O
 (time python -m pytest tests -q -m gpu -x 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -6) > $O/r03_gputests.log 2>&1
@@ -23,12 +27,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_f16 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-legs --streams 1 --precision fp16 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_x3 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-legs --streams 1 --precision fp16x3 --steps 5 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_c3 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-legs --streams 1 --model hubert-large-ll60k --batch 64 --steps 5 --warmup 2 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
+cd "$GRAFT_REPO_ROOT"
 bash tools/pmc.sh r03_final/pmc_fetch FETCH_SIZE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
 bash tools/pmc.sh r03_final/pmc_write WRITE_SIZE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
 bash tools/pmc.sh r03_final/pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --streams 1
 bash tools/pmc.sh r03_final/pmc_mfma_x3 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --streams 1 --precision fp16x3
-cd $GRAFT_REPO_ROOT
+cd "$GRAFT_REPO_ROOT"
 python tools/trace_summary.py $O/prof_s1 43 > $O/r03_bench_kernel_trace_summary.txt
 python tools/trace_summary.py $O/prof_s2 43 > $O/r03_bench_2streams_kernel_trace_summary.txt
 python tools/trace_summary.py $O/prof_f16 43 > $O/r03_bench_fp16_kernel_trace_summary.txt
