@@ -47,7 +47,7 @@ import torch  # noqa: E402
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
 
 
 def synth_wav(B, L, seed=1986):
@@ -597,9 +597,9 @@ def main():
                                                    "norm_all_reduce": "2 x 16 B per step (global-batch norms)" if args.global_norm else None},
             "per_rank_clips_per_s": [round(B * args.steps / t, 3) for t in res["elapsed_per_rank"]],
             "roofline": {"bound": "mfma",
-                         "kernel": ("svt::gemm_x3p_kernel / gemm_x3s_kernel (LDS-DMA split-operand products: fp32 activations cut into 16-bit (hi, lo) "
-                                    "pieces in the kernel, pre-cut weight pieces, three MFMAs per 16x16x32 block; staggered 8-slot schedule, "
-                                    "persistent for the GELU launches)") if split else
+                         "kernel": ("svt::gemm_x3q_kernel <BM=128|192|256> (split-operand products on pair rows: activations AND weights pre-cut into "
+                                    "16-bit (hi, lo) pieces by their producers, hi*hi + hi*lo + lo*hi = three MFMAs per 16x16x32 block on the persistent "
+                                    "staggered schedule of gemm_pps_kernel); gemm_x3s_kernel for the batched positional conv") if split else
                                    ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, staggered schedule: persistent "
                                     "stream of tiles per CU; one tile per workgroup for the batched positional conv)"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -468,7 +468,8 @@ int svt_debug_gemm_pairs(int32_t precision, const float* a, int64_t a_elems, con
                          int32_t n, int32_t k, int32_t a_rpb, int64_t a_bstride, int64_t a_rstride, int32_t act, int32_t out_kind,
                          int device, void* stream, int32_t time_iters, float* ms_out) {
   if (!a || !w || !c) { set_error("svt_debug_gemm_pairs: null argument"); return SVT_ERR_INVALID; }
-  if (precision != SVT_PREC_BF16X3 && precision != SVT_PREC_FP16X3) { set_error("svt_debug_gemm_pairs: split-operand precisions only"); return SVT_ERR_INVALID; }
+  if ((precision != SVT_PREC_BF16X3 && precision != SVT_PREC_FP16X3) || !valid_precision(precision)) {
+    set_error("svt_debug_gemm_pairs: split-operand precisions only (they live in libsvt_mi355.so, not in the IEEE-half build)"); return SVT_ERR_INVALID; }
   if (out_kind < 0 || out_kind > 2 || a_elems % 32 || ((int64_t)m * n) % 32) { set_error("svt_debug_gemm_pairs: out_kind / sizes"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;

@@ -24,6 +24,14 @@
 // no residual, activation none or GELU, fp32 C or (hi, lo) planes.  Everything else stays on gemm_x3s_kernel.
 #include "common.h"
 
+#ifdef SVT_OPERAND_F16
+// The split-operand engines live in the bf16 build only (libsvt_mi355.so): precision codes 2 / 3 are rejected by the IEEE-half build.
+namespace svt {
+bool gemm_x3p_eligible(const GemmArgs&) { return false; }
+int launch_gemm_x3p(int, const GemmArgs&, const void*, hipStream_t) { set_error("gemm_x3p: not part of the IEEE-half build"); return -1; }
+}  // namespace svt
+#else
+
 namespace svt {
 namespace {
 
@@ -438,3 +446,4 @@ int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t
 }
 
 }  // namespace svt
+#endif  // SVT_OPERAND_F16

@@ -27,6 +27,14 @@
 // K >= 64, N % 256 == 0, M >= 128.  Everything else stays on gemm_x3s_kernel / the register-staged split kernel, which cut fp32 rows.
 #include "common.h"
 
+#ifdef SVT_OPERAND_F16
+// The split-operand engines live in the bf16 build only (libsvt_mi355.so): precision codes 2 / 3 are rejected by the IEEE-half build.
+namespace svt {
+bool gemm_x3q_eligible(const GemmArgs&) { return false; }
+int launch_gemm_x3q(int, const GemmArgs&, const void*, int, hipStream_t) { set_error("gemm_x3q: not part of the IEEE-half build"); return -1; }
+}  // namespace svt
+#else
+
 namespace svt {
 namespace {
 
@@ -389,3 +397,4 @@ int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hip
 }
 
 }  // namespace svt
+#endif  // SVT_OPERAND_F16
