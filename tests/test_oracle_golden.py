@@ -55,7 +55,7 @@ def test_oracle_tiny(golden, name):
         assert notes == d["notes"]
 
 
-@pytest.mark.parametrize("name", ["base_c1", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"])
+@pytest.mark.parametrize("name", ["base_c1", "base_b2", "large_c1", "hubert_large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"])
 def test_oracle_full_size(golden, name):
     fx = golden(name)
     torch.set_num_threads(8)
