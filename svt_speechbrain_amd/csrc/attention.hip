@@ -314,7 +314,11 @@ __device__ __forceinline__ void attn_dma16(const void* gsrc, unsigned lds_byte_a
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int DH>
+// PIPE (experiment, built by make DIAG=1 only; svt_debug_set(21, 2)): the P V product of tile j - 1 issued BEHIND the S MFMAs of tile j
+// and in front of tile j's softmax, so that inside one wave the matrix pipe works through 8 PV MFMAs while the wave issues the softmax's
+// vector instructions; no second accumulator set is needed (P of the previous tile and S of this one coexist anyway, V of tile j - 1 is
+// still in its stage).  Measured SLOWER than the plain staggered order: 43.0-43.9 against 41.0-42.1 us at C2, 115-118 against 109-114 at C3.
+template <int DH, bool PIPE = false>
 __global__ __launch_bounds__(512) void flash_attn_stag_kernel(const bf16_t* __restrict__ Q, long ldq, long q_bstride,
                                                               const bf16_t* __restrict__ K, long ldk, long k_bstride,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, long ldo,
@@ -462,6 +466,44 @@ __global__ __launch_bounds__(512) void flash_attn_stag_kernel(const bf16_t* __re
 
   stage_dma(0, 0);
   int st = 0;   // stage of the tile being multiplied
+  if constexpr (PIPE) {
+    int st_prev = 0;
+    if (wave < 4) {
+      for (int tile = 0; tile < ntiles; ++tile) {
+        const int st_next = st + 1 == NST ? 0 : st + 1;
+        SVT_AT_BAR(tile)
+        SVT_AT_S(st)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile > 0) SVT_AT_PV(st_prev)
+        __builtin_amdgcn_sched_barrier(0);
+        SVT_AT_SM(tile)
+        __builtin_amdgcn_sched_barrier(0);
+        st_prev = st;
+        st = st_next;
+      }
+    } else {
+      {
+        const int st_next = 1;
+        SVT_AT_BAR(0)
+      }
+      for (int tile = 0; tile < ntiles; ++tile) {
+        const int st1 = st + 1 == NST ? 0 : st + 1;
+        SVT_AT_S(st)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile > 0) SVT_AT_PV(st_prev)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + 1 < ntiles) {
+          const int st_next = st1 + 1 == NST ? 0 : st1 + 1;   // stage of tile + 2 (= the stage tile - 1 has just left)
+          SVT_AT_BAR(tile + 1)
+        }
+        SVT_AT_SM(tile)
+        __builtin_amdgcn_sched_barrier(0);
+        st_prev = st;
+        st = st1;
+      }
+    }
+    SVT_AT_PV(st_prev)
+  } else
   if (wave < 4) {
     for (int tile = 0; tile < ntiles; ++tile) {
       const int st_next = st + 1 == NST ? 0 : st + 1;
@@ -1125,9 +1167,16 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   if (dh == 64 && wide && g_attn_variant == 0) {
     // staggered form (flash_attn_stag_kernel): three K / V stages, waves 4-7 half a tile behind waves 0-3
     const int nqb = (T + 255) / 256;
-    hipLaunchKernelGGL((flash_attn_stag_kernel<64>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+    hipLaunchKernelGGL((flash_attn_stag_kernel<64, false>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
   }
+#ifdef SVT_DIAG
+  else if (dh == 64 && wide && g_attn_variant == 2) {   // PIPE form (measured slower: 43.0-43.9 against 41.0-42.1 us at C2), make DIAG=1
+    const int nqb = (T + 255) / 256;
+    hipLaunchKernelGGL((flash_attn_stag_kernel<64, true>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
+  }
+#endif
   else if (dh == 64 && wide)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
