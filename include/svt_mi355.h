@@ -286,7 +286,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * kernel on/off (off: the register-staged one), 12 = svt_debug_gemm keeps the split copy of its weight between calls,
  * 13 = page-guarded device allocations (see svt_debug_alloc), 19 = split-operand modes keep product operands as pair rows written by
  * their producers (1, default) or as fp32 cut inside the product kernels (0: the round-2/3 path, A/B), 20 = (hi, lo) LayerNorm with two
- * rows per wave (1, default) or one (0).
+ * rows per wave (1, default) or one (0), 21 = fused attention variant (0 = staggered wave groups, 1 = the round-3 lockstep kernel),
+ * 22 = conv layer 0 on the matrix pipe in the 16-bit modes (1, default) or on the vector ALU (0).
  * Returns 0. */
 int svt_debug_set(int key, int value);
 

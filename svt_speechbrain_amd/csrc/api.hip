@@ -556,6 +556,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 19) g_x3_pairs = value;
   else if (key == 20) g_ln_two_rows = value;
   else if (key == 21) g_attn_variant = value;
+  else if (key == 22) g_conv0_mfma = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -874,6 +875,7 @@ struct EncWs {
   double* mom;      // [0..1] wav, [2..3] out, [4 ..] window moments B*65
   size_t mom_bytes;
   float* coef;
+  void* c0tab;      // conv layer 0 on the matrix pipe: weight-side tables (32 KiB per clip), 16-bit modes
   void* act[2];
   float* convF;     // fp32 pre-LN conv output (layer mode)
   void* xln;
@@ -903,6 +905,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.mom_bytes = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments
   w.mom = (double*)cv.take(w.mom_bytes);
   w.coef = (float*)cv.take((size_t)B * c.conv_dim[0] * 11 * 4);
+  w.c0tab = sp ? cv.take(conv0_mfma_table_bytes(B)) : nullptr;
   size_t max_act = 0, max_f = 0;
   int64_t t = L;
   for (int i = 0; i < c.num_conv_layers; ++i) {
@@ -1105,9 +1108,17 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     if (int r = launch_conv0_group_coef(wav_mom, n_wav, wm, B, t1, c.conv_dim[0], c.conv_kernel[0], c0.w.as<float>(),
                                         c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
                                         c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s, cpg)) return r;
+    if (conv0_mfma_ok(prec, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
+      if (int r = launch_conv0_mfma_group(wav, B, L, c.conv_stride[0], t1, w.coef, w.c0tab, w.act[0], s)) return r;
+    } else
     if (int r = launch_conv0_group_apply(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], w.coef,
                                          w.act[0], s, pk_front)) return r;
   } else {
+    if (conv0_mfma_ok(prec, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
+      if (int r = launch_conv0_mfma_layer(wav, B, L, c.conv_stride[0], t1, wav_mom, n_wav, 1e-5f, c0.w.as<float>(),
+                                          c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f,
+                                          w.c0tab, w.act[0], s, cpg)) return r;
+    } else
     if (int r = launch_conv0_layer(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], wav_mom, n_wav,
                                    1e-5f, c0.w.as<float>(), c.conv_bias ? c0.bias.as<float>() : nullptr,
                                    c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f, w.act[0], s, cpg, pk_front)) return r;
