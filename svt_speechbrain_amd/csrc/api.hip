@@ -905,7 +905,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.mom_bytes = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments
   w.mom = (double*)cv.take(w.mom_bytes);
   w.coef = (float*)cv.take((size_t)B * c.conv_dim[0] * 11 * 4);
-  w.c0tab = sp ? cv.take(conv0_mfma_table_bytes(B)) : nullptr;
+  w.c0tab = (sp || c.precision >= 2) ? cv.take(conv0_mfma_table_bytes(B)) : nullptr;
   size_t max_act = 0, max_f = 0;
   int64_t t = L;
   for (int i = 0; i < c.num_conv_layers; ++i) {
@@ -1108,16 +1108,16 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     if (int r = launch_conv0_group_coef(wav_mom, n_wav, wm, B, t1, c.conv_dim[0], c.conv_kernel[0], c0.w.as<float>(),
                                         c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
                                         c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s, cpg)) return r;
-    if (conv0_mfma_ok(prec, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
-      if (int r = launch_conv0_mfma_group(wav, B, L, c.conv_stride[0], t1, w.coef, w.c0tab, w.act[0], s)) return r;
+    if (conv0_mfma_ok(prec, pk_front, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
+      if (int r = launch_conv0_mfma_group(wav, B, L, c.conv_stride[0], t1, w.coef, w.c0tab, w.act[0], s, pk_front)) return r;
     } else
     if (int r = launch_conv0_group_apply(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], w.coef,
                                          w.act[0], s, pk_front)) return r;
   } else {
-    if (conv0_mfma_ok(prec, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
+    if (conv0_mfma_ok(prec, pk_front, c.conv_kernel[0], c.conv_stride[0], c.conv_dim[0]) && w.c0tab) {
       if (int r = launch_conv0_mfma_layer(wav, B, L, c.conv_stride[0], t1, wav_mom, n_wav, 1e-5f, c0.w.as<float>(),
                                           c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(), c0.beta.as<float>(), 1e-5f,
-                                          w.c0tab, w.act[0], s, cpg)) return r;
+                                          w.c0tab, w.act[0], s, cpg, pk_front)) return r;
     } else
     if (int r = launch_conv0_layer(prec, wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, c.conv_dim[0], wav_mom, n_wav,
                                    1e-5f, c0.w.as<float>(), c.conv_bias ? c0.bias.as<float>() : nullptr,

@@ -322,13 +322,13 @@ int launch_conv0_layer(int prec, const float* wav, int B, int64_t L, int k, int 
                        int pair_kind = 0);
 
 // conv layer 0 on the matrix pipe (conv0_mfma.hip; 16-bit throughput modes, k = 10, C = 512): table_ws = conv0_mfma_table_bytes(B) bytes
-bool conv0_mfma_ok(int prec, int k, int stride, int C);
+bool conv0_mfma_ok(int prec, int pair_kind, int k, int stride, int C);   // prec 1 (16-bit rows out) or pair_kind 2 / 3 (split modes: pair rows out)
 size_t conv0_mfma_table_bytes(int B);
 int launch_conv0_mfma_group(const float* wav, int B, int64_t L, int stride, int64_t T1, const float* coef, void* table_ws, void* out,
-                            hipStream_t s);
+                            hipStream_t s, int pair_kind = 0);
 int launch_conv0_mfma_layer(const float* wav, int B, int64_t L, int stride, int64_t T1, const double* wav_moments, int64_t n_wav,
                             float eps_wav, const float* w0, const float* b0, const float* gamma, const float* beta, float eps, void* table_ws,
-                            void* out, hipStream_t s, int clips_per_norm_group);
+                            void* out, hipStream_t s, int clips_per_norm_group, int pair_kind = 0);
 extern int g_conv0_mfma;
 
 // positional-conv operand: (B,T,D) fp32 -> (B, G, T + kp, D/G) operand type, zero padded by kp/2 in front

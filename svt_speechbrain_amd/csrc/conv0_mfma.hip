@@ -25,9 +25,51 @@ namespace {
 
 constexpr int K0 = 10, C0 = 512, TBL16 = 2048;   // uint4 per table (32 KiB)
 
+// PK = 0: the build's 16-bit operand type, 16-bit rows out, polynomial GELU (throughput modes);
+// PK = 2 / 3 (split modes, fp32-grade): bf16 / IEEE-half pieces, output written as PAIR ROWS ([32 hi | 32 lo] per 32 channels, the
+// operand layout of gemm_x3q_kernel), exact-erf GELU -- the taps then carry the same 2^-17 / 2^-22 relative error as every other
+// product of those modes.
+template <int PK> struct C0T { typedef bf16_t piece; };
+template <> struct C0T<2> { typedef __bf16 piece; };
+template <> struct C0T<3> { typedef _Float16 piece; };
+template <int PK> __device__ __forceinline__ f32x4 c0_mma(const typename C0T<PK>::piece __attribute__((ext_vector_type(8))) & a, const uint4& b, const f32x4& c) {
+  typedef typename C0T<PK>::piece P;
+  typedef P P8 __attribute__((ext_vector_type(8)));
+  if constexpr (PK == 3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(P8, b), c, 0, 0, 0);
+  else if constexpr (PK == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(P8, b), c, 0, 0, 0);
+  else return SVT_MFMA_16x16x32(a, __builtin_bit_cast(P8, b), c);
+}
+// 8 consecutive channels of one frame: 16-bit row (PK = 0) or pair row (PK = 2 / 3: e = element index of the first channel)
+template <int PK> __device__ __forceinline__ void c0_store8(void* out, int64_t e, f32x2_t (&p)[4]) {
+  typedef typename C0T<PK>::piece P;
+  typedef P P8 __attribute__((ext_vector_type(8)));
+  if constexpr (PK == 0) {
+    gelu_bf16x2_x4(p);
+    P8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = (P)p[i].x; o[2 * i + 1] = (P)p[i].y; }
+    *(P8*)((P*)out + e) = o;
+  } else {
+    P8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2_t y = gelu_fast2(p[i]);
+      hi[2 * i] = (P)y.x; lo[2 * i] = (P)(y.x - (float)hi[2 * i]);
+      hi[2 * i + 1] = (P)y.y; lo[2 * i + 1] = (P)(y.y - (float)hi[2 * i + 1]);
+    }
+    char* d = (char*)out + (e >> 5) * 128 + (e & 31) * 2;
+    *(P8*)d = hi;
+    *(P8*)(d + 64) = lo;
+  }
+}
+
 // table[(clip,) block = q * 8 + nb][lane][8]: lane (g = lane >> 4, j = lane & 15) holds k = 8 g .. 8 g + 7 of channel 128 q + 8 j + nb
+template <int PK>
 __global__ void conv0_table_kernel(const float* __restrict__ w, long w_clip_stride, int w_row, const float* __restrict__ bias,
-                                   bf16_t* __restrict__ table) {
+                                   void* __restrict__ table_) {
+  typedef typename C0T<PK>::piece bf16_t;   // (shadows the build's operand type inside this kernel)
+  typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+  bf16_t* table = (bf16_t*)table_;
   const int b = blockIdx.y;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= TBL16) return;
@@ -47,12 +89,15 @@ __global__ void conv0_table_kernel(const float* __restrict__ w, long w_clip_stri
   *(bf16x8*)(table + ((long)b * TBL16 + idx) * 8) = o;
 }
 
-template <int MODE>   // 0 = GroupNorm form (per-clip coefficient table, GELU), 1 = LayerNorm form (shared table, LayerNorm over channels, GELU)
+template <int MODE, int PK = 0>   // MODE 0 = GroupNorm form (per-clip coefficient table, GELU), 1 = LayerNorm form (shared table, LayerNorm over channels, GELU)
 __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ wav, int64_t L, int stride, int64_t T1,
-                                                         const bf16_t* __restrict__ table, long table_clip_stride,
+                                                         const void* __restrict__ table_, long table_clip_stride,
                                                          const double* __restrict__ wav_mom, int64_t n_wav, float eps_wav,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int cpg,
-                                                         bf16_t* __restrict__ out) {
+                                                         void* __restrict__ out) {
+  typedef typename C0T<PK>::piece bf16_t;   // piece type of this instantiation
+  typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+  const bf16_t* table = (const bf16_t*)table_;
   constexpr int FPW = 64;   // frames per wave
   __shared__ __attribute__((aligned(16))) uint4 tbl[TBL16];
   __shared__ float xs[4][FPW * 5 + 16];
@@ -103,7 +148,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
       a = g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
     }
     // this lane's output frames: 4 g + r of the chunk; channels 128 q + 8 j .. + 7
-    bf16_t* orow = out + (((int64_t)b * T1 + t0 + chunk * 16 + 4 * g) * C0 + 8 * j);
+    const int64_t e0 = ((int64_t)b * T1 + t0 + chunk * 16 + 4 * g) * C0 + 8 * j;   // element index of (frame 4 g of the chunk, channel 8 j)
     const int fr0 = chunk * 16 + 4 * g;
     if constexpr (MODE == 0) {
 #pragma unroll 1
@@ -112,18 +157,14 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
           acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[nb] = SVT_MFMA_16x16x32(a, __builtin_bit_cast(bf16x8, tbl[(q * 8 + nb) * 64 + lane]), acc[nb]);
+          acc[nb] = c0_mma<PK>(a, tbl[(q * 8 + nb) * 64 + lane], acc[nb]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f32x2_t p[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) p[i] = f32x2_t{acc[2 * i][r], acc[2 * i + 1][r]};
-          gelu_bf16x2_x4(p);
-          bf16x8 o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { o[2 * i] = (bf16_t)p[i].x; o[2 * i + 1] = (bf16_t)p[i].y; }
-          if (fr0 + r < nfr) *(bf16x8*)(orow + (int64_t)r * C0 + 128 * q) = o;
+          if (fr0 + r < nfr) c0_store8<PK>(out, e0 + (int64_t)r * C0 + 128 * q, p);
         }
       }
     } else {
@@ -131,7 +172,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 #pragma unroll
       for (int blk = 0; blk < 32; ++blk) {
         acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[blk] = SVT_MFMA_16x16x32(a, __builtin_bit_cast(bf16x8, tbl[blk * 64 + lane]), acc[blk]);
+        acc[blk] = c0_mma<PK>(a, tbl[blk * 64 + lane], acc[blk]);
       }
       // LayerNorm statistics of the lane's four frames: 32 channels in registers, the other 480 in the 15 lanes with the same g
       float mean[4], rstd[4];
@@ -166,11 +207,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
           for (int i = 0; i < 4; ++i)
             p[i] = f32x2_t{fmaf((acc[q * 8 + 2 * i][r] - mean[r]) * rstd[r], gg[2 * i], bb[2 * i]),
                            fmaf((acc[q * 8 + 2 * i + 1][r] - mean[r]) * rstd[r], gg[2 * i + 1], bb[2 * i + 1])};
-          gelu_bf16x2_x4(p);
-          bf16x8 o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { o[2 * i] = (bf16_t)p[i].x; o[2 * i + 1] = (bf16_t)p[i].y; }
-          if (fr0 + r < nfr) *(bf16x8*)(orow + (int64_t)r * C0 + 128 * q) = o;
+          if (fr0 + r < nfr) c0_store8<PK>(out, e0 + (int64_t)r * C0 + 128 * q, p);
         }
       }
     }
@@ -181,18 +218,27 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
 
 int g_conv0_mfma = 1;   // svt_debug_set key 22: 0 = the vector-ALU conv0 kernels in the 16-bit modes too (A/B)
 
-bool conv0_mfma_ok(int prec, int k, int stride, int C) { return g_conv0_mfma && prec == 1 && k == K0 && stride >= 1 && stride <= 5 && C == C0; }
+// prec: storage precision (1 = 16-bit rows out); pair_kind 2 / 3 = split modes writing pair rows (fp32 storage)
+bool conv0_mfma_ok(int prec, int pair_kind, int k, int stride, int C) {
+  return g_conv0_mfma && (prec == 1 || pair_kind == 2 || pair_kind == 3) && k == K0 && stride >= 1 && stride <= 5 && C == C0;
+}
 size_t conv0_mfma_table_bytes(int B) { return (size_t)B * TBL16 * 16; }
 
-// GroupNorm form: coef (B, C, 11) from conv0_group_coef_kernel -> per-clip tables -> out (B, T1, C) in the operand type
+#define SVT_C0_DISPATCH(PKV, STMT)                 \
+  if ((PKV) == 3) { constexpr int PK_ = 3; STMT }  \
+  else if ((PKV) == 2) { constexpr int PK_ = 2; STMT } \
+  else { constexpr int PK_ = 0; STMT }
+
+// GroupNorm form: coef (B, C, 11) from conv0_group_coef_kernel -> per-clip tables -> out (B, T1, C): 16-bit rows, or pair rows (pair_kind)
 int launch_conv0_mfma_group(const float* wav, int B, int64_t L, int stride, int64_t T1, const float* coef, void* table_ws, void* out,
-                            hipStream_t s) {
-  if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 15)) { set_error("conv0_mfma: alignment"); return -1; }
-  hipLaunchKernelGGL(conv0_table_kernel, dim3(TBL16 / 256, B), dim3(256), 0, s, coef, (long)C0 * (K0 + 1), K0 + 1, (const float*)nullptr,
-                     (bf16_t*)table_ws);
+                            hipStream_t s, int pair_kind) {
+  if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 127)) { set_error("conv0_mfma: alignment"); return -1; }
   dim3 grid((unsigned)((T1 + 255) / 256), B);
-  hipLaunchKernelGGL((conv0_mfma_kernel<0>), grid, dim3(256), 0, s, wav, L, stride, T1, (const bf16_t*)table_ws, (long)TBL16 * 8,
-                     (const double*)nullptr, (int64_t)1, 0.f, (const float*)nullptr, (const float*)nullptr, 0.f, 1, (bf16_t*)out);
+  SVT_C0_DISPATCH(pair_kind,
+    hipLaunchKernelGGL((conv0_table_kernel<PK_>), dim3(TBL16 / 256, B), dim3(256), 0, s, coef, (long)C0 * (K0 + 1), K0 + 1, (const float*)nullptr,
+                       table_ws);
+    hipLaunchKernelGGL((conv0_mfma_kernel<0, PK_>), grid, dim3(256), 0, s, wav, L, stride, T1, (const void*)table_ws, (long)TBL16 * 8,
+                       (const double*)nullptr, (int64_t)1, 0.f, (const float*)nullptr, (const float*)nullptr, 0.f, 1, out);)
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -200,14 +246,16 @@ int launch_conv0_mfma_group(const float* wav, int B, int64_t L, int stride, int6
 // LayerNorm form: conv (w0 (C, 10), b0 (C) or null) on the normalised waveform -> LayerNorm(gamma, beta) -> GELU
 int launch_conv0_mfma_layer(const float* wav, int B, int64_t L, int stride, int64_t T1, const double* wav_moments, int64_t n_wav,
                             float eps_wav, const float* w0, const float* b0, const float* gamma, const float* beta, float eps, void* table_ws,
-                            void* out, hipStream_t s, int cpg) {
-  if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) { set_error("conv0_mfma: alignment"); return -1; }
-  hipLaunchKernelGGL(conv0_table_kernel, dim3(TBL16 / 256, 1), dim3(256), 0, s, w0, 0L, K0, b0, (bf16_t*)table_ws);
+                            void* out, hipStream_t s, int cpg, int pair_kind) {
+  if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 127) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) { set_error("conv0_mfma: alignment"); return -1; }
   dim3 grid((unsigned)((T1 + 255) / 256), B);
-  hipLaunchKernelGGL((conv0_mfma_kernel<1>), grid, dim3(256), 0, s, wav, L, stride, T1, (const bf16_t*)table_ws, 0L, wav_moments, n_wav,
-                     eps_wav, gamma, beta, eps, cpg, (bf16_t*)out);
+  SVT_C0_DISPATCH(pair_kind,
+    hipLaunchKernelGGL((conv0_table_kernel<PK_>), dim3(TBL16 / 256, 1), dim3(256), 0, s, w0, 0L, K0, b0, table_ws);
+    hipLaunchKernelGGL((conv0_mfma_kernel<1, PK_>), grid, dim3(256), 0, s, wav, L, stride, T1, (const void*)table_ws, 0L, wav_moments, n_wav,
+                       eps_wav, gamma, beta, eps, cpg, out);)
   SVT_LAUNCH_CHECK();
   return 0;
 }
+#undef SVT_C0_DISPATCH
 
 }  // namespace svt
