@@ -72,7 +72,13 @@ template <int N> __device__ __forceinline__ void touch_frag(u32x4v (&r)[N]) {
   else asm volatile("" : "+v"(r[0]), "+v"(r[1]));
 }
 
-template <bool F16, int BM, int OUT>
+// DBG (timing ablations, make DIAG=1 + svt_debug_set(0, n); results are WRONG): bit 0 = no LDS-DMA after the head of the stream,
+// bit 1 = no fragment reads after the first LOAD slot, bit 2 = no MFMAs, bit 3 = no barriers between the slots of a slab
+// NQ = 3 (round 4, dispatched): the slab as THREE slots of 32 MFMAs instead of six of 16 -- lo x hi, hi x hi, hi x lo over all eight column
+// blocks of the wave (eight weight fragments live: +16 registers, 24 fragment reads per slab instead of 28).  The timing ablations
+// (tools/x3q_bench.py --dbg, profiles/r04_gemm_x3q_ablation.txt) put the main loop's loss in the barrier intervals themselves: with
+// neither LDS-DMA nor fragment reads the six-slot slab still takes ~4 100 cycles against 3 072 of MFMA issue, ~170 cycles per interval.
+template <bool F16, int BM, int OUT, int DBG = 0, int NQ = 3>
 __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* wsplit, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 32, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -157,9 +163,11 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
 #pragma unroll
     for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
 
-  u32x4v wfr[4], xfr[MB];
+  u32x4v wfr[NQ == 3 ? 8 : 4], xfr[MB];
   int sa = 0, sw = 1, kt = 0, ti = 0;
   const int grp = wave >> 2;   // = wn
+  bool first_load = true;
+#define X3Q_SLOTBAR() { if (!(DBG & 8)) __builtin_amdgcn_s_barrier(); }
 
   // ---- the tile's epilogue: accumulators (bias already inside) -> activation -> fp32 rows / pair rows / planes; clears the
   //      accumulators to the next tile's bias and rotates the source offsets ----
@@ -239,14 +247,15 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
 #define X3Q_LOAD(Q)                                                                                                 \
   {                                                                                                                 \
     constexpr int q_ = (Q);                                                                                         \
-    if (q_ == 0) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragH]; }              \
-    if (q_ == 4) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragL]; }              \
-    if (q_ != 4) {                                                                                                  \
+    const bool rd_ = !(DBG & 2) || first_load;                                                                      \
+    if (q_ == 0 && rd_) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragH]; }       \
+    if (q_ == 4 && rd_) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragL]; }       \
+    if (q_ != 4 && rd_) {                                                                                           \
       constexpr int half_ = (q_ == 2 || q_ == 3) ? 1 : 0;                                                           \
       constexpr bool lo_ = (q_ == 1 || q_ == 2);                                                                    \
       _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) wfr[nb] = wa[(half_ * 4 + nb) * 128 + (lo_ ? fragL : fragH)]; \
     }                                                                                                               \
-    if (q_ == 0 || q_ == 1) {                                                                                       \
+    if ((q_ == 0 || q_ == 1) && !(DBG & 1)) {                                                                       \
       const char* wb = w_cur ? gW + (long)(kt + 1) * ROWB : gW;                                                     \
       _Pragma("unroll") for (int i2 = q_ * 2; i2 < q_ * 2 + 2; ++i2)                                                \
           dma_sv(w_even ? wofE[i2] : wofO[i2], wb, lds_unit(wslot, i2));                                            \
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
                      : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");                                              \
       }                                                                                                             \
     }                                                                                                               \
-    if (q_ == 3 || q_ == 4) {                                                                                       \
+    if ((q_ == 3 || q_ == 4) && !(DBG & 1)) {                                                                       \
       const char* ab = (a_even ? abE : abO) + (long)(a_cur ? kt + 2 : kt + 2 - nk) * ROWB;                          \
       constexpr int hh_ = q_ - 3;                                                                                   \
       _Pragma("unroll") for (int i2 = hh_ * ((GA + 1) / 2); i2 < (hh_ ? GA : (GA + 1) / 2); ++i2)                   \
@@ -266,16 +275,63 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
     /* the fragment registers are "used" here, in the LOAD slot: hipcc cannot see the asm wait above and would otherwise put its   \
        own s_waitcnt lgkmcnt(..) between the MFMAs of the next slot (gemm_pps.hip) */                                      \
     if (q_ == 0 || q_ == 4) touch_frag(xfr);                                                                        \
-    if (q_ != 4) touch_frag(wfr);                                                                                   \
+    if (q_ != 4) { asm volatile("" : "+v"(wfr[0]), "+v"(wfr[1]), "+v"(wfr[2]), "+v"(wfr[3])); }                       \
+    first_load = false;                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 #define X3Q_MMA(Q)                                                                                                  \
   {                                                                                                                 \
     constexpr int half_ = ((Q) >= 2 && (Q) <= 4) ? 1 : 0;                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                                  \
+    if (!(DBG & 4)) {                                                                                               \
     _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                                                \
       _Pragma("unroll") for (int jj = 0; jj < MB; ++jj)                                                             \
         acc[half_ * 4 + nb][jj] = mma16<F16>(xfr[jj], wfr[nb], acc[half_ * 4 + nb][jj]);                            \
+    } else { touch_frag(xfr); }                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+  // ---- NQ = 3: slot 0 = A.lo x W.hi, slot 1 = A.hi x W.hi, slot 2 = A.hi x W.lo, each over the wave's eight column blocks.  A is read in
+  //      slots 0 - 1 only and W.lo last, so the ring hazards are those of the six-slot form: W_{g+1} (requested in slot 0) lands in the
+  //      slot of A_{g-1}, whose last reader (waves 4-7, slot 1 of slab g - 1) is in front of that slab's third barrier; A_{g+2}
+  //      (requested in slot 1) lands in the slot of W_{g-1}, whose last reader (waves 4-7, slot 2 of slab g - 1) is in front of this
+  //      slab's first barrier.
+#define X3W_LOAD(Q)                                                                                                 \
+  {                                                                                                                 \
+    constexpr int q_ = (Q);                                                                                         \
+    const bool rd_ = !(DBG & 2) || first_load;                                                                      \
+    if (q_ == 0 && rd_) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragL]; }       \
+    if (q_ == 1 && rd_) { _Pragma("unroll") for (int jj = 0; jj < MB; ++jj) xfr[jj] = xa[jj * 128 + fragH]; }       \
+    if (q_ != 1 && rd_) {                                                                                           \
+      _Pragma("unroll") for (int nb = 0; nb < 8; ++nb) wfr[nb] = wa[nb * 128 + (q_ == 2 ? fragL : fragH)];           \
+    }                                                                                                               \
+    if (q_ == 0 && !(DBG & 1)) {                                                                                    \
+      const char* wb = w_cur ? gW + (long)(kt + 1) * ROWB : gW;                                                     \
+      _Pragma("unroll") for (int i2 = 0; i2 < GW; ++i2) dma_sv(w_even ? wofE[i2] : wofO[i2], wb, lds_unit(wslot, i2)); \
+      if (last_k && has_bias) {                                                                                     \
+        const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);       \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"                 \
+                     : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");                                              \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (q_ == 1 && !(DBG & 1)) {                                                                                    \
+      const char* ab = (a_even ? abE : abO) + (long)(a_cur ? kt + 2 : kt + 2 - nk) * ROWB;                          \
+      _Pragma("unroll") for (int i2 = 0; i2 < GA; ++i2) dma_sv(a_even ? aofE[i2] : aofO[i2], ab, lds_unit(aslot, i2)); \
+    }                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    if (q_ != 2) touch_frag(xfr);                                                                                   \
+    if (q_ != 1) { asm volatile("" : "+v"(wfr[0]), "+v"(wfr[1]), "+v"(wfr[2]), "+v"(wfr[3]), "+v"(wfr[4]), "+v"(wfr[5]), "+v"(wfr[6]), "+v"(wfr[7])); } \
+    first_load = false;                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define X3W_MMA()                                                                                                   \
+  {                                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    if (!(DBG & 4)) {                                                                                               \
+    _Pragma("unroll") for (int nb = 0; nb < 8; ++nb)                                                                \
+      _Pragma("unroll") for (int jj = 0; jj < MB; ++jj)                                                             \
+        acc[nb][jj] = mma16<F16>(xfr[jj], wfr[nb], acc[nb][jj]);                                                    \
+    } else { touch_frag(xfr); }                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
@@ -303,6 +359,42 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
   // the slab's requests -- and behind it waves 0-3 read the next slab.  Ring hazards: W_{g+1} lands in the slot of A_{g-1}, whose last
   // reader (waves 4-7, slot 4 of slab g - 1) is in front of that slab's sixth barrier; A_{g+2} lands in the slot of W_{g-1}, whose last
   // reader (waves 4-7, slot 5 of slab g - 1) is in front of this slab's first barrier, and its requests start in slot 3.
+  if constexpr (NQ == 3) {
+    if (grp == 0) {
+      {
+        X3Q_VARS()
+        X3W_LOAD(0)
+      }
+      for (int g = 0; g < G; ++g) {
+        X3Q_VARS()
+        __builtin_amdgcn_s_barrier();
+        X3W_MMA() X3W_LOAD(1) X3Q_SLOTBAR()
+        X3W_MMA() X3W_LOAD(2)
+        X3Q_RETIRE()
+        __builtin_amdgcn_s_barrier();
+        X3W_MMA()
+        const bool pending = last_k;
+        X3Q_ADVANCE()
+        if (pending) epilogue();
+        if (g + 1 < G) {
+          X3Q_VARS()
+          X3W_LOAD(0)
+        }
+      }
+    } else {
+      for (int g = 0; g < G; ++g) {
+        X3Q_VARS()
+        __builtin_amdgcn_s_barrier();
+        X3W_LOAD(0) X3W_MMA() X3Q_SLOTBAR()
+        X3W_LOAD(1) X3W_MMA()
+        X3Q_RETIRE()
+        __builtin_amdgcn_s_barrier();
+        X3W_LOAD(2) X3W_MMA()
+        if (last_k) epilogue();
+        X3Q_ADVANCE()
+      }
+    }
+  } else
   if (grp == 0) {
     {
       X3Q_VARS()
@@ -311,10 +403,10 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
     for (int g = 0; g < G; ++g) {
       X3Q_VARS()
       __builtin_amdgcn_s_barrier();
-      X3Q_MMA(0) X3Q_LOAD(1) __builtin_amdgcn_s_barrier();
-      X3Q_MMA(1) X3Q_LOAD(2) __builtin_amdgcn_s_barrier();
-      X3Q_MMA(2) X3Q_LOAD(3) __builtin_amdgcn_s_barrier();
-      X3Q_MMA(3) X3Q_LOAD(4) __builtin_amdgcn_s_barrier();
+      X3Q_MMA(0) X3Q_LOAD(1) X3Q_SLOTBAR()
+      X3Q_MMA(1) X3Q_LOAD(2) X3Q_SLOTBAR()
+      X3Q_MMA(2) X3Q_LOAD(3) X3Q_SLOTBAR()
+      X3Q_MMA(3) X3Q_LOAD(4) X3Q_SLOTBAR()
       X3Q_MMA(4) X3Q_LOAD(5)
       X3Q_RETIRE()
       __builtin_amdgcn_s_barrier();
@@ -331,10 +423,10 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
     for (int g = 0; g < G; ++g) {
       X3Q_VARS()
       __builtin_amdgcn_s_barrier();
-      X3Q_LOAD(0) X3Q_MMA(0) __builtin_amdgcn_s_barrier();
-      X3Q_LOAD(1) X3Q_MMA(1) __builtin_amdgcn_s_barrier();
-      X3Q_LOAD(2) X3Q_MMA(2) __builtin_amdgcn_s_barrier();
-      X3Q_LOAD(3) X3Q_MMA(3) __builtin_amdgcn_s_barrier();
+      X3Q_LOAD(0) X3Q_MMA(0) X3Q_SLOTBAR()
+      X3Q_LOAD(1) X3Q_MMA(1) X3Q_SLOTBAR()
+      X3Q_LOAD(2) X3Q_MMA(2) X3Q_SLOTBAR()
+      X3Q_LOAD(3) X3Q_MMA(3) X3Q_SLOTBAR()
       X3Q_LOAD(4) X3Q_MMA(4)
       X3Q_RETIRE()
       __builtin_amdgcn_s_barrier();
@@ -347,20 +439,23 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(GemmArgs p, const void* w
   // epilogue's MB * 8 stores, which need not be waited for.
   wait_vm<MB * 8>();
 #undef X3Q_LOAD
+#undef X3W_LOAD
+#undef X3W_MMA
+#undef X3Q_SLOTBAR
 #undef X3Q_MMA
 #undef X3Q_RETIRE
 #undef X3Q_VARS
 #undef X3Q_ADVANCE
 }
 
-template <bool F16, int BM, int OUT>
+template <bool F16, int BM, int OUT, int DBG = 0, int NQ = 3>
 int launch_x3q_t(const GemmArgs& a, const void* packed, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_x3q_kernel<F16, BM, OUT>, (int)lds_bytes)) return r_;
-  hipLaunchKernelGGL((gemm_x3q_kernel<F16, BM, OUT>), dim3(nblk), dim3(512), lds_bytes, s, a, packed, tiles_n, ntiles);
+  if (int r_ = ensure_dyn_lds((const void*)gemm_x3q_kernel<F16, BM, OUT, DBG, NQ>, (int)lds_bytes)) return r_;
+  hipLaunchKernelGGL((gemm_x3q_kernel<F16, BM, OUT, DBG, NQ>), dim3(nblk), dim3(512), lds_bytes, s, a, packed, tiles_n, ntiles);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -390,6 +485,31 @@ bool gemm_x3q_eligible(const GemmArgs& a) {
 // kind = svt_precision (2 = bf16 pieces, 3 = fp16 pieces); `packed` = the registered (hi, lo) image of the weight rows (launch_gemm_x3);
 // bm = tile height (256 / 192 / 128)
 int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s) {
+#ifdef SVT_DIAG
+  if (kind == 3 && bm == 256 && !a.planes && g_gemm_dbg >= 101 && g_gemm_dbg <= 115) {   // the same ablations on the six-slot form
+    const bool pr = a.c_pairs != 0;
+    switch (g_gemm_dbg - 100) {
+#define SVT_X3Q_DBG(D) case D: return pr ? launch_x3q_t<true, 256, 1, D, 6>(a, packed, s) : launch_x3q_t<true, 256, 0, D, 6>(a, packed, s);
+      SVT_X3Q_DBG(1) SVT_X3Q_DBG(2) SVT_X3Q_DBG(3) SVT_X3Q_DBG(4)
+#undef SVT_X3Q_DBG
+      default: break;
+    }
+  }
+  if (kind == 3 && g_gemm_dbg == 100 && !a.planes) {   // six slots per slab (the first form of this kernel): A/B
+    const bool pr = a.c_pairs != 0;
+    if (bm == 256) return pr ? launch_x3q_t<true, 256, 1, 0, 6>(a, packed, s) : launch_x3q_t<true, 256, 0, 0, 6>(a, packed, s);
+    if (bm == 192) return pr ? launch_x3q_t<true, 192, 1, 0, 6>(a, packed, s) : launch_x3q_t<true, 192, 0, 0, 6>(a, packed, s);
+  }
+  if (kind == 3 && bm == 256 && !a.planes && g_gemm_dbg >= 1 && g_gemm_dbg <= 15) {   // timing ablations of the fp16, 256-row form (wrong results)
+    const bool pr = a.c_pairs != 0;
+    switch (g_gemm_dbg) {
+#define SVT_X3Q_DBG(D) case D: return pr ? launch_x3q_t<true, 256, 1, D>(a, packed, s) : launch_x3q_t<true, 256, 0, D>(a, packed, s);
+      SVT_X3Q_DBG(1) SVT_X3Q_DBG(2) SVT_X3Q_DBG(3) SVT_X3Q_DBG(4) SVT_X3Q_DBG(6) SVT_X3Q_DBG(7) SVT_X3Q_DBG(8) SVT_X3Q_DBG(10)
+#undef SVT_X3Q_DBG
+      default: break;
+    }
+  }
+#endif
   if (kind == 3) {
     if (bm == 256) return launch_x3q_o<true, 256>(a, packed, s);
     if (bm == 192) return launch_x3q_o<true, 192>(a, packed, s);

@@ -30,10 +30,13 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--prec", type=int, default=3)
     ap.add_argument("--only", default="")
+    ap.add_argument("--dbg", type=int, default=0, help="svt_debug_set(0, n): timing ablations of gemm_x3q_kernel (make DIAG=1; results are wrong): "
+                    "1 no LDS-DMA after the head, 2 no fragment reads, 4 no MFMAs, 8 no barriers between slots (sums combine)")
     a = ap.parse_args()
     lib = _lib.load()
     _lib.require_gpu()
     lib.svt_debug_set(1, a.bm)
+    lib.svt_debug_set(0, a.dbg)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for name, M, N, K, conv, act, ok in SHAPES:
