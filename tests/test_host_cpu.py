@@ -1,6 +1,7 @@
 """CPU tests (-m "not gpu"): host logic, state-dict schema, C-ABI symbol export, loud failure without a GPU."""
 import ctypes
 import os
+import sys
 import time
 import re
 
@@ -656,3 +657,20 @@ def test_pretrain_without_weights_and_do_normalize_defaults(caplog):
     assert preset_do_normalize("facebook/hubert-large-ll60k") is True and preset_do_normalize("some/unknown-model") is None
     assert S.HuggingFaceWav2Vec2("facebook/hubert-base-ls960", None, pretrain=False).normalize_wav is False
     assert S.HuggingFaceWav2Vec2("facebook/hubert-base-ls960", None, pretrain=False, normalize_wav=True).normalize_wav is True
+
+
+def test_operand_rounding_simulation_brackets_the_exact_oracle():
+    """tools/sim_split.py (the yardstick of the 16-bit modes' bounds in tests/test_gpu_parity.py): rounding every dense product's operands to
+    bf16 costs about ten times what rounding them to IEEE half costs, the three-product split reproduces the golden to 1e-3 / 1e-4, and no
+    argmax moves on the tiny golden."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_split
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "tiny_group.pt"), weights_only=False)
+    b1 = sim_split.simulate(fx, "bf16x1")
+    h1 = sim_split.simulate(fx, "f16x1")
+    b3 = sim_split.simulate(fx, "bf16x3")
+    h3 = sim_split.simulate(fx, "f16x3")
+    assert 0.02 < b1[0] < 0.3 and b1[0] > 4 * h1[0]
+    assert b3[0] < 1e-3 and h3[0] < 1e-4
+    assert b1[2] == h1[2] == b3[2] == h3[2] == 0 and b1[3] == fx["logits"].shape[0] * fx["logits"].shape[1]
