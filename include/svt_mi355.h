@@ -287,8 +287,10 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * 13 = page-guarded device allocations (see svt_debug_alloc), 19 = split-operand modes keep product operands as pair rows written by
  * their producers (1, default) or as fp32 cut inside the product kernels (0: the round-2/3 path, A/B), 20 = (hi, lo) LayerNorm with two
  * rows per wave (1, default) or one (0), 21 = fused attention variant (0 = staggered wave groups, 1 = the round-3 lockstep kernel),
- * 22 = conv layer 0 on the matrix pipe in the 16-bit modes (1, default) or on the vector ALU (0).
- * Returns 0. */
+ * 22 = conv layer 0 on the matrix pipe in the 16-bit modes (1, default) or on the vector ALU (0), 23 = stage 1 of the lip front-end on
+ * the frame-resident direct convolution (1, default; conv3x3_c64.hip) or on the GEMM kernels (0), 24 = query: returns the number of
+ * direct-convolution launches of this process so far (value ignored).
+ * Returns 0 (key 24: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

@@ -557,6 +557,9 @@ int svt_debug_set(int key, int value) {
   else if (key == 20) g_ln_two_rows = value;
   else if (key == 21) g_attn_variant = value;
   else if (key == 22) g_conv0_mfma = value;
+  else if (key == 23) g_conv3x3_c64 = value;
+  else if (key == 24) return g_conv3x3_c64_launches;
+  else if (key == 25) g_conv3x3_c64_form = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -1751,6 +1754,7 @@ struct svt_video {
   VConv grp1[2][2], grp2[2][2];
   DevBuf gslope1[2][2], gslope2[2][2];
   DevBuf slope2[4][2];
+  DevBuf frag1[2], frag2[2];  // stage 1, 16-bit storage: the 3x3 kernels as MFMA fragment images (conv3x3_c64.hip)
   DevBuf proj_w, proj_b;
 };
 
@@ -1842,6 +1846,27 @@ int fold_conv_group(const ParamMap& P, const std::string& wkey, const std::strin
   if (int r = upload_operand(1, out->w, t.data(), t.size())) return r;
   return upload_f32(out->bias, b2.data(), b2.size());
 }
+// 64 -> 64 channel 3x3 kernel + BN scale as conv3x3_c64_kernel's LDS image: [tap ky*3+kx][k-step][channel block nb][lane] x 8 values,
+// lane (i = lane & 15, kq = lane >> 4) = A-operand row i of block nb = output channel (i>>2)*16 + nb*4 + (i&3), input channels
+// ks*32 + kq*8 .. +7 (the row permutation leaves a lane of the MFMA result with 16 consecutive channels of one pixel)
+int fold_conv_frag64(const ParamMap& P, const std::string& wkey, const std::string& bnkey, DevBuf* out) {
+  const Param* w = nullptr;
+  if (int r = need(P, wkey, {64, 64, 3, 3}, &w)) return r;
+  std::vector<float> sc, bi;
+  if (int r = bn_fold(P, bnkey, 64, &sc, &bi)) return r;
+  std::vector<float> t((size_t)9 * 2 * 4 * 64 * 8);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int ks = 0; ks < 2; ++ks)
+      for (int nb = 0; nb < 4; ++nb)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, co = (i >> 2) * 16 + nb * 4 + (i & 3);
+          for (int e = 0; e < 8; ++e) {
+            const int ci = ks * 32 + kq * 8 + e;
+            t[((((size_t)tap * 2 + ks) * 4 + nb) * 64 + lane) * 8 + e] = w->v[(((size_t)co * 64 + ci) * 3 + tap / 3) * 3 + tap % 3] * sc[co];
+          }
+        }
+  return upload_operand(1, *out, t.data(), t.size());
+}
 int upload_vec_rep(const ParamMap& P, const std::string& key, int C, int G, DevBuf* out) {
   const Param* p = nullptr;
   if (int r = need(P, key, {C}, &p)) return r;
@@ -1922,6 +1947,8 @@ int svt_video_finalize(svt_video* v) {
       if (b == 0 && li > 0)
         if (int r = fold_conv(v->prec, P, pre + ".downsample.0.weight", pre + ".downsample.1", C, cin, 1, &v->down[li])) return r;
       if (li == 0 && v->prec) {
+        if (int r = fold_conv_frag64(P, pre + ".conv1.weight", pre + ".bn1", &v->frag1[b])) return r;
+        if (int r = fold_conv_frag64(P, pre + ".conv2.weight", pre + ".bn2", &v->frag2[b])) return r;
         for (int gi = 0; gi < 2; ++gi) {
           const int G = gi ? 4 : 2;
           if (int r = fold_conv_group(P, pre + ".conv1.weight", pre + ".bn1", 64, 64, G, &v->grp1[gi][b])) return r;
@@ -2031,6 +2058,15 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
       void* t1 = fr[0];
       void* outb = fr[1];
       const void* res = x;
+      if (li == 0 && v->gp == 1 && conv3x3_c64_ok(prec, Ho, Wo)) {
+        // frame-resident direct convolution (conv3x3_c64.hip): every input pixel fetched once, weights resident in LDS
+        if (launch_conv3x3_c64(x, v->frag1[b].p, v->conv1[0][b].bias.as<float>(), v->conv1[0][b].slope.as<float>(), nullptr, t1, F, Ho, Wo, s))
+          return SVT_ERR_HIP;
+        if (launch_conv3x3_c64(t1, v->frag2[b].p, v->conv2[0][b].bias.as<float>(), v->slope2[0][b].as<float>(), x, outb, F, Ho, Wo, s))
+          return SVT_ERR_HIP;
+        x = outb;
+        continue;
+      }
       if (li == 0 && grp) {
         const int gi = grp == 4 ? 1 : 0;
         if (int r = conv_group(x, Ho, Wo, t1, v->grp1[gi][b], v->gslope1[gi][b].as<float>(), nullptr)) return r;

@@ -388,6 +388,11 @@ int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bi
 int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s);
 int launch_zero_halo(int prec, void* buf, long F, int Hp, int Wp, int C, hipStream_t s);
 int launch_avgpool_interior(int prec, const void* in, long F, int H, int W, int C, void* out, hipStream_t s);
+// conv3x3_c64.hip: stage 1 of the lip front-end (64 -> 64 channels, 3x3) with the frame and the weights resident in LDS
+extern int g_conv3x3_c64, g_conv3x3_c64_launches, g_conv3x3_c64_form;
+bool conv3x3_c64_ok(int prec, int Hs, int Ws);
+int launch_conv3x3_c64(const void* in, const void* wimg, const float* bias, const float* slope, const void* resid, void* out, long F,
+                       int Hs, int Ws, hipStream_t s);
 // validation losses (masked BCE-with-logits / NLL, speechbrain/nnet/losses.py) and the narrow (log-)softmax
 int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,
                     const float* pos_weight, float* per_frame, double* sums, hipStream_t s);

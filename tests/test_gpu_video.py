@@ -46,6 +46,33 @@ def test_video_frontend_bf16_error_bound(golden, name):
     assert d.max().item() < 0.06 * scale and d.mean().item() < 0.01 * scale
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("hw,B,T", [(88, 2, 300), (88, 1, 7), (80, 1, 40), (60, 3, 100), (50, 2, 31), (92, 1, 30)])
+def test_stage1_frame_resident_conv_against_the_gemm_path(precision, hw, B, T):
+    """conv3x3_c64_kernel (two padded frames resident in LDS, the 3x3 weights in registers; ROIs of 50-88 pixels) against the same
+    front-end with stage 1 on the GEMM kernels (svt_debug_set(23, 0)).  Same 16-bit storage, and the same fp32 summation order (tap by
+    tap, 32 channels per MFMA; the GEMM path's structural zeros add exact zeros): BIT-IDENTICAL, so svt_debug_set(24, 0)'s launch
+    count is the proof that the direct path ran.  600 frames = more than two frames per workgroup (both LDS buffers re-used), 7 = fewer
+    frames than CUs; 92 pixels = two 25 x 25 padded frames do not fit the LDS and fall back."""
+    lib = _lib.load("f16" if precision == "fp16" else "")
+    m = SubModel(512, 256, "prelu", precision=precision, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(hw + T)
+    video = torch.randn(B, 1, T, hw, hw, generator=g).to(DEV)
+    n0 = lib.svt_debug_set(24, 0)
+    y = m(video).float()
+    n1 = lib.svt_debug_set(24, 0)
+    assert n1 - n0 == (0 if hw == 92 else 4), "two BasicBlocks x two convolutions on the direct path"
+    assert torch.equal(y, m(video).float())
+    lib.svt_debug_set(23, 0)
+    try:
+        ref = m(video).float()
+    finally:
+        lib.svt_debug_set(23, 1)
+    assert lib.svt_debug_set(24, 0) == n1 + (0 if hw == 92 else 4)
+    assert torch.isfinite(y).all() and y.abs().max().item() > 1.0
+    assert torch.equal(y, ref)
+
+
 def test_video_frontend_errors():
     m = SubModel(512, 64, "prelu", precision="fp32").to(DEV)
     with pytest.raises(ValueError):

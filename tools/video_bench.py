@@ -13,8 +13,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--frames", type=int, default=500)
 ap.add_argument("--precision", default="bf16")
+ap.add_argument("--debug", default="", help="svt_debug_set pairs key=value,key=value")
 a = ap.parse_args()
 dev = "cuda:0"
+for kv in filter(None, a.debug.split(",")):
+    _lib.load("f16" if a.precision == "fp16" else "").svt_debug_set(*map(int, kv.split("=")))
 m = SubModel(512, 1024, "prelu", precision=a.precision).to(dev)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.batch, 1, a.frames, 88, 88, generator=g).to(dev)
