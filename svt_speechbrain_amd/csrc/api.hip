@@ -560,6 +560,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 23) g_conv3x3_c64 = value;
   else if (key == 24) return g_conv3x3_c64_launches;
   else if (key == 25) g_conv3x3_c64_form = value;
+  else if (key == 26) g_stem_pool_fused = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -1987,13 +1988,17 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   const size_t es = esize(prec);
   const long F = (long)batch * t;
   if (launch_video_pad(prec, video_dev, batch, t, h, w, g.Hp0, g.Wp0, ws.vp, s)) return SVT_ERR_HIP;
-  if (launch_conv3d_front(prec, ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0, g.H0,
-                          g.W0, ws.o0, s)) return SVT_ERR_HIP;
+  const bool fused_stem = v->gp == 1 && conv3d_front_pool_ok(prec, g.Hp0, g.Wp0, g.W0);
+  if (!fused_stem && launch_conv3d_front(prec, ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0,
+                                         g.H0, g.W0, ws.o0, s)) return SVT_ERR_HIP;
   // zero halos: the padded stage buffers are written in their interior only
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 3; ++j)
       if (launch_zero_halo(prec, ws.buf[i][j], F, g.Hs[i] + 2, g.Ws[i] + 2, kVC[i], s)) return SVT_ERR_HIP;
-  if (launch_maxpool_3x3s2(prec, ws.o0, F, g.H0, g.W0, 64, g.Hs[0], g.Ws[0], ws.buf[0][0], s)) return SVT_ERR_HIP;
+  if (fused_stem) {
+    if (launch_conv3d_front_pool(ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0, g.H0, g.W0,
+                                 g.Hs[0], g.Ws[0], ws.buf[0][0], s)) return SVT_ERR_HIP;
+  } else if (launch_maxpool_3x3s2(prec, ws.o0, F, g.H0, g.W0, 64, g.Hs[0], g.Ws[0], ws.buf[0][0], s)) return SVT_ERR_HIP;
 
   // one k x k convolution (k = 3: pad 1; k = 1: no pad) over the zero-haloed channels-last tensor `in`
   auto conv = [&](const void* in, int Hin, int Win, int Cin, void* out, int Ho, int Wo, int Cout, int stride, int k,

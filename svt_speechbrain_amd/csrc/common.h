@@ -386,6 +386,11 @@ int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int H
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,
                         int Wp, int H0, int W0, void* out, hipStream_t s);
 int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s);
+// stem + max-pool in one persistent kernel (16-bit storage; six plane slots + a 9-row band of the stem output in LDS)
+extern int g_stem_pool_fused;
+bool conv3d_front_pool_ok(int prec, int Hp, int Wp, int W0);
+int launch_conv3d_front_pool(const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp, int Wp, int H0,
+                             int W0, int H1, int W1, void* out, hipStream_t s);
 int launch_zero_halo(int prec, void* buf, long F, int Hp, int Wp, int C, hipStream_t s);
 int launch_avgpool_interior(int prec, const void* in, long F, int H, int W, int C, void* out, hipStream_t s);
 // conv3x3_c64.hip: stage 1 of the lip front-end (64 -> 64 channels, 3x3) with the frame and the weights resident in LDS

@@ -132,6 +132,153 @@ __global__ __launch_bounds__(512) void conv3d_front_bf16_kernel(const bf16_t* vp
   }
 }
 
+// The same stem FUSED with the 3x3 / 2 max-pool behind it and made persistent (round 4): the unfused pair writes the 44 x 44 x 64
+// stem output (2 GB per 8 000 frames) and reads it back to keep a quarter of it.  One workgroup per CU takes a run of consecutive frames:
+//   planes  six plane slots in LDS, slot = padded time index mod 6: consecutive frames of a clip share four of their five planes, so a
+//           frame fetches ONE new plane (LDS-DMA, requested a frame ahead) instead of five; weights and bias / slope stay in registers
+//           for the whole run (the one-frame kernel reloads 10 KB of fragments per wave and frame);
+//   bands   a frame is computed in bands of 8 stem rows = 4 pool rows; the band's post-PReLU outputs go to a 9-row circular LDS buffer
+//           (16-byte chunks XOR-swizzled by the pixel's x), row slot = row mod 9 keeps the row above the band for the pool window;
+//   pool    after the band's barrier the workgroup max-pools 4 x W1 x 8 chunk items straight out of LDS into the zero-haloed stage-1
+//           input; the values pooled are the bf16-rounded outputs the unfused pair would have stored: bit-identical results.
+// timing ablations (make DIAG=1; svt_debug_set key 26 value 1 + 16 x bits: 1 = no pool phase, 2 = no MFMA phase, 4 = no plane
+// requests, 8 = no stem epilogue; tools/c3_ablate.sh with KEY=26): compiled out of the shipped library
+#ifdef SVT_DIAG
+#define STEM_DBG(bit) (dbg & (bit))
+#else
+#define STEM_DBG(bit) 0
+#endif
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+// bf16 / IEEE-half bits <-> int16 with the same ordering as the values (an involution: negative values get their magnitude bits flipped)
+__device__ __forceinline__ s16x8v ordered16(s16x8v u) { return u ^ ((u >> 15) & (short)0x7FFF); }
+__device__ __forceinline__ void stem_dma16(const void* gsrc, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__global__ __launch_bounds__(512) void conv3d_front_pool_kernel(const bf16_t* __restrict__ vp, const uint4* __restrict__ wfrag,
+                                                                const float* __restrict__ bias, const float* __restrict__ slope, int Tt,
+                                                                int Hp, int Wp, int H0, int W0, int H1, int W1, long F, int fpb,
+                                                                bf16_t* __restrict__ out, int dbg) {
+  extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = Hp * Wp;                            // elements, multiple of 8
+  const unsigned SB = (unsigned)((plane * 2 + 1023) / 1024) * 1024u;   // bytes per plane slot
+  const unsigned lds0 = (unsigned)(size_t)lds_raw;
+  char* band = lds_raw + 6 * SB;
+  const long f0 = (long)blockIdx.x * fpb, f1 = f0 + fpb < F ? f0 + fpb : F;
+
+  // nine of the image's ten k-steps: chunks 36..39 (k-step 9) are all padding with zero weights
+  bf16x8 wr[9][4];
+#pragma unroll
+  for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) wr[ks][nb] = __builtin_bit_cast(bf16x8, wfrag[(ks * 4 + nb) * 64 + lane]);
+  // bias / slope behind the band (registers are for the weights and the pool's nine reads)
+  float* bs = (float*)(band + 9 * W0 * 128);
+  if (tid < 64) { bs[tid] = bias[tid]; bs[64 + tid] = slope[tid]; }
+
+  // padded plane tp of clip b -> slot tp % 6 (whole KiB pieces; the tail piece is clamped to the plane's last 16 bytes)
+  auto request_plane = [&](int b, int tp) {
+    const char* src = (const char*)(vp + ((long)b * (Tt + 4) + tp) * plane);
+    const unsigned dst = lds0 + (unsigned)(tp % 6) * SB;
+    for (int i = wave; i < (int)(SB >> 10); i += 8) {
+      int off = i * 1024 + lane * 16;
+      off = off < plane * 2 - 16 ? off : plane * 2 - 16;
+      stem_dma16(src + off, dst + (unsigned)i * 1024u);
+    }
+  };
+  const int nbands = (H1 + 3) >> 2;
+  const float rW0 = 1.0f / (float)W0;
+  int cur_b = -1;
+  for (long f = f0; f < f1; ++f) {
+    const int b = (int)(f / Tt), t = (int)(f - (long)b * Tt);
+    if (b != cur_b) {   // first frame of the run, or a new clip: all five planes
+      for (int dt = 0; dt < 5; ++dt) request_plane(b, t + dt);
+      cur_b = b;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (f + 1 < f1 && t + 1 < Tt && !STEM_DBG(4)) request_plane(b, t + 5);   // the next frame's new plane into the slot plane t - 1 left
+    int koff[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+      int s = ks * 4 + (lane >> 4);
+      if (s > 34) s = 34;  // chunks 35..39 are padding: their weights are zero, any valid address will do
+      const int dt = s / 7, dy = s - dt * 7;
+      koff[ks] = (int)(((unsigned)((t + dt) % 6) * SB) >> 1) + dy * Wp;
+    }
+    const bf16_t* img = (const bf16_t*)lds_raw;
+    for (int bi = 0; bi < nbands; ++bi) {
+      const int r0 = bi * 8, nrows = H0 - r0 < 8 ? H0 - r0 : 8;
+      const int npix = nrows * W0, nblk = (npix + 15) >> 4;
+      for (int blk = wave; blk < nblk && !STEM_DBG(2); blk += 8) {
+        int pix = blk * 16 + (lane & 15);
+        const bool live = pix < npix;
+        if (!live) pix = npix - 1;
+        const int ry = (int)(((float)pix + 0.5f) * rW0), x = pix - ry * W0, yy = r0 + ry;   // pix < 8 W0: exact
+        const int pbase = 2 * yy * Wp + 2 * x;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+          const unsigned* q = (const unsigned*)(img + koff[ks] + pbase);
+          const u32x4v xv = {q[0], q[1], q[2], q[3]};
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[nb] = SVT_MFMA_16x16x32(wr[ks][nb], __builtin_bit_cast(bf16x8, xv), acc[nb]);
+        }
+        if (live && !STEM_DBG(8)) {
+          char* o = band + ((yy % 9) * W0 + x) * 128;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float* bq = bs + (lane >> 4) * 16 + h * 8;
+            const float4 b0 = *(const float4*)bq, b1 = *(const float4*)(bq + 4), s0 = *(const float4*)(bq + 64), s1 = *(const float4*)(bq + 68);
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int jj = h * 8 + j;
+              float v = acc[jj >> 2][jj & 3] + bv[j];
+              v = v > 0.f ? v : v * sv[j];
+              ov[j] = (bf16_t)v;
+            }
+            *(s16x8v*)(o + ((((lane >> 4) * 2 + h) ^ (x & 7)) << 4)) = ordered16(__builtin_bit_cast(s16x8v, ov));
+          }
+        }
+      }
+      // the requests of this frame are waited for once, in front of the last band's barrier (a frame old by then)
+      if (bi == nbands - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // pool: slot = (pool row of the band, x1 padded to 32, chunk) -- shifts only; window coordinates clamped instead of skipped (a
+      // duplicate does not change a maximum), so the nine reads go out together; the maximum is taken on the order-preserving int16
+      // image of the values the stem wrote (v_pk_max_i16: 4 instructions per 16 bytes instead of 8 conversions + 8 maxima)
+      const int py0 = bi * 4, nprow = H1 - py0 < 4 ? H1 - py0 : 4;
+#pragma unroll 1
+      for (int i = tid; i < 1024 && !STEM_DBG(1); i += 512) {
+        const int c = i & 7, x1 = (i >> 3) & 31, pr = i >> 8, y1 = py0 + pr;
+        if (x1 < W1 && pr < nprow) {
+          int ro[3], xo[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            int y = 2 * y1 + d - 1, x = 2 * x1 + d - 1;
+            y = y < 0 ? 0 : (y >= H0 ? H0 - 1 : y);
+            x = x < 0 ? 0 : (x >= W0 ? W0 - 1 : x);
+            ro[d] = (y % 9) * W0 * 128;
+            xo[d] = x * 128 + ((c ^ (x & 7)) << 4);
+          }
+          s16x8v v[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[k] = *(const s16x8v*)(band + ro[k / 3] + xo[k % 3]);
+          s16x8v m = v[0];
+#pragma unroll
+          for (int k = 1; k < 9; ++k) m = __builtin_elementwise_max(m, v[k]);
+          *(s16x8v*)(out + ((f * (H1 + 2) + y1 + 1) * (long)(W1 + 2) + x1 + 1) * 64 + c * 8) = ordered16(m);
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
 // 3x3 stride-2 pad-1 max-pool over [F][H0][W0][C] -> interior of the zero-haloed [F][H1+2][W1+2][C]
 template <typename T>
 __global__ void maxpool_3x3s2_kernel(const T* in, long F, int H0, int W0, int C, int H1, int W1, T* out) {
@@ -250,6 +397,32 @@ int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bi
     hipLaunchKernelGGL(conv3d_front_f32_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, (const float*)vp, (const float*)w,
                        bias, slope, T, Hp, Wp, H0, W0, npix, (float*)out);
   }
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int g_stem_pool_fused = 1;  // svt_debug_set key 26: 0 = stem and max-pool as two kernels (A/B, tests)
+static size_t stem_pool_lds(int Hp, int Wp, int W0) { return (size_t)6 * (((size_t)Hp * Wp * 2 + 1023) / 1024 * 1024) + (size_t)9 * W0 * 128 + 512; }
+bool conv3d_front_pool_ok(int prec, int Hp, int Wp, int W0) { return g_stem_pool_fused && prec == 1 && stem_pool_lds(Hp, Wp, W0) <= 160 * 1024; }
+// stem + 3x3/2 max-pool -> interior of the zero-haloed [F][H1+2][W1+2][64] (16-bit storage modes)
+int launch_conv3d_front_pool(const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp, int Wp, int H0,
+                             int W0, int H1, int W1, void* out, hipStream_t s) {
+  const size_t lds_bytes = stem_pool_lds(Hp, Wp, W0);
+  if (int r_ = ensure_dyn_lds((const void*)conv3d_front_pool_kernel, (int)lds_bytes)) return r_;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    SVT_HIP(hipGetDevice(&dev));
+    SVT_HIP(hipGetDeviceProperties(&pr, dev));
+    ncu = pr.multiProcessorCount;
+  }
+  const int fpb = (int)((F + ncu - 1) / ncu);
+  const unsigned grid = (unsigned)((F + fpb - 1) / fpb);
+  prof_begin(s);
+  hipLaunchKernelGGL(conv3d_front_pool_kernel, dim3(grid), dim3(512), lds_bytes, s, (const bf16_t*)vp, (const uint4*)w, bias, slope, T, Hp,
+                     Wp, H0, W0, H1, W1, F, fpb, (bf16_t*)out, g_stem_pool_fused >> 4);
+  prof_end(s, 2.0 * F * H0 * W0 * 64.0 * 245.0, 0.0, 1);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -73,6 +73,29 @@ def test_stage1_frame_resident_conv_against_the_gemm_path(precision, hw, B, T):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("hw,B,T", [(88, 2, 301), (88, 9, 33), (88, 1, 5), (60, 3, 50), (50, 2, 31), (32, 4, 20), (92, 1, 12)])
+def test_fused_stem_and_maxpool_against_the_two_kernels(precision, hw, B, T):
+    """conv3d_front_pool_kernel (stem + 3x3/2 max-pool, persistent over runs of consecutive frames with one new plane per frame) against
+    the stem and pool kernels it replaces (svt_debug_set(26, 0)): it pools the same bf16-rounded stem outputs -> bit-identical.
+    602 = 3 frames per workgroup with a run crossing from clip 0 into clip 1; 9 x 33: runs of two frames crossing clips at odd
+    boundaries; 5 frames: one frame per workgroup; 60 / 50 / 32: 30, 25 (odd) and 16 stem rows (short last bands); 92: the six plane
+    slots and the band do not fit the LDS, the two kernels run."""
+    lib = _lib.load("f16" if precision == "fp16" else "")
+    m = SubModel(512, 128, "prelu", precision=precision, seed=9).to(DEV)
+    g = torch.Generator().manual_seed(hw * 7 + T)
+    video = torch.randn(B, 1, T, hw, hw, generator=g).to(DEV)
+    y = m(video).float()
+    assert torch.equal(y, m(video).float())
+    lib.svt_debug_set(26, 0)
+    try:
+        ref = m(video).float()
+    finally:
+        lib.svt_debug_set(26, 1)
+    assert torch.isfinite(y).all() and y.abs().max().item() > 1.0
+    assert torch.equal(y, ref)
+
+
 def test_video_frontend_errors():
     m = SubModel(512, 64, "prelu", precision="fp32").to(DEV)
     with pytest.raises(ValueError):
