@@ -38,6 +38,37 @@ __global__ void video_pad_kernel(const float* v, int B, int Tt, int H, int W, in
   }
 }
 
+// 16-bit modes, W % 4 == 0: 8 output pixels (16 bytes) per thread from two aligned float4 (Wp is a multiple of 8, pixel x sits at
+// x + 4, so an 8-pixel group starts at x = 8 g - 4: both halves are whole float4 inside or outside the row)
+__global__ void video_pad8_kernel(const float* v, int B, int Tt, int H, int W, int Hp, int Wp, bf16_t* out) {
+  const int Wg = Wp >> 3;
+  const long n = (long)B * (Tt + 4) * Hp * Wg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % Wg);
+    long r = i / Wg;
+    const int yp = (int)(r % Hp);
+    r /= Hp;
+    const int tp = (int)(r % (Tt + 4));
+    const int b = (int)(r / (Tt + 4));
+    const int x0 = g * 8 - 4, y = yp - 3, t = tp - 2;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    if (y >= 0 && y < H && t >= 0 && t < Tt) {
+      const float* row = v + (((long)b * Tt + t) * H + y) * W;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int x = x0 + 4 * h;
+        if (x >= 0 && x + 3 < W) {
+          const float4 q = *(const float4*)(row + x);
+          o[4 * h] = (bf16_t)q.x; o[4 * h + 1] = (bf16_t)q.y; o[4 * h + 2] = (bf16_t)q.z; o[4 * h + 3] = (bf16_t)q.w;
+        }
+      }
+    }
+    *(bf16x8*)(out + i * 8) = o;
+  }
+}
+
 // exact-fp32 stem (parity mode): one thread per (pixel, channel); w is [35*8][64] (k-major), BN scale folded
 __global__ __launch_bounds__(256) void conv3d_front_f32_kernel(const float* vp, const float* w, const float* bias,
                                                                const float* slope, int Tt, int Hp, int Wp, int H0, int W0,
@@ -376,7 +407,9 @@ unsigned grid_of(long n) {
 
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s) {
   const long n = (long)B * (T + 4) * Hp * Wp;
-  if (prec) hipLaunchKernelGGL(video_pad_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (bf16_t*)out);
+  if (prec && W % 4 == 0 && Wp % 8 == 0 && ((size_t)v & 15) == 0)
+    hipLaunchKernelGGL(video_pad8_kernel, dim3(grid_of(n / 8)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (bf16_t*)out);
+  else if (prec) hipLaunchKernelGGL(video_pad_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (bf16_t*)out);
   else hipLaunchKernelGGL(video_pad_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (float*)out);
   SVT_LAUNCH_CHECK();
   return 0;
