@@ -1756,6 +1756,7 @@ struct svt_video {
   DevBuf gslope1[2][2], gslope2[2][2];
   DevBuf slope2[4][2];
   DevBuf frag1[2], frag2[2];  // stage 1, 16-bit storage: the 3x3 kernels as MFMA fragment images (conv3x3_c64.hip)
+  DevBuf frag128[3];          // stage 2's stride-1 convolutions: block 0 conv2, block 1 conv1 / conv2 (conv3x3_c128_kernel)
   DevBuf proj_w, proj_b;
 };
 
@@ -1868,6 +1869,28 @@ int fold_conv_frag64(const ParamMap& P, const std::string& wkey, const std::stri
         }
   return upload_operand(1, *out, t.data(), t.size());
 }
+// 128 -> 128 channel 3x3 kernel + BN scale as conv3x3_c128_kernel's register image: [wave = cq*2 + kh][tap][k-step][nb][lane] x 8
+// values; lane (i = lane & 15, kq = lane >> 4) = A-operand row i of block nb = output channel cq*32 + (i>>2)*8 + nb*4 + (i&3) (a lane of
+// the result holds 8 consecutive channels), input channels kh*64 + ks*32 + kq*8 .. +7
+int fold_conv_frag128(const ParamMap& P, const std::string& wkey, const std::string& bnkey, DevBuf* out) {
+  const Param* w = nullptr;
+  if (int r = need(P, wkey, {128, 128, 3, 3}, &w)) return r;
+  std::vector<float> sc, bi;
+  if (int r = bn_fold(P, bnkey, 128, &sc, &bi)) return r;
+  std::vector<float> t((size_t)8 * 36 * 64 * 8);
+  for (int wv = 0; wv < 8; ++wv)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int ks = 0; ks < 2; ++ks)
+        for (int nb = 0; nb < 2; ++nb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, co = (wv >> 1) * 32 + (i >> 2) * 8 + nb * 4 + (i & 3);
+            for (int e = 0; e < 8; ++e) {
+              const int ci = (wv & 1) * 64 + ks * 32 + kq * 8 + e;
+              t[(((size_t)wv * 36 + (tap * 2 + ks) * 2 + nb) * 64 + lane) * 8 + e] = w->v[(((size_t)co * 128 + ci) * 3 + tap / 3) * 3 + tap % 3] * sc[co];
+            }
+          }
+  return upload_operand(1, *out, t.data(), t.size());
+}
 int upload_vec_rep(const ParamMap& P, const std::string& key, int C, int G, DevBuf* out) {
   const Param* p = nullptr;
   if (int r = need(P, key, {C}, &p)) return r;
@@ -1947,6 +1970,11 @@ int svt_video_finalize(svt_video* v) {
       if (int r = upload_vec(P, pre + ".relu2.weight", C, &v->slope2[li][b])) return r;
       if (b == 0 && li > 0)
         if (int r = fold_conv(v->prec, P, pre + ".downsample.0.weight", pre + ".downsample.1", C, cin, 1, &v->down[li])) return r;
+      if (li == 1 && v->prec) {
+        if (b == 1)
+          if (int r = fold_conv_frag128(P, pre + ".conv1.weight", pre + ".bn1", &v->frag128[1])) return r;
+        if (int r = fold_conv_frag128(P, pre + ".conv2.weight", pre + ".bn2", &v->frag128[b == 0 ? 0 : 2])) return r;
+      }
       if (li == 0 && v->prec) {
         if (int r = fold_conv_frag64(P, pre + ".conv1.weight", pre + ".bn1", &v->frag1[b])) return r;
         if (int r = fold_conv_frag64(P, pre + ".conv2.weight", pre + ".bn2", &v->frag2[b])) return r;
@@ -2079,13 +2107,20 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
         x = outb;
         continue;
       }
-      if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
+      const bool direct128 = li == 1 && v->gp == 1 && conv3x3_c128_ok(prec, Ho, Wo);
+      if (direct128 && stride == 1) {
+        if (launch_conv3x3_c128(x, v->frag128[1].p, v->conv1[1][b].bias.as<float>(), v->conv1[1][b].slope.as<float>(), nullptr, t1, F, Ho, Wo, s))
+          return SVT_ERR_HIP;
+      } else if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
       if (stride == 2) {  // first block of stages 2-4: the residual is the 1x1 stride-2 conv + BN of the block input
         if (int r = conv(x, Hin, Win, cin, fr[1], Ho, Wo, C, 2, 1, v->down[li], nullptr, nullptr)) return r;
         res = fr[1];
         outb = fr[2];
       }
-      if (int r = conv(t1, Ho, Wo, C, outb, Ho, Wo, C, 1, 3, v->conv2[li][b], v->slope2[li][b].as<float>(), res)) return r;
+      if (direct128) {
+        if (launch_conv3x3_c128(t1, v->frag128[b == 0 ? 0 : 2].p, v->conv2[1][b].bias.as<float>(), v->slope2[1][b].as<float>(), res, outb, F, Ho, Wo, s))
+          return SVT_ERR_HIP;
+      } else if (int r = conv(t1, Ho, Wo, C, outb, Ho, Wo, C, 1, 3, v->conv2[li][b], v->slope2[li][b].as<float>(), res)) return r;
       x = outb; Hin = Ho; Win = Wo; cin = C;
     }
   }

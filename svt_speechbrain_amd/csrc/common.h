@@ -398,6 +398,9 @@ extern int g_conv3x3_c64, g_conv3x3_c64_launches, g_conv3x3_c64_form;
 bool conv3x3_c64_ok(int prec, int Hs, int Ws);
 int launch_conv3x3_c64(const void* in, const void* wimg, const float* bias, const float* slope, const void* resid, void* out, long F,
                        int Hs, int Ws, hipStream_t s);
+bool conv3x3_c128_ok(int prec, int Hs, int Ws);   // stage 2's stride-1 convolutions (128 -> 128 channels), same file
+int launch_conv3x3_c128(const void* in, const void* wimg, const float* bias, const float* slope, const void* resid, void* out, long F,
+                        int Hs, int Ws, hipStream_t s);
 // validation losses (masked BCE-with-logits / NLL, speechbrain/nnet/losses.py) and the narrow (log-)softmax
 int launch_bce_loss(const float* x, int64_t B, int64_t t_pred, const float* y, int64_t t_tgt, int64_t T, const float* rel_len,
                     const float* pos_weight, float* per_frame, double* sums, hipStream_t s);

@@ -149,6 +149,141 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same idea for the second trunk stage (128 -> 128 channels, 13 x 13 padded frames at an 88-pixel ROI; N20EMv2/video_only/
+// resnet.py:76-87 layer2's stride-1 convolutions): the GEMM kernels run these 128 columns wide at 0.45-0.66 PFLOP/s, bound by the
+// LDS-DMA of an im2col view that fetches every pixel nine times.  The 3x3 kernel is 295 KB -- exactly the eight waves' weight
+// registers (8 x 144 VGPRs x 256 B) -- so the split is by OUTPUT-CHANNEL QUARTER x INPUT-CHANNEL HALF: wave (cq, kh) holds 32 output
+// channels x 9 taps x 64 input channels as 36 A fragments, every wave walks ALL positions of the frame (triples of 16-position
+// blocks) reading only its input-channel half of each pixel (0.5 of the LDS port at full matrix rate), and the two input-channel
+// halves of a channel quarter meet through LDS: per triple one wave of the pair parks its 24 accumulator registers in a scratch
+// slot, the workgroup's barrier of the triple passes, the other adds them and runs the epilogue while its partner is already in
+// the next triple (the roles alternate by triple and frame).  Frames double-buffered as above; pixels are 256 B, chunks
+// XOR-swizzled by the slot's low four bits.
+template <bool RESID>
+__global__ __launch_bounds__(512) void conv3x3_c128_kernel(const bf16_t* __restrict__ in, const uint4* __restrict__ wimg,
+                                                           const float* __restrict__ bias, const float* __restrict__ slope,
+                                                           const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int F, int Hs,
+                                                           int Ws, unsigned fbytes) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cq = wave >> 1, kh = wave & 1;
+  const int Wp = Ws + 2, FP = (Hs + 2) * Wp, NV = Hs * Wp;
+  const int MB = (NV + 15) >> 4, NT = (MB + 2) / 3, NG = (FP + 3) >> 2;
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int G = gridDim.x;
+  float* scratch = (float*)(lds + 2 * fbytes);                 // [pair cq][triple parity][6][64 lanes] x 16 B
+  float* bs = scratch + 4 * 2 * 6 * 64 * 4;                    // bias[128], slope[128]
+
+  // frame tf -> buffer b: a request moves 4 pixels; lane (slot = lane >> 4, position q = lane & 15) fetches chunk q ^ (slot index & 15)
+  auto request = [&](long tf, int b) {
+    const bf16_t* fb = in + tf * (long)FP * 128;
+    for (int g = wave; g < NG; g += 8) {
+      int px = g * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ (px & 15);
+      px = px < FP ? px : FP - 1;
+      c3_dma16(fb + (long)px * 128 + c * 8, lds0 + (unsigned)b * fbytes + (unsigned)g * 1024u);
+    }
+  };
+  if ((int)blockIdx.x < F) request(blockIdx.x, 0);
+
+  const int n = lane & 15, kq = lane >> 4;
+  bf16x8 wr[9][2][2];
+  {
+    const uint4* wsrc = wimg + (long)wave * (36 * 64) + lane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wr[tap][ks][nb] = __builtin_bit_cast(bf16x8, wsrc[((tap * 2 + ks) * 2 + nb) * 64]);
+  }
+  const int c0 = cq * 32 + kq * 8;  // the lane's 8 output channels
+  const float rWp = 1.0f / (float)Wp;
+  if (tid < 128) { bs[tid] = bias[tid]; bs[128 + tid] = slope[tid]; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int buf = 0, fc = 0;
+  for (long f = blockIdx.x; f < F; f += G, buf ^= 1, ++fc) {
+    if (f + G < F) request(f + G, buf ^ 1);   // the other buffer: the barrier of the previous frame's last triple is behind every wave
+    const unsigned fb0 = (unsigned)buf * fbytes;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      // this wave adds the pair's halves and stores; the two waves of a SIMD (w, w + 4 = channel quarters cq, cq + 2) take opposite
+      // roles, so a SIMD always has one wave multiplying while the other converts and stores
+      const bool fin = ((t + fc + (cq >> 1)) & 1) == kh;
+      const int pl = t * 48 + n;
+      constexpr int RD = 3;
+      bf16x8 xb[RD][3];
+      auto fetch = [&](int g, bf16x8 (&x)[3]) {
+        const int tap = g >> 1;
+        const int sl = pl + (tap / 3) * Wp + (tap % 3);
+        const unsigned a0 = fb0 + (unsigned)(sl * 256 + ((((kh << 3) | kq) ^ (sl & 15)) << 4));
+        const unsigned ak = (g & 1) ? (a0 ^ 64u) : a0;
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) x[mb] = *(const bf16x8*)(lds + ak + mb * 4096);
+      };
+      fetch(0, xb[0]);
+      fetch(1, xb[1]);
+      f32x4 acc[3][2];
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 rs[3];
+#pragma unroll
+      for (int g = 0; g < 18; ++g) {
+        if (g + RD - 1 < 18) fetch(g + RD - 1, xb[(g + RD - 1) % RD]);
+        if (RESID && g == 17 && fin) {
+#pragma unroll
+          for (int mb = 0; mb < 3; ++mb) {
+            const int p = pl + mb * 16;
+            rs[mb] = *(const bf16x8*)(resid + (f * (long)FP + (p < NV ? p : 0) + Wp + 1) * 128 + c0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = SVT_MFMA_16x16x32(wr[g >> 1][g & 1][nb], xb[g % RD][mb], acc[mb][nb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float* sc = scratch + ((cq * 2 + (t & 1)) * 6 * 64 + lane) * 4;
+      if (!fin) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) *(f32x4*)(sc + (mb * 2 + nb) * 256) = acc[mb][nb];
+      }
+      if (t == NT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this frame's requests (a frame old) in front of its last barrier
+      __builtin_amdgcn_s_barrier();
+      if (fin) {
+        const float4 b0 = *(const float4*)(bs + c0), b1 = *(const float4*)(bs + c0 + 4);
+        const float4 s0 = *(const float4*)(bs + 128 + c0), s1 = *(const float4*)(bs + 128 + c0 + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) {
+          const int p = pl + mb * 16;
+          const int y = (int)(((float)p + 0.5f) * rWp);
+          const f32x4 h0 = *(const f32x4*)(sc + (mb * 2) * 256), h1 = *(const f32x4*)(sc + (mb * 2 + 1) * 256);
+          if (p < NV && p - y * Wp < Ws) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float a = acc[mb][j >> 2][j & 3] + (j < 4 ? h0[j & 3] : h1[j & 3]) + bv[j];
+              if (RESID) a += (float)rs[mb][j];
+              o[j] = (bf16_t)(a > 0.f ? a : a * sv[j]);
+            }
+            *(bf16x8*)(out + (f * (long)FP + p + Wp + 1) * 128 + c0) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int g_conv3x3_c64_form = 0;      // svt_debug_set key 25: C3_DBG bits << 4 (DIAG builds)
@@ -186,6 +321,41 @@ int launch_conv3x3_c64(const void* in, const void* wimg, const float* bias, cons
     return 0;
   };
   if (resid ? go(conv3x3_c64_kernel<true>) : go(conv3x3_c64_kernel<false>)) return 1;
+  return hipGetLastError() != hipSuccess;
+}
+
+
+static int c128_ring_slots(int Hs, int Ws) {
+  const int Wp = Ws + 2, FP = (Hs + 2) * Wp, MB = (Hs * Wp + 15) / 16, NT = (MB + 2) / 3;
+  const int need = NT * 48 + 2 * Wp + 2;   // the last triple's garbage positions read this far
+  return ((FP > need ? FP : need) + 7) / 8 * 8;
+}
+static size_t c128_lds_bytes(int Hs, int Ws) { return (size_t)2 * c128_ring_slots(Hs, Ws) * 256 + 4 * 2 * 6 * 1024 + 1024; }
+bool conv3x3_c128_ok(int prec, int Hs, int Ws) {
+  if (!g_conv3x3_c64 || prec != 1 || Hs < 1 || Ws < 1) return false;
+  return Hs * (Ws + 2) >= 48 && c128_lds_bytes(Hs, Ws) <= 160 * 1024;
+}
+// in / out / resid: [F][Hs+2][Ws+2][128] 16-bit, halos zero; wimg: fold_conv_frag128's image; bias / slope: 128 floats
+int launch_conv3x3_c128(const void* in, const void* wimg, const float* bias, const float* slope, const void* resid, void* out, long F,
+                        int Hs, int Ws, hipStream_t s) {
+  const size_t shm = c128_lds_bytes(Hs, Ws);
+  const unsigned fbytes = (unsigned)c128_ring_slots(Hs, Ws) * 256u;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1;
+    ncu = pr.multiProcessorCount;
+  }
+  const int grid = (int)(F < ncu ? F : ncu);
+  ++g_conv3x3_c64_launches;
+  auto go = [&](auto kern) -> int {
+    if (ensure_dyn_lds((const void*)kern, (int)shm)) return 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, s, (const bf16_t*)in, (const uint4*)wimg, bias, slope, (const bf16_t*)resid,
+                       (bf16_t*)out, (int)F, Hs, Ws, fbytes);
+    return 0;
+  };
+  if (resid ? go(conv3x3_c128_kernel<true>) : go(conv3x3_c128_kernel<false>)) return 1;
   return hipGetLastError() != hipSuccess;
 }
 

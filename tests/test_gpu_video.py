@@ -51,8 +51,8 @@ def test_video_frontend_bf16_error_bound(golden, name):
 def test_stage1_frame_resident_conv_against_the_gemm_path(precision, hw, B, T):
     """conv3x3_c64_kernel (two padded frames resident in LDS, the 3x3 weights in registers; ROIs of 50-88 pixels) against the same
     front-end with stage 1 on the GEMM kernels (svt_debug_set(23, 0)).  Same 16-bit storage, and the same fp32 summation order (tap by
-    tap, 32 channels per MFMA; the GEMM path's structural zeros add exact zeros): BIT-IDENTICAL, so svt_debug_set(24, 0)'s launch
-    count is the proof that the direct path ran.  600 frames = more than two frames per workgroup (both LDS buffers re-used), 7 = fewer
+    tap, 32 channels per MFMA; the GEMM path's structural zeros add exact zeros) in stage 1, two separately summed input-channel halves
+    in stage 2's conv3x3_c128_kernel: a few ulps of the activations, and svt_debug_set(24, 0)'s launch count proves the direct path ran.  600 frames = more than two frames per workgroup (both LDS buffers re-used), 7 = fewer
     frames than CUs; 92 pixels = two 25 x 25 padded frames do not fit the LDS and fall back."""
     lib = _lib.load("f16" if precision == "fp16" else "")
     m = SubModel(512, 256, "prelu", precision=precision, seed=5).to(DEV)
@@ -61,16 +61,24 @@ def test_stage1_frame_resident_conv_against_the_gemm_path(precision, hw, B, T):
     n0 = lib.svt_debug_set(24, 0)
     y = m(video).float()
     n1 = lib.svt_debug_set(24, 0)
-    assert n1 - n0 == (0 if hw == 92 else 4), "two BasicBlocks x two convolutions on the direct path"
+    # stage 1: two BasicBlocks x two convolutions, stage 2: its three stride-1 convolutions (92: neither fits the LDS)
+    assert n1 - n0 == (0 if hw == 92 else 7)
     assert torch.equal(y, m(video).float())
     lib.svt_debug_set(23, 0)
     try:
         ref = m(video).float()
     finally:
         lib.svt_debug_set(23, 1)
-    assert lib.svt_debug_set(24, 0) == n1 + (0 if hw == 92 else 4)
+    assert lib.svt_debug_set(24, 0) == 2 * n1 - n0
     assert torch.isfinite(y).all() and y.abs().max().item() > 1.0
-    assert torch.equal(y, ref)
+    # stage 1 is bit-identical to the GEMM path; stage 2 sums its two input-channel halves separately (another fp32 summation order)
+    d = (y - ref).abs()
+    scale = ref.abs().max().item()
+    print(f"direct convolutions {precision} {hw}: max |d| {d.max().item():.5f} mean {d.mean().item():.6f} scale {scale:.2f}")
+    if hw == 92:
+        assert torch.equal(y, ref)
+    else:
+        assert 0 < d.max().item() < 0.03 * scale and d.mean().item() < 0.003 * scale
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])

@@ -30,6 +30,9 @@ SHAPES = [  # name, M, N, K, conv(T_in, T_out, stride, Cin) or None, act, out_f3
     ("large_ffn2", 31936, 1024, 4096, None, 0, 1, 0),
     ("large_qkv", 31936, 3072, 1024, None, 0, 0, 0),
     ("large_out", 31936, 1024, 1024, None, 0, 1, 0),
+    ("conv1_noact", 32 * 15999, 512, 1536, (31999, 15999, 2, 512), 0, 0, 0),   # what the GELU epilogue costs: same products without it
+    ("ffn1_noact", 15968, 3072, 768, None, 0, 0, 0),
+    ("large_ffn1_noact", 31936, 4096, 1024, None, 0, 0, 0),
     ("b1_qkv", 249, 2304, 768, None, 0, 0, 0),       # one 5 s utterance (the recipes' evaluation batch)
     ("b1_out", 249, 768, 768, None, 0, 0, 0),
     ("b1_ffn1", 249, 3072, 768, None, 1, 0, 0),
