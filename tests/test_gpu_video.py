@@ -104,6 +104,34 @@ def test_fused_stem_and_maxpool_against_the_two_kernels(precision, hw, B, T):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("h,w", [(72, 88), (88, 64), (56, 80)])
+def test_non_square_roi_on_every_path(precision, h, w):
+    """Non-square lip ROIs (the C-ABI takes h and w separately; the reference crops 88 x 88): the round-4 kernels (fused stem + pool,
+    frame-resident stage 1-2 convolutions) against the kernels they replace, and the fp32 mode as the yardstick of both."""
+    lib = _lib.load("f16" if precision == "fp16" else "")
+    m = SubModel(512, 128, "prelu", precision=precision, seed=3).to(DEV)
+    m32 = SubModel(512, 128, "prelu", precision="fp32", seed=3).to(DEV)
+    g = torch.Generator().manual_seed(h * 100 + w)
+    video = torch.randn(2, 1, 37, h, w, generator=g).to(DEV)
+    n0 = lib.svt_debug_set(24, 0)
+    y = m(video).float()
+    assert lib.svt_debug_set(24, 0) - n0 == 7
+    lib.svt_debug_set(23, 0)
+    lib.svt_debug_set(26, 0)
+    try:
+        old = m(video).float()
+    finally:
+        lib.svt_debug_set(23, 1)
+        lib.svt_debug_set(26, 1)
+    ref = m32(video).float()
+    scale = ref.abs().max().item()
+    e_new, e_old = (y - ref).abs().max().item(), (old - ref).abs().max().item()
+    print(f"non-square {precision} {h}x{w}: new {e_new:.4f} old {e_old:.4f} scale {scale:.2f}")
+    lim = 0.06 if precision == "bf16" else 0.01
+    assert e_new < lim * scale and e_old < lim * scale and e_new < 1.5 * e_old + 1e-3 * scale
+
+
 def test_video_frontend_errors():
     m = SubModel(512, 64, "prelu", precision="fp32").to(DEV)
     with pytest.raises(ValueError):
