@@ -181,7 +181,17 @@ __global__ __launch_bounds__(512) void conv3d_front_bf16_kernel(const bf16_t* vp
 #endif
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 // bf16 / IEEE-half bits <-> int16 with the same ordering as the values (an involution: negative values get their magnitude bits flipped)
-__device__ __forceinline__ s16x8v ordered16(s16x8v u) { return u ^ ((u >> 15) & (short)0x7FFF); }
+// (on whole dwords: s - (s >> 15) turns each half's sign bit into 0x7FFF without a borrow between the halves; the vector-of-short form
+// compiles to per-element 16-bit operations, 41 instructions per 16 bytes instead of 16)
+__device__ __forceinline__ s16x8v ordered16(s16x8v u) {
+  u32x4v w = __builtin_bit_cast(u32x4v, u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned sg = w[i] & 0x80008000u;
+    w[i] ^= sg - (sg >> 15);
+  }
+  return __builtin_bit_cast(s16x8v, w);
+}
 __device__ __forceinline__ void stem_dma16(const void* gsrc, unsigned lds_byte_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
