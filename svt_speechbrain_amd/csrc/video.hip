@@ -446,7 +446,10 @@ int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bi
 
 int g_stem_pool_fused = 1;  // svt_debug_set key 26: 0 = stem and max-pool as two kernels (A/B, tests)
 static size_t stem_pool_lds(int Hp, int Wp, int W0) { return (size_t)6 * (((size_t)Hp * Wp * 2 + 1023) / 1024 * 1024) + (size_t)9 * W0 * 128 + 512; }
-bool conv3d_front_pool_ok(int prec, int Hp, int Wp, int W0) { return g_stem_pool_fused && prec == 1 && stem_pool_lds(Hp, Wp, W0) <= 160 * 1024; }
+// (the pool phase indexes its items as (4 rows, 32 columns, 8 chunks): pooled width (W0 + 1) / 2 <= 32)
+bool conv3d_front_pool_ok(int prec, int Hp, int Wp, int W0) {
+  return (g_stem_pool_fused & 1) && prec == 1 && W0 <= 64 && stem_pool_lds(Hp, Wp, W0) <= 160 * 1024;
+}
 // stem + 3x3/2 max-pool -> interior of the zero-haloed [F][H1+2][W1+2][64] (16-bit storage modes)
 int launch_conv3d_front_pool(const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp, int Wp, int H0,
                              int W0, int H1, int W1, void* out, hipStream_t s) {
