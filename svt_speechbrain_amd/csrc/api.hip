@@ -1849,8 +1849,9 @@ int fold_conv_group(const ParamMap& P, const std::string& wkey, const std::strin
   return upload_f32(out->bias, b2.data(), b2.size());
 }
 // 64 -> 64 channel 3x3 kernel + BN scale as conv3x3_c64_kernel's LDS image: [tap ky*3+kx][k-step][channel block nb][lane] x 8 values,
-// lane (i = lane & 15, kq = lane >> 4) = A-operand row i of block nb = output channel (i>>2)*16 + nb*4 + (i&3), input channels
-// ks*32 + kq*8 .. +7 (the row permutation leaves a lane of the MFMA result with 16 consecutive channels of one pixel)
+// lane (i = lane & 15, kq = lane >> 4) = A-operand row i of block nb = output channel (nb>>1)*32 + (i>>2)*8 + (nb&1)*4 + (i&3), input
+// channels ks*32 + kq*8 .. +7: a wave takes the two blocks of one channel half (nb>>1), a lane of its result then holds 8 consecutive
+// channels and the four lanes of a pixel 32 consecutive ones (whole 64-byte segments per store instruction)
 int fold_conv_frag64(const ParamMap& P, const std::string& wkey, const std::string& bnkey, DevBuf* out) {
   const Param* w = nullptr;
   if (int r = need(P, wkey, {64, 64, 3, 3}, &w)) return r;
@@ -1861,7 +1862,7 @@ int fold_conv_frag64(const ParamMap& P, const std::string& wkey, const std::stri
     for (int ks = 0; ks < 2; ++ks)
       for (int nb = 0; nb < 4; ++nb)
         for (int lane = 0; lane < 64; ++lane) {
-          const int i = lane & 15, kq = lane >> 4, co = (i >> 2) * 16 + nb * 4 + (i & 3);
+          const int i = lane & 15, kq = lane >> 4, co = (nb >> 1) * 32 + (i >> 2) * 8 + (nb & 1) * 4 + (i & 3);
           for (int e = 0; e < 8; ++e) {
             const int ci = ks * 32 + kq * 8 + e;
             t[((((size_t)tap * 2 + ks) * 4 + nb) * 64 + lane) * 8 + e] = w->v[(((size_t)co * 64 + ci) * 3 + tap / 3) * 3 + tap % 3] * sc[co];

@@ -8,7 +8,7 @@
 // time are of the same size.  So: ONE persistent workgroup per CU, 8 waves = 4 position groups x 2 channel halves.
 //   weights  a wave's half of the 3x3 kernel (32 output channels x 576) lives in its REGISTERS as 36 ready-made MFMA A fragments
 //            (144 VGPRs, fetched once per kernel; the row permutation of the fragment leaves a lane of the result 8 consecutive
-//            channels of one pixel = one 16-byte store);
+//            channels of one pixel = one 16-byte store, and the four lanes of a pixel its whole 64-byte half);
 //   frames   two padded frames (FP = (Hs+2)(Ws+2) pixels x 128 B, XOR-swizzled 16-byte chunks) in LDS, the next one filled by
 //            LDS-DMA while this one is computed: every input pixel is fetched from memory once;
 //   flat     output position p = y (Ws+2) + x reads input positions p + ky (Ws+2) + kx -- a tap is an address offset; the two
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restri
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) wr[tap][ks][nb] = __builtin_bit_cast(bf16x8, wimg[((tap * 2 + ks) * 4 + ch * 2 + nb) * 64 + lane]);
-  const int c0 = kq * 16 + ch * 8;  // the lane's 8 output channels
+  const int c0 = ch * 32 + kq * 8;  // the lane's 8 output channels (the four lanes of a pixel: 64 contiguous bytes)
   const float rWp = 1.0f / (float)Wp;
   // bias / slope behind the two frame buffers (registers are for the weights)
   float* bs = (float*)(lds + 2 * fbytes);
