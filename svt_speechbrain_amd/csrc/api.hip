@@ -536,6 +536,7 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
   return SVT_OK;
 }
 
+static int g_conv_down_fused = 1;   // svt_debug_set key 27: 0 = stage 2's stride-2 conv1 and its 1x1 downsample as two products (A/B, tests)
 int svt_debug_set(int key, int value) {
   if (key == 0) g_gemm_dbg = value;
   else if (key == 1) g_gemm_force_bm = value;
@@ -561,6 +562,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 24) return g_conv3x3_c64_launches;
   else if (key == 25) g_conv3x3_c64_form = value;
   else if (key == 26) g_stem_pool_fused = value;
+  else if (key == 27) g_conv_down_fused = value;
   else { set_error("svt_debug_set: unknown key"); return SVT_ERR_INVALID; }
   return SVT_OK;
 }
@@ -1756,6 +1758,7 @@ struct svt_video {
   DevBuf gslope1[2][2], gslope2[2][2];
   DevBuf slope2[4][2];
   DevBuf frag1[2], frag2[2];  // stage 1, 16-bit storage: the 3x3 kernels as MFMA fragment images (conv3x3_c64.hip)
+  VConv comb2;                // stage 2, block 0: conv1 (3x3 / 2) and the 1x1 / 2 downsample as ONE 256-column product (see svt_video_finalize)
   DevBuf frag128[3];          // stage 2's stride-1 convolutions: block 0 conv2, block 1 conv1 / conv2 (conv3x3_c128_kernel)
   DevBuf proj_w, proj_b;
 };
@@ -1971,6 +1974,33 @@ int svt_video_finalize(svt_video* v) {
       if (int r = upload_vec(P, pre + ".relu2.weight", C, &v->slope2[li][b])) return r;
       if (b == 0 && li > 0)
         if (int r = fold_conv(v->prec, P, pre + ".downsample.0.weight", pre + ".downsample.1", C, cin, 1, &v->down[li])) return r;
+      if (li == 1 && b == 0 && v->prec) {
+        // The 1x1 stride-2 downsample reads exactly the centre tap of conv1's 3x3 stride-2 window: as 128 more output columns of the
+        // same product (weights zero outside the centre tap's 64 input channels, slope 1 = no activation) it rides in the half of the
+        // 256-column tile that conv1 alone leaves empty, and the separate 168 us launch disappears.  Columns >= 128 go to the next
+        // stage buffer (GemmArgs::c_nsplit).
+        const Param *w1 = nullptr, *wd = nullptr, *sl = nullptr;
+        if (int r = need(P, pre + ".conv1.weight", {128, 64, 3, 3}, &w1)) return r;
+        if (int r = need(P, pre + ".downsample.0.weight", {128, 64, 1, 1}, &wd)) return r;
+        if (int r = need(P, pre + ".relu1.weight", {128}, &sl)) return r;
+        std::vector<float> s1, b1, sd, bd;
+        if (int r = bn_fold(P, pre + ".bn1", 128, &s1, &b1)) return r;
+        if (int r = bn_fold(P, pre + ".downsample.1", 128, &sd, &bd)) return r;
+        std::vector<float> t((size_t)256 * 576, 0.f), bb(256), ss(256);
+        for (int co = 0; co < 128; ++co) {
+          bb[co] = b1[co]; ss[co] = sl->v[co];
+          bb[128 + co] = bd[co]; ss[128 + co] = 1.0f;
+          for (int ci = 0; ci < 64; ++ci) {
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx)
+                t[(size_t)co * 576 + (size_t)(ky * 3 + kx) * 64 + ci] = w1->v[(((size_t)co * 64 + ci) * 3 + ky) * 3 + kx] * s1[co];
+            t[(size_t)(128 + co) * 576 + (size_t)4 * 64 + ci] = wd->v[(size_t)co * 64 + ci] * sd[co];
+          }
+        }
+        if (int r = upload_operand(v->prec, v->comb2.w, t.data(), t.size())) return r;
+        if (int r = upload_f32(v->comb2.bias, bb.data(), bb.size())) return r;
+        if (int r = upload_f32(v->comb2.slope, ss.data(), ss.size())) return r;
+      }
       if (li == 1 && v->prec) {
         if (b == 1)
           if (int r = fold_conv_frag128(P, pre + ".conv1.weight", pre + ".bn1", &v->frag128[1])) return r;
@@ -2031,13 +2061,14 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
 
   // one k x k convolution (k = 3: pad 1; k = 1: no pad) over the zero-haloed channels-last tensor `in`
   auto conv = [&](const void* in, int Hin, int Win, int Cin, void* out, int Ho, int Wo, int Cout, int stride, int k,
-                  const VConv& cw, const float* slope, const void* resid) -> int {
+                  const VConv& cw, const float* slope, const void* resid, long second_out = 0) -> int {
     GemmArgs a;
     const long Wpi = Win + 2, Hpi = Hin + 2, Wpo = Wo + 2, Hpo = Ho + 2;
     a.gen = 1;
     a.A = (const char*)in + (k == 1 ? (size_t)(Wpi + 1) * Cin * es : 0);
     a.W = cw.w.p; a.C = out; a.bias = cw.bias.as<float>();
-    a.M = (int)(F * Ho * Wo); a.N = Cout; a.K = k * k * Cin;
+    a.M = (int)(F * Ho * Wo); a.N = second_out ? 2 * Cout : Cout; a.K = k * k * Cin;
+    a.c_nsplit = second_out ? Cout : 0; a.c_nstride = second_out;   // columns >= Cout: the tensor second_out elements behind `out`
     a.a_rstride = (long)stride * Cin;
     a.a_d1 = Wo; a.a_e1 = (long)stride * Wpi * Cin - (long)Wo * stride * Cin;
     a.a_d2 = Wo * Ho; a.a_e2 = Hpi * Wpi * Cin - (long)Ho * stride * Wpi * Cin;
@@ -2112,11 +2143,20 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
       if (direct128 && stride == 1) {
         if (launch_conv3x3_c128(x, v->frag128[1].p, v->conv1[1][b].bias.as<float>(), v->conv1[1][b].slope.as<float>(), nullptr, t1, F, Ho, Wo, s))
           return SVT_ERR_HIP;
-      } else if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
-      if (stride == 2) {  // first block of stages 2-4: the residual is the 1x1 stride-2 conv + BN of the block input
-        if (int r = conv(x, Hin, Win, cin, fr[1], Ho, Wo, C, 2, 1, v->down[li], nullptr, nullptr)) return r;
+      } else if (li == 1 && stride == 2 && v->gp == 1 && g_conv_down_fused && (const char*)fr[1] > (const char*)t1 &&
+                 ((const char*)fr[1] - (const char*)t1) % (16 * es) == 0) {
+        // conv1 + downsample as one 256-column product (svt_video_finalize): t1 <- columns 0..127, fr[1] <- columns 128..255
+        if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, 2, 3, v->comb2, v->comb2.slope.as<float>(), nullptr,
+                         (long)(((const char*)fr[1] - (const char*)t1) / es))) return r;
         res = fr[1];
         outb = fr[2];
+      } else {
+        if (int r = conv(x, Hin, Win, cin, t1, Ho, Wo, C, stride, 3, v->conv1[li][b], v->conv1[li][b].slope.as<float>(), nullptr)) return r;
+        if (stride == 2) {  // first block of stages 2-4: the residual is the 1x1 stride-2 conv + BN of the block input
+          if (int r = conv(x, Hin, Win, cin, fr[1], Ho, Wo, C, 2, 1, v->down[li], nullptr, nullptr)) return r;
+          res = fr[1];
+          outb = fr[2];
+        }
       }
       if (direct128) {
         if (launch_conv3x3_c128(t1, v->frag128[b == 0 ? 0 : 2].p, v->conv2[1][b].bias.as<float>(), v->slope2[1][b].as<float>(), res, outb, F, Ho, Wo, s))

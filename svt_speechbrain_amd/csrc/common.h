@@ -217,6 +217,8 @@ struct GemmArgs {
   long kseg_stride = 0;
   int c_d1 = 1, c_d2 = 1;            // C (and resid) row offset = c_base + m * ldc + (m / c_d1) * c_e1 + (m / c_d2) * c_e2
   long c_e1 = 0, c_e2 = 0, c_base = 0;
+  int c_nsplit = 0;                  // gen: columns >= c_nsplit belong to a SECOND output tensor of the same row addressing, c_nstride
+  long c_nstride = 0;                // elements behind the first (column n there = n - c_nsplit); multiples of 8
   const float* slope = nullptr;      // ACT_PRELU: per-column negative slope
   int resid_first = 0;               // act(acc + bias + resid) instead of act(acc + bias) + resid
   int resid_op_type = 0;             // resid is stored in the operand type (bf16 in bf16 mode), not fp32

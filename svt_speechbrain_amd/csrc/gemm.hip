@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmArgs p) {
     for (int mb = 0; mb < 4; ++mb) {
       const int m = m0 + wm * 64 + mb * 16 + (lane & 15);
       if (m >= p.M) continue;
-      const long idx = coff + p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + nbase;
+      const long idx = coff + p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + nbase +
+                       (p.c_nsplit && nbase >= p.c_nsplit ? p.c_nstride - p.c_nsplit : 0);
       float v[16], rs[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) rs[j] = 0.f;

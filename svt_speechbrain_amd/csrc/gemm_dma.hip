@@ -212,7 +212,8 @@ __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, f32x4 (&ac
     if (r < 16 && m < p.M && n < p.N) {
       const float4 v0 = *(const float4*)(patch + r * PITCH + c8), v1 = *(const float4*)(patch + r * PITCH + c8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const long idx = p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + n;
+      const long idx = p.c_base + (long)m * p.ldc + (long)(m / p.c_d1) * p.c_e1 + (long)(m / p.c_d2) * p.c_e2 + n +
+                       (p.c_nsplit && n >= p.c_nsplit ? p.c_nstride - p.c_nsplit : 0);
       float rr[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) rr[j] = 0.f;

@@ -132,6 +132,26 @@ def test_non_square_roi_on_every_path(precision, h, w):
     assert e_new < lim * scale and e_old < lim * scale and e_new < 1.5 * e_old + 1e-3 * scale
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("hw,B,T", [(88, 2, 40), (60, 1, 9), (92, 1, 6)])
+def test_stage2_downsample_inside_conv1_product(precision, hw, B, T):
+    """Stage 2, block 0: the 1x1 stride-2 downsample as columns 128..255 of conv1's 3x3 stride-2 product (centre-tap weights, slope 1;
+    GemmArgs::c_nsplit sends them to the next buffer) against the two separate products (svt_debug_set(27, 0)): the extra K range
+    multiplies exact zeros -> bit-identical."""
+    lib = _lib.load("f16" if precision == "fp16" else "")
+    m = SubModel(512, 128, "prelu", precision=precision, seed=11).to(DEV)
+    g = torch.Generator().manual_seed(hw + 3 * T)
+    video = torch.randn(B, 1, T, hw, hw, generator=g).to(DEV)
+    y = m(video).float()
+    lib.svt_debug_set(27, 0)
+    try:
+        ref = m(video).float()
+    finally:
+        lib.svt_debug_set(27, 1)
+    assert torch.isfinite(y).all() and y.abs().max().item() > 1.0
+    assert torch.equal(y, ref)
+
+
 def test_video_frontend_errors():
     m = SubModel(512, 64, "prelu", precision="fp32").to(DEV)
     with pytest.raises(ValueError):
