@@ -289,7 +289,9 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * rows per wave (1, default) or one (0), 21 = fused attention variant (0 = staggered wave groups, 1 = the round-3 lockstep kernel),
  * 22 = conv layer 0 on the matrix pipe in the 16-bit modes (1, default) or on the vector ALU (0), 23 = stage 1 of the lip front-end on
  * the frame-resident direct convolution (1, default; conv3x3_c64.hip) or on the GEMM kernels (0), 24 = query: returns the number of
- * direct-convolution launches of this process so far (value ignored).
+ * direct-convolution launches of this process so far (value ignored), 25 = timing-ablation bits of the direct convolution (DIAG builds),
+ * 26 = stem + max-pool of the lip front-end as one persistent kernel (1, default) or as two kernels (0), 27 = stage 2's 1x1 stride-2
+ * downsample inside conv1's product (1, default) or as its own product (0).
  * Returns 0 (key 24: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);
 
