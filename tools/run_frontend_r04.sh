@@ -11,7 +11,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 python bench.py > "$O/r04_bench_final_tree.json" 2> "$O/bench.err"
 (python tools/av_bench.py; python tools/rca_bench.py) 2>&1 | grep -v amdgpu.ids > "$O/r04_c4_av_bench.txt"
 (echo "round-4 kernels (default):"; python tools/video_bench.py 2>&1 | tail -1
- echo "stage 1-2 on the GEMM kernels, stem and pool as two kernels, scalar pad excluded (svt_debug_set 23=0, 26=0):"; python tools/video_bench.py --debug 23=0,26=0 2>&1 | tail -1
+ echo "stage 1-2 on the GEMM kernels, stem and pool as two kernels, downsample as its own product (svt_debug_set 23=0, 26=0, 27=0; the pad kernel stays the new one):"; python tools/video_bench.py --debug 23=0,26=0,27=0 2>&1 | tail -1
  echo "fp16 build:"; python tools/video_bench.py --precision fp16 2>&1 | tail -1) > "$O/r04_video_frontend_ab.txt"
 bash tools/video_trace.sh r04_front/r04_video_frontend_kernel_trace_summary
 bash tools/c1_trace.sh r04_front/r04_c1_kernel_trace_summary
