@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 O="gpurun_out/r04_front"
 mkdir -p "$O"
 FILT='^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path'
-(time python -m pytest tests -q -m gpu -x 2>&1 | grep -v "$FILT" | tail -6) > "$O/r04_gputests.log" 2>&1
+(time python -m pytest tests -q -m gpu -x 2>&1 | grep -v "$FILT" | tail -40) > "$O/r04_gputests.log" 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 python bench.py > "$O/r04_bench_final_tree.json" 2> "$O/bench.err"
 (python tools/av_bench.py; python tools/rca_bench.py) 2>&1 | grep -v amdgpu.ids > "$O/r04_c4_av_bench.txt"
