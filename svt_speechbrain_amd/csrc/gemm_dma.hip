@@ -174,7 +174,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const f32x4& a
 // PReLU slope.  bf16 output only.  NBW = 16-column MFMA blocks per wave (tile width 64 * NBW).
 template <int MB, int BM, int NBW, int I>
 __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, f32x4 (&acc)[NBW][MB], float* patch, int lane, int wm,
-                                                   int wn, int m0, int n0, const float* bias) {
+                                                   int wn, int m0, int n0, const float (&bb)[8], const float (&ss)[8]) {
   constexpr int WC = 16 * NBW;       // columns per wave
   constexpr int PITCH = WC + 4;      // floats
   constexpr int LPR = 2 * NBW;       // lanes per row on the read-back side (8 columns each)
@@ -192,19 +192,6 @@ __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, f32x4 (&ac
   const int mbase = m0 + wm * (BM / 2) + I * 16;
   const int c8 = (lane % LPR) * 8;
   const int n = n0 + wn * WC + c8;
-  float bb[8], ss[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { bb[j] = 0.f; ss[j] = 0.f; }
-  if (n < p.N) {
-    if (bias) {
-      const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
-      bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-    }
-    if (p.slope) {
-      const float4 s0 = *(const float4*)(p.slope + n), s1 = *(const float4*)(p.slope + n + 4);
-      ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
-    }
-  }
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     const int r = pass * RPP + lane / LPR;
@@ -242,7 +229,23 @@ __device__ __forceinline__ void epilogue_block_gen(const GemmArgs& p, f32x4 (&ac
 template <int MB, int BM, int NBW, int... I>
 __device__ __forceinline__ void epilogue_seq_gen(std::integer_sequence<int, I...>, const GemmArgs& p, f32x4 (&acc)[NBW][MB],
                                                  float* patch, int lane, int wm, int wn, int m0, int n0, const float* bias) {
-  (epilogue_block_gen<MB, BM, NBW, I>(p, acc, patch, lane, wm, wn, m0, n0, bias), ...);
+  // bias / slope of the lane's 8 columns ONCE per tile: inside the per-block function they sit behind its wave fences, where the
+  // compiler re-issues the four loads for every 16-row block and every block waits out their round trip
+  const int n = n0 + wn * (16 * NBW) + (lane % (2 * NBW)) * 8;
+  float bb[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bb[j] = 0.f; ss[j] = 0.f; }
+  if (n < p.N) {
+    if (bias) {
+      const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
+      bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
+    if (p.slope) {
+      const float4 s0 = *(const float4*)(p.slope + n), s1 = *(const float4*)(p.slope + n + 4);
+      ss[0] = s0.x; ss[1] = s0.y; ss[2] = s0.z; ss[3] = s0.w; ss[4] = s1.x; ss[5] = s1.y; ss[6] = s1.z; ss[7] = s1.w;
+    }
+  }
+  (epilogue_block_gen<MB, BM, NBW, I>(p, acc, patch, lane, wm, wn, m0, n0, bb, ss), ...);
 }
 
 template <int MB, int BM, bool OUT32, int... I>
