@@ -3,6 +3,7 @@
 reference.  Tolerances: fp32 parity mode — logits within 1e-3 (north star) and identical per-frame
 argmax / note sequences; bf16 throughput mode — reported error bound + decode agreement rate."""
 import hashlib
+import json
 import os
 import sys
 
@@ -112,11 +113,18 @@ def simulated_error(name, fx, mode):
     measured figures: a change of summation order inside a kernel moves near-tie frames without being a regression."""
     key = (name, mode)
     if key not in _SIM_CACHE:
-        tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
-        if tools not in sys.path:
-            sys.path.insert(0, tools)
-        import sim_split
-        _SIM_CACHE[key] = sim_split.simulate(fx, mode)
+        # tests/golden/sim_bounds.json holds the simulation's figures for every bound case (tests/golden/make_sim_bounds.py writes it, the
+        # CPU suite re-derives the cases that take seconds: tests/test_host_cpu.py); a case it does not hold is simulated here
+        table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sim_bounds.json")
+        cached = json.load(open(table)).get(name, {}).get(mode) if os.path.exists(table) else None
+        if cached is not None:
+            _SIM_CACHE[key] = tuple(cached)
+        else:
+            tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+            if tools not in sys.path:
+                sys.path.insert(0, tools)
+            import sim_split
+            _SIM_CACHE[key] = sim_split.simulate(fx, mode)
     return _SIM_CACHE[key]
 
 
@@ -144,7 +152,7 @@ BOUND_CASES = ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "da
 @pytest.mark.parametrize("name", BOUND_CASES)
 def test_bf16_mode_error_bound(golden, name):
     """bf16 MFMA operands, fp32 accumulate / residual / norms: error bounded by a multiple of what rounding the operands to bf16 costs
-    in a CPU simulation of the same case (computed here, not frozen: see check_16bit_mode_bound) -- i.e. the price of bf16 operands on
+    in a CPU simulation of the same case (tools/sim_split.py, not a frozen kernel measurement: see check_16bit_mode_bound) -- i.e. the price of bf16 operands on
     these random-init weights (base 5 s clip: simulation 0.38 max / 0.080 mean / 15 of 249 frames; kernels 0.44 / 0.081 / 18)."""
     fx = golden(name)
     cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], "bf16")

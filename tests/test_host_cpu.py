@@ -674,3 +674,23 @@ def test_operand_rounding_simulation_brackets_the_exact_oracle():
     assert 0.02 < b1[0] < 0.3 and b1[0] > 4 * h1[0]
     assert b3[0] < 1e-3 and h3[0] < 1e-4
     assert b1[2] == h1[2] == b3[2] == h3[2] == 0 and b1[3] == fx["logits"].shape[0] * fx["logits"].shape[1]
+
+
+def test_committed_simulation_bounds_are_what_the_simulation_gives():
+    """tests/golden/sim_bounds.json (the yardstick the GPU suite holds the 16-bit modes to) against a fresh run of tools/sim_split.py on
+    the cases that take seconds here; every bound case of the GPU suite must be in the table."""
+    import json
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_split
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "sim_bounds.json")))
+    for name in ("tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"):
+        assert set(table[name]) == {"bf16x1", "f16x1"}
+    torch.set_num_threads(8)
+    for name in ("tiny_group", "tiny_layer", "base_c1"):
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
+        for mode in ("bf16x1", "f16x1"):
+            mx, mean, mism, frames = sim_split.simulate(fx, mode)
+            t = table[name][mode]
+            # another BLAS thread count may move the last bits of a sum, hence a near-tie frame
+            assert abs(mx - t[0]) <= 0.02 * t[0] + 1e-5 and abs(mean - t[1]) <= 0.01 * t[1] + 1e-6 and abs(mism - t[2]) <= 1 and frames == t[3], (name, mode)
