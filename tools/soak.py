@@ -12,7 +12,33 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--iters", type=int, default=300)
 ap.add_argument("--precision", default="bf16")
+ap.add_argument("--video", action="store_true", help="soak the lip front-end (16 x --frames lip ROIs of 88 x 88) instead of an audio encoder: two "
+                "front-end objects on two streams, every output compared bit for bit (no atomics in that path)")
+ap.add_argument("--frames", type=int, default=500)
 a = ap.parse_args()
+if a.video:
+    from svt_speechbrain_amd.video import SubModel
+    dev = "cuda:0"
+    B = min(a.batch, 16)
+    ms = [SubModel(512, 1024, "prelu", precision=a.precision, seed=4).to(dev) for _ in range(2)]
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(B, 1, a.frames, 88, 88, generator=g).to(dev)
+    ref = ms[0](x).clone()
+    torch.cuda.synchronize()
+    streams[1].wait_stream(streams[0])
+    bad, outs, t0 = 0, [], time.time()
+    for i in range(a.iters):
+        k = i % 2
+        with torch.cuda.stream(streams[k]):
+            outs.append((ms[k](x) != ref).any())
+        if len(outs) == 20 or i + 1 == a.iters:
+            torch.cuda.synchronize()
+            bad += sum(int(o.item()) for o in outs)
+            outs = []
+    print(f"lip front-end B={B} x {a.frames} frames {a.precision}: {a.iters} forwards in {time.time() - t0:.1f} s on two streams, "
+          f"{bad} forwards differ from the first")
+    sys.exit(1 if bad else 0)
 dev = "cuda:0"
 cfg = S.PRESETS[a.model]
 enc = S.HuggingFaceWav2Vec2(a.model, None, config=cfg, precision=a.precision, seed=3).to(dev)
