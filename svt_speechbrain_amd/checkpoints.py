@@ -26,12 +26,12 @@ Checkpoint.__hash__ = lambda self: hash(self.path)
 
 
 def ckpt_recency(ckpt: Checkpoint):
-    """Importance key: later ``unixtime`` is more important."""
+    """Ranking function of the default selection: the save time recorded in the meta file."""
     return ckpt.meta["unixtime"]
 
 
 def torch_recovery(obj, path, end_of_epoch=True, device=None):
-    """``obj.load_state_dict(torch.load(path))``, strict when the object's load_state_dict accepts it."""
+    """Default loader of a ``<name>.ckpt`` file: a torch-saved state dict, loaded strictly where the object takes ``strict``."""
     del end_of_epoch
     state = torch.load(path, map_location=device or "cpu")
     try:
@@ -40,9 +40,14 @@ def torch_recovery(obj, path, end_of_epoch=True, device=None):
         obj.load_state_dict(state)
 
 
-def _is_checkpoint_dir(path: pathlib.Path) -> bool:
-    path = pathlib.Path(path)
-    return path.is_dir() and path.name.startswith(CKPT_PREFIX) and (path / METAFNAME).exists()
+def _read_checkpoint_dir(folder: pathlib.Path) -> Optional[Checkpoint]:
+    """``CKPT+<name>/`` with its ``CKPT.yaml`` -> record; anything else in the save folder -> None."""
+    meta_file = folder / METAFNAME
+    if not (folder.is_dir() and folder.name.startswith(CKPT_PREFIX) and meta_file.exists()):
+        return None
+    with open(meta_file) as fh:
+        meta = yaml.safe_load(fh)
+    return Checkpoint(folder, meta, {f.stem: f for f in folder.glob("*" + PARAMFILE_EXT)})
 
 
 class Checkpointer:
@@ -64,70 +69,62 @@ class Checkpointer:
             self.custom_load_hooks[name] = custom_load_hook
 
     def add_recoverables(self, recoverables):
-        if isinstance(recoverables, collections.abc.Mapping):
-            self.recoverables.update(recoverables)
-        else:
-            raise AttributeError(f"Checkpointer needs a mapping (e.g. dict), got {recoverables!r} instead.")
+        if not isinstance(recoverables, collections.abc.Mapping):
+            raise AttributeError(f"recoverables must map names to objects, got {type(recoverables).__name__}")
+        self.recoverables.update(recoverables)
 
     # ---- listing / selection ----
     def list_checkpoints(self) -> List[Checkpoint]:
-        out = []
         if not self.checkpoints_dir.is_dir():
-            return out
-        for d in self.checkpoints_dir.iterdir():
-            if not _is_checkpoint_dir(d):
-                continue
-            with open(d / METAFNAME) as fi:
-                meta = yaml.load(fi, Loader=yaml.SafeLoader)
-            files = {f.stem: f for f in d.iterdir() if f.suffix == PARAMFILE_EXT}
-            out.append(Checkpoint(d, meta, files))
-        return out
+            return []
+        found = (_read_checkpoint_dir(d) for d in self.checkpoints_dir.iterdir())
+        return [c for c in found if c is not None]
 
     def find_checkpoints(self, importance_key=None, max_key=None, min_key=None, ckpt_predicate=None,
                          max_num_checkpoints=None) -> List[Checkpoint]:
-        if importance_key is None and min_key is None and max_key is None:
-            importance_key = ckpt_recency
-        if max_key and not importance_key:
-            def importance_key(ckpt):
-                return ckpt.meta[max_key]
-            user_pred = ckpt_predicate
-
-            def ckpt_predicate(ckpt):
-                return max_key in ckpt.meta and (user_pred is None or user_pred(ckpt))
-        elif min_key and not importance_key:
-            def importance_key(ckpt):
-                return -ckpt.meta[min_key]
-            user_pred = ckpt_predicate
-
-            def ckpt_predicate(ckpt):
-                return min_key in ckpt.meta and (user_pred is None or user_pred(ckpt))
-        elif min_key or max_key:
-            raise ValueError("Must specify only one of 'importance_key', 'max_key', and 'min_key'.")
-        ckpts = list(filter(ckpt_predicate, self.list_checkpoints()))
-        ckpts = sorted(ckpts, key=ckpt_recency, reverse=True)  # stable: importance ties go to the most recent
-        ranked = sorted(ckpts, key=importance_key, reverse=True)
-        return ranked if max_num_checkpoints is None else ranked[:max_num_checkpoints]
+        """Checkpoints best-first.  Ranking: ``importance_key(ckpt)`` descending, or the meta entry ``max_key`` descending
+        / ``min_key`` ascending (then only checkpoints whose meta carries that entry take part; ``max_key`` wins if both
+        names are given, as in the reference), or — with nothing given — save time.  Equal ranks: latest first.  A
+        ranking function together with a key name is the one combination refused."""
+        named = max_key or min_key
+        if importance_key is not None and named:
+            raise ValueError("pass either importance_key or one of max_key / min_key, not both")
+        if importance_key is not None:
+            score, needs = importance_key, None
+        elif max_key:
+            score, needs = (lambda c: c.meta[max_key]), max_key
+        elif min_key:
+            score, needs = (lambda c: -c.meta[min_key]), min_key
+        else:
+            score, needs = ckpt_recency, None
+        pool = [c for c in self.list_checkpoints()
+                if (needs is None or needs in c.meta) and (ckpt_predicate is None or ckpt_predicate(c))]
+        pool.sort(key=ckpt_recency, reverse=True)   # list.sort is stable: the second sort keeps latest-first among equals
+        pool.sort(key=score, reverse=True)
+        return pool if max_num_checkpoints is None else pool[:max_num_checkpoints]
 
     def find_checkpoint(self, importance_key=None, max_key=None, min_key=None, ckpt_predicate=None) -> Optional[Checkpoint]:
-        found = self.find_checkpoints(importance_key, max_key, min_key, ckpt_predicate)
-        return found[0] if found else None
+        ranked = self.find_checkpoints(importance_key, max_key, min_key, ckpt_predicate, max_num_checkpoints=1)
+        return ranked[0] if ranked else None
 
     # ---- loading ----
     def load_checkpoint(self, checkpoint: Checkpoint, device=None):
-        end_of_epoch = checkpoint.meta["end-of-epoch"]
+        """Every registered object takes its ``<name>.ckpt``: through its custom hook if one was registered, else through
+        ``torch_recovery`` if it has ``load_state_dict``.  A registered name without a file is an error unless
+        ``allow_partial_load``."""
+        at_epoch_end = checkpoint.meta["end-of-epoch"]
         for name, obj in self.recoverables.items():
-            try:
-                loadpath = checkpoint.paramfiles[name]
-            except KeyError:
-                if self.allow_partial_load:
-                    continue
-                raise RuntimeError(f"Loading checkpoint from {checkpoint.path}, but missing a load path for {name}")
-            if name in self.custom_load_hooks:
-                self.custom_load_hooks[name](obj, loadpath, end_of_epoch, device)
-            elif hasattr(obj, "load_state_dict"):
-                torch_recovery(obj, loadpath, end_of_epoch, device)
-            else:
-                raise RuntimeError(f"Don't know how to load {type(obj)}. Register default hook or add custom hook for this object.")
+            source = checkpoint.paramfiles.get(name)
+            if source is None:
+                if not self.allow_partial_load:
+                    raise RuntimeError(f"{checkpoint.path} holds no {name}{PARAMFILE_EXT} for the registered object {name!r}")
+                continue
+            loader = self.custom_load_hooks.get(name)
+            if loader is None:
+                if not hasattr(obj, "load_state_dict"):
+                    raise RuntimeError(f"{name!r} ({type(obj).__name__}) has neither a custom load hook nor load_state_dict")
+                loader = torch_recovery
+            loader(obj, source, at_epoch_end, device)
 
     def recover_if_possible(self, importance_key=None, max_key=None, min_key=None, ckpt_predicate=None, device=None):
         chosen = self.find_checkpoint(importance_key, max_key, min_key, ckpt_predicate)

@@ -27,13 +27,13 @@ def read_manifest(path: str) -> List[Dict[str, str]]:
     with open(path, newline="") as fh:
         rd = csv.DictReader(fh, skipinitialspace=True)
         if rd.fieldnames is None or "ID" not in rd.fieldnames:
-            raise KeyError("CSV has to have an 'ID' field, with unique ids for all data points")
+            raise KeyError(f"manifest {path}: no 'ID' column (every row needs a unique ID)")
         missing = [c for c in CSV_COLUMNS if c not in rd.fieldnames]
         if missing:
             raise KeyError(f"manifest {path} lacks the columns {missing}")
         for row in rd:
             if row["ID"] in seen:
-                raise ValueError(f"Duplicate id: {row['ID']}")
+                raise ValueError(f"manifest {path}: ID {row['ID']!r} appears twice")
             seen.add(row["ID"])
             row = dict(row)
             row["duration"] = float(row["duration"])
@@ -75,27 +75,36 @@ def slice_annotation(anno: torch.Tensor, utter_id, utter_num, frame_rate: float 
 
 
 def batch_pad_right(tensors: Sequence[torch.Tensor], mode: str = "constant", value=0):
-    """Right-pad dim 0 to the longest item and stack; second result = relative lengths (len / max_len)."""
-    if not len(tensors):
-        raise IndexError("Tensors list must not be empty")
-    if len(tensors) == 1:
-        return tensors[0].unsqueeze(0), torch.tensor([1.0])
-    if not any(tensors[i].ndim == tensors[0].ndim for i in range(1, len(tensors))):
-        raise IndexError("All tensors must have same number of dimensions")
-    for dim in range(1, tensors[0].ndim):
-        if not all(x.shape[dim] == tensors[0].shape[dim] for x in tensors[1:]):
-            raise EnvironmentError("Tensors should have same dimensions except for the first one")
-    max_len = max(x.shape[0] for x in tensors)
-    batched, valid = [], []
-    for t in tensors:
-        pads = [0, 0] * (t.ndim - 1) + [0, max_len - t.shape[0]]
-        batched.append(torch.nn.functional.pad(t, pads, mode=mode, value=value))
-        valid.append(t.shape[0] / max_len)
-    return torch.stack(batched), torch.tensor(valid)
+    """Stack items that differ only in their leading extent: item ``i`` occupies ``out[i, :len_i]``, the rest of the row
+    holds ``value``.  Returns ``(out, len_i / longest)``.  An empty list is an ``IndexError``; items of different rank or
+    different trailing extents cannot share a row layout (``IndexError`` / ``EnvironmentError``, the exception types the
+    reference's callers catch)."""
+    count = len(tensors)
+    if count == 0:
+        raise IndexError("batch_pad_right: nothing to batch (empty list)")
+    first = tensors[0]
+    if count == 1:
+        return first.unsqueeze(0), torch.ones(1)
+    rank, tail = first.ndim, tuple(first.shape[1:])
+    if all(t.ndim != rank for t in tensors[1:]):     # the reference lets a batch through as long as ONE other item agrees
+        raise IndexError(f"batch_pad_right: no other item has the first item's rank ({rank})")
+    for idx, t in enumerate(tensors):
+        if t.ndim == rank and tuple(t.shape[1:]) != tail:
+            raise EnvironmentError(f"batch_pad_right: item {idx} has trailing shape {tuple(t.shape[1:])}, the batch has {tail}")
+    extents = [int(t.shape[0]) for t in tensors]
+    longest = max(extents)
+    if mode == "constant":
+        out = first.new_full((count, longest) + tail, value)
+        for row, t, n in zip(out, tensors, extents):
+            row[:n] = t
+    else:  # reflect / replicate / circular: torch's own padding, one item at a time
+        grow = lambda t, n: torch.nn.functional.pad(t, [0, 0] * (rank - 1) + [0, longest - n], mode=mode)  # noqa: E731
+        out = torch.stack([grow(t, n) for t, n in zip(tensors, extents)])
+    return out, torch.tensor([n / longest for n in extents])
 
 
 class PaddedData(tuple):
-    """``(data, lengths)`` pair, attribute access like speechbrain's namedtuple."""
+    """``(data, lengths)`` pair that also answers ``.data`` / ``.lengths``."""
     __slots__ = ()
 
     def __new__(cls, data, lengths):
@@ -104,55 +113,76 @@ class PaddedData(tuple):
     data = property(lambda self: self[0])
     lengths = property(lambda self: self[1])
 
+    def to(self, *args, **kwargs):
+        return PaddedData(self[0].to(*args, **kwargs), self[1].to(*args, **kwargs))
+
+
+def _as_tensor_if_array(v):
+    """numeric numpy arrays become tensors (what torch's default_convert does); strings / objects are left alone"""
+    kind = getattr(getattr(v, "dtype", None), "kind", None)
+    return torch.as_tensor(v) if type(v).__module__ == "numpy" and kind is not None and kind not in "USO" else v
+
+
+def _gather_plain(column):
+    """a column that is not padded: Python numbers -> one tensor (the recipes read ``batch.cur_utter.item()``), same-shape
+    tensors -> stacked, anything else (ids, paths, ragged tensors) stays a list"""
+    head = column[0]
+    if isinstance(head, (bool, int)):
+        return torch.tensor(column)
+    if isinstance(head, float):
+        return torch.tensor(column, dtype=torch.float64)
+    if isinstance(head, torch.Tensor) and all(isinstance(v, torch.Tensor) and v.shape == head.shape for v in column):
+        return torch.stack(list(column), 0)
+    return column
+
 
 class PaddedBatch:
-    """Collate a list of example dicts: tensor-valued keys are right-padded into ``PaddedData(data, lengths)``, other
-    keys become lists (``speechbrain/dataio/batch.py:101-137``).  ``batch.sig`` -> ``(wavs, wav_lens)`` as
-    ``compute_forward`` unpacks it; ``to(device)`` moves the padded tensors."""
+    """A batch as the recipes consume it (the contract of ``speechbrain/dataio/batch.py:101-178``): built from a list of
+    example dicts, one COLUMN per key held in ``self._columns``.  Tensor-valued columns (or exactly those named in
+    ``padded_keys``) become ``PaddedData(data, lengths)`` via ``batch_pad_right``; the others are gathered by
+    ``_gather_plain``.  Columns read as attributes and items (``batch.sig`` -> ``(wavs, wav_lens)``, as
+    ``compute_forward`` unpacks it), iterate in key order, and ``to(device)`` moves the tensor-valued ones (or those named
+    in ``device_prep_keys``)."""
 
     def __init__(self, examples: Sequence[dict], padded_keys=None, device_prep_keys=None, padding_kwargs=None):
-        self.__length = len(examples)
-        self.__keys = list(examples[0].keys())
-        self.__padded_keys = []
-        self.__device_prep_keys = []
-        for key in self.__keys:
-            values = [ex[key] for ex in examples]
-            # default_convert: numpy arrays become tensors, everything else is left alone
-            values = [torch.as_tensor(v) if type(v).__module__ == "numpy" and getattr(v, "dtype", None) is not None
-                      and v.dtype.kind not in "USO" else v for v in values]
-            if (padded_keys is not None and key in padded_keys) or (padded_keys is None and isinstance(values[0], torch.Tensor)):
-                self.__padded_keys.append(key)
-                setattr(self, key, PaddedData(*batch_pad_right(values, **(padding_kwargs or {}))))
-            else:
-                # mod_default_collate: Python numbers become one tensor (batch.cur_utter.item() in the recipes), equal-size
-                # tensors are stacked, strings and ragged items stay lists
-                if isinstance(values[0], bool) or isinstance(values[0], (int, float)):
-                    values = torch.tensor(values, dtype=torch.float64 if isinstance(values[0], float) else None)
-                elif isinstance(values[0], torch.Tensor):
-                    try:
-                        values = torch.stack(values, 0)
-                    except RuntimeError:
-                        pass
-                setattr(self, key, values)
-            if (device_prep_keys is not None and key in device_prep_keys) or (device_prep_keys is None and isinstance(values[0], torch.Tensor)):
-                self.__device_prep_keys.append(key)
+        columns, movable = {}, []
+        for name in examples[0]:
+            column = [_as_tensor_if_array(ex[name]) for ex in examples]
+            tensor_valued = isinstance(column[0], torch.Tensor)
+            pad = tensor_valued if padded_keys is None else name in padded_keys
+            columns[name] = PaddedData(*batch_pad_right(column, **(padding_kwargs or {}))) if pad else _gather_plain(column)
+            if tensor_valued if device_prep_keys is None else name in device_prep_keys:
+                movable.append(name)
+        object.__setattr__(self, "_columns", columns)
+        object.__setattr__(self, "_movable", movable)
+        object.__setattr__(self, "_size", len(examples))
 
     def __len__(self):
-        return self.__length
+        return self._size
 
-    def __getitem__(self, key):
-        if key in self.__keys:
-            return getattr(self, key)
-        raise KeyError(f"Batch doesn't have key: {key}")
+    def __getattr__(self, name):  # only reached for names that are not real attributes: the columns
+        try:
+            return self.__dict__["_columns"][name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __setattr__(self, name, value):
+        if name in self._columns:
+            self._columns[name] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    def __getitem__(self, name):
+        if name not in self._columns:
+            raise KeyError(f"this batch has no column {name!r} (columns: {list(self._columns)})")
+        return self._columns[name]
 
     def __iter__(self):
-        return iter(getattr(self, key) for key in self.__keys)
+        return iter(self._columns.values())
 
     def to(self, *args, **kwargs):
-        for key in self.__device_prep_keys:
-            v = getattr(self, key)
-            if isinstance(v, PaddedData):
-                setattr(self, key, PaddedData(v.data.to(*args, **kwargs), v.lengths.to(*args, **kwargs)))
-            elif isinstance(v, torch.Tensor):
-                setattr(self, key, v.to(*args, **kwargs))
+        for name in self._movable:
+            held = self._columns[name]
+            if isinstance(held, (PaddedData, torch.Tensor)):
+                self._columns[name] = held.to(*args, **kwargs)
         return self
