@@ -22,6 +22,8 @@ After the timed region (never part of `value`):
                       (s_memtime / s_memrealtime) on either side: the clock the chip HELD under this load;
   * notes-out leg  -- step + device-to-host copy of the decoded frames + `frames2note` of every clip
                       (`notes_out_clips_per_s`: "greedy decode" all the way to note lists on the host);
+  * parity leg     -- one forward of the same batch in the timed dtype and one in the exact-fp32 mode: max |dlogit|, frames whose
+                      argmax differs, clips with identical note lists, note-level precision / recall (`parity`, and `verified`);
   * parity-grade leg -- the same workload in precision "fp16x3", the fast mode that meets the north star's tolerance
                       (`parity_grade`: clips/s, its own roofline fraction against 2.5 PF / 3, max |dlogit| vs the exact fp32 mode);
   * cpu_baseline   -- the oracle on the host cores, SURVEY.md §8(d) protocol (rank 0, N = 1 only).
@@ -47,6 +49,16 @@ import torch  # noqa: E402
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
+# What each numeric mode promises against the exact-fp32 mode (README "Numeric modes"; asserted by tests/test_gpu_parity.py on the
+# goldens and checked here on the bench batch): largest |dlogit|, share of frames whose octave / pitch-class argmax may differ, and the
+# note-level COnPOff F1 of the mode's notes against the exact mode's.  Only fp32 and fp16x3 meet north_star's "1e-3 + identical notes".
+PARITY_BOUNDS = {
+    "fp32":   {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.0, "COnPOff_f1": 1.0},
+    "fp16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.0, "COnPOff_f1": 1.0},
+    "bf16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.003, "COnPOff_f1": 0.99},
+    "fp16":   {"max_abs_dlogit": 0.12, "frames_mismatch_frac": 0.02, "COnPOff_f1": 0.95},
+    "bf16":   {"max_abs_dlogit": 1.0, "frames_mismatch_frac": 0.15, "COnPOff_f1": 0.80},
+}
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
 
 
@@ -249,8 +261,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3", "fp16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained and notes-out legs (profiling runs)")
-    ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity-grade (fp16x3) leg of the default bf16 line")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained, notes-out, parity and parity-grade legs (profiling runs)")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip the parity leg (timed dtype vs the exact-fp32 mode: logits, frames, notes) and the parity-grade (fp16x3) leg of the default bf16 line")
     ap.add_argument("--sustain-seconds", type=float, default=3.2)
     ap.add_argument("--gather", default="logits", choices=["logits", "frames"],
                     help="N > 1: all-gather the fp32 logits (80 B per frame, the north star's collective) or the compact decoded "
@@ -489,6 +501,37 @@ def main():
                              "(the reference's frame2note semantics, MIR_ST500/utils.py:82-149); one step per lane stays in flight "
                              "while the host assembles the notes of the step that just finished; host_ms_per_step = the frame2note share"}
 
+    # parity leg: what the TIMED dtype computes against the exact-fp32-MFMA mode on the same batch, same weights, at the three levels
+    # north_star names -- logits (1e-3), per-frame argmax, and the note lists out of frame2note with note-level precision / recall
+    # (svt_speechbrain_amd/agreement.py; MIR_ST500/train_audio_ssl.py:93-134, utils.py:82-149).  One extra forward per mode, local
+    # shard, after the timed region.  The weights are seeded random (no network): near-tie rates of a trained checkpoint may differ.
+    parity = None
+    ref_logits = ref_frames = None
+    if not args.no_parity_leg and not args.no_extra_legs:
+        from svt_speechbrain_amd.agreement import mode_agreement
+        torch.cuda.synchronize()
+        t_par = time.perf_counter()
+        ref_enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision="fp32", normalize_wav=True, seed=1986).to(dev)
+        ref_frames = torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev)
+        ref_logits = ref_enc.forward_head(wav, head, frames=ref_frames)
+        own_frames = torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev)
+        own_logits = enc.forward_head(wav, head, frames=own_frames)
+        torch.cuda.synchronize()
+        del ref_enc
+        parity = mode_agreement(own_logits, own_frames, ref_logits, ref_frames, 0.4, 0.5, 1 / 49.8)
+        bound = PARITY_BOUNDS[args.precision]
+        parity.update({"mode": args.precision, "reference_mode": "fp32 (exact fp32 MFMA), same library, same batch and weights",
+                       "thresholds": {"onset": 0.4, "offset": 0.5, "frame_size_s": round(1 / 49.8, 6)},
+                       "stated_bound": bound,
+                       "within_stated_bound": bool(parity["max_abs_dlogit"] <= bound["max_abs_dlogit"] and
+                                                   parity["frames_argmax_mismatch"] <= bound["frames_mismatch_frac"] * parity["frames"] and
+                                                   parity["COnPOff_f1"] >= bound["COnPOff_f1"]),
+                       "seconds": round(time.perf_counter() - t_par, 2),
+                       "what": "timed dtype vs exact mode over the rank's whole batch: |dlogit|, frames whose octave / pitch-class argmax differs, "
+                               "clips whose frame2note lists are identical, note-level precision / recall / F1 of this mode's notes against the "
+                               "exact mode's (COnPOff / COnP / COn, 50 ms onset, 50 cents, offset 20 % / 50 ms; micro-averaged over the clips)"})
+        del own_logits, own_frames
+
     # parity-grade leg (bf16 default line only): the SAME workload in the mode that meets north_star's tolerance ("frame logits within
     # 1e-3 fp32, bit-identical argmax / note sequences": MIR_ST500/train_audio_ssl.py:93-100 -> utils.py:110-146), precision
     # "fp16x3" (three 16-bit MFMAs per algorithmic multiply-add, fp32 accumulate): 3 warm-up + 10 timed steps on the same two lanes
@@ -496,7 +539,7 @@ def main():
     # fraction (against 2.5 PF / 3), and the largest |logit - fp32 logit| over the batch's first two clips (the exact-fp32-MFMA
     # mode on the whole batch: the whole-batch norms see the same clips).
     parity_grade = None
-    if not args.no_extra_legs and not args.no_parity_leg and args.precision == "bf16":
+    if not args.no_extra_legs and not args.no_parity_leg and args.precision == "bf16" and parity is not None:
         pg_prec = "fp16x3"
         pg_encs = [S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=pg_prec, normalize_wav=True, seed=1986).to(dev)]
         pg_encs += [pg_encs[0].replica() for _ in range(ns - 1)]
@@ -522,15 +565,12 @@ def main():
         pg_dom, pg_attn = prof(0), prof(2)
         pg_logits = pg_last[0].clone()
         del pg_encs, pg_fwds
-        ref_enc = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision="fp32", normalize_wav=True, seed=1986).to(dev)
-        ref_frames = torch.empty((hi - lo, T, 4), dtype=torch.int32, device=dev)
-        ref_logits = ref_enc.forward_head(wav, head, frames=ref_frames)
         torch.cuda.synchronize()
-        ncmp = min(2, hi - lo)
-        dmax = float((pg_logits[:ncmp] - ref_logits[:ncmp]).abs().max().item())
-        same_frames = bool(torch.equal(pg_frames[0][:ncmp, :, 2:], ref_frames[:ncmp, :, 2:]))
-        bf16_dmax = float((out[lo:lo + ncmp].float() - ref_logits[:ncmp]).abs().max().item()) if (not gather_frames) else None
-        del ref_enc
+        pg_agree = mode_agreement(pg_logits, pg_frames[0], ref_logits, ref_frames, 0.4, 0.5, 1 / 49.8)
+        ncmp = hi - lo
+        dmax = pg_agree["max_abs_dlogit"]
+        same_frames = pg_agree["frames_argmax_mismatch"] == 0
+        bf16_dmax = parity["max_abs_dlogit"]
         pg_peak = MFMA_PEAK_TFLOPS[pg_prec]
         pg_ach = (pg_dom[2] / 1e12) / (pg_dom[1] / 1e3) if pg_dom[1] > 0 else 0.0
         pg_cps = n_total * pg_steps / pres["elapsed"]
@@ -539,6 +579,7 @@ def main():
                         "max_abs_dlogit_vs_fp32": dmax, "clips_compared": ncmp, "tolerance": 1e-3,
                         "octave_pitch_argmax_identical_to_fp32": same_frames,
                         "bf16_line_max_abs_dlogit_vs_fp32": bf16_dmax,
+                        "agreement_with_fp32": pg_agree,
                         "end_to_end_mfma_frac": round(pg_cps / world * cfg.flops_per_clip(L) / (pg_peak * 1e12), 4),
                         "roofline": {"bound": "mfma", "achieved": round(pg_ach, 2), "peak": round(pg_peak, 1), "unit": "TFLOP/s (algorithmic)",
                                      "frac": round(pg_ach / pg_peak, 4), "launches": int(pg_dom[0]),
@@ -590,7 +631,10 @@ def main():
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates
             "rccl_ranks": res["ranks"],
-            "verified": verified,
+            # --verify: the gathered rows against a local recomputation of every shard.  Without it (N = 1): the parity leg's verdict --
+            # the timed dtype's logits / frames / notes against the exact mode, within the bound stated for that dtype (PARITY_BOUNDS)
+            "verified": verified if verified is not None else (parity["within_stated_bound"] if parity is not None else None),
+            "parity": parity,
             "collective": None if world == 1 else {"op": "all_gather_into_tensor", "payload": args.gather,
                                                    "bytes_per_rank_per_step": gatherers[0].bytes_per_rank(),
                                                    "backend": torch.distributed.get_backend(),

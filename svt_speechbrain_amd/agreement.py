@@ -1,0 +1,82 @@
+"""How far one numeric mode's transcription is from another's, at the three levels the north star names:
+
+* logits  — max / mean ``|logit - reference logit|`` (the "frame logits within 1e-3" bar);
+* frames  — frames whose decoded octave or pitch class differs (the per-frame argmax of
+  ``MIR_ST500/train_audio_ssl.py:93-100``), and the largest onset / offset probability difference;
+* notes   — the note lists both sides produce through ``frame2note`` (``MIR_ST500/utils.py:82-149``, the library's host
+  routine ``svt_frames_to_notes``): clips whose lists are identical, and note-level precision / recall / F-measure of
+  the mode's notes against the reference mode's notes with the recipes' scoring (``scoring.score_song``: COnPOff, COnP,
+  COn — ``train_audio_ssl.py:119-134``), micro-averaged over the batch.
+
+``bench.py`` runs it after the timed region (timed dtype against the exact-fp32 mode, same batch, same weights) and the
+GPU suite asserts the same numbers as bounds.  Host code: numpy on frames already copied from the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .decode import FRAME_DTYPE, frames2note_batch
+from . import scoring
+
+
+def _frames_host(frames) -> np.ndarray:
+    """(clips, T, 4) int32 device / host tensor, or a structured array -> structured (clips, T)."""
+    if isinstance(frames, torch.Tensor):
+        frames = frames.detach().cpu().contiguous().numpy()
+    fr = np.ascontiguousarray(frames)
+    if fr.dtype != FRAME_DTYPE:
+        fr = fr.view(FRAME_DTYPE).reshape(fr.shape[:-1])
+    return fr
+
+
+def note_agreement(est_notes, ref_notes) -> Dict[str, float]:
+    """Micro-averaged note metrics over a batch of clips: matched / estimated / reference note counts summed over the clips
+    before the ratios are taken (a clip without notes on either side contributes its counts, not a 0 / 0)."""
+    keys = {"COnPOff": ("Precision", "Recall"), "COnP": ("Precision_no_offset", "Recall_no_offset"), "COn": ("Onset_Precision", "Onset_Recall")}
+    matched = {k: 0.0 for k in keys}
+    n_est = n_ref = 0
+    identical = 0
+    for est, ref in zip(est_notes, ref_notes):
+        identical += int(est == ref)
+        n_est += len(est)
+        n_ref += len(ref)
+        if est and ref:
+            sc = scoring.score_song(est, ref)
+            for k, (pk, _) in keys.items():
+                matched[k] += sc[pk] * len(est)     # precision x estimated notes = size of the matching
+    out: Dict[str, float] = {"clips": len(ref_notes), "clips_with_identical_notes": identical, "notes": n_est, "reference_notes": n_ref}
+    for k in keys:
+        m = round(matched[k])
+        p = m / n_est if n_est else (1.0 if n_ref == 0 else 0.0)
+        r = m / n_ref if n_ref else (1.0 if n_est == 0 else 0.0)
+        out[f"{k}_precision"], out[f"{k}_recall"] = round(p, 6), round(r, 6)
+        out[f"{k}_f1"] = round(0.0 if p + r == 0 else 2 * p * r / (p + r), 6)
+    return out
+
+
+def mode_agreement(logits: torch.Tensor, frames, ref_logits: torch.Tensor, ref_frames, onset_thres: float = 0.4,
+                   offset_thres: float = 0.5, frame_size: float = 1 / 49.8, lengths: Optional[np.ndarray] = None) -> Dict[str, object]:
+    """Everything above for one batch: ``logits`` (clips, T, 20) and ``frames`` (clips, T, 4 x int32, what the fused tail /
+    ``svt_decode_frames`` wrote) of the mode under test against the reference mode's."""
+    d = (logits.detach().float() - ref_logits.detach().float()).abs()
+    fr, rf = _frames_host(frames), _frames_host(ref_frames)
+    if fr.shape != rf.shape:
+        raise ValueError(f"mode_agreement: frame arrays of different shape {fr.shape} vs {rf.shape}")
+    differ = (fr["octave"] != rf["octave"]) | (fr["pitch_class"] != rf["pitch_class"])
+    notes = frames2note_batch(fr, onset_thres, offset_thres, frame_size, lengths)
+    ref_notes = frames2note_batch(rf, onset_thres, offset_thres, frame_size, lengths)
+    out: Dict[str, object] = {
+        "max_abs_dlogit": float(d.max().item()) if d.numel() else 0.0,
+        "mean_abs_dlogit": float(d.mean().item()) if d.numel() else 0.0,
+        "frames": int(differ.size),
+        "frames_argmax_mismatch": int(differ.sum()),
+        "max_abs_dp_onset": float(np.abs(fr["p_on"] - rf["p_on"]).max()) if differ.size else 0.0,
+        "max_abs_dp_offset": float(np.abs(fr["p_off"] - rf["p_off"]).max()) if differ.size else 0.0,
+    }
+    out.update(note_agreement(notes, ref_notes))
+    out["meets_1e-3_and_identical_notes"] = bool(out["max_abs_dlogit"] <= 1e-3 and out["frames_argmax_mismatch"] == 0 and
+                                                 out["clips_with_identical_notes"] == out["clips"])
+    return out

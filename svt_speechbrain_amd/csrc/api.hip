@@ -474,11 +474,27 @@ int svt_debug_gemm_pairs(int32_t precision, const float* a, int64_t a_elems, con
   SVT_HIP(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   void *ap = nullptr, *cp = nullptr;
-  if (dev_alloc(&ap, (size_t)a_elems * 4)) return SVT_ERR_HIP;
-  if (out_kind && dev_alloc(&cp, (size_t)m * n * 4)) { dev_free(ap); return SVT_ERR_HIP; }
-  int rc = launch_f32_to_pairs(precision, a, ap, a_elems, s);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // one exit: the staging buffers, the events and (unless svt_debug_set key 13 keeps it) the registered split weight are released on
+  // every path, including a failed HIP call in the middle
+  static std::mutex s_mu;          // s_kept is shared by every caller of this hook
   static const void* s_kept = nullptr;
-  if (!rc && !(g_debug_keep_split && s_kept == w)) { rc = split_weights_register(w, n, k, precision, s); s_kept = w; }
+  std::lock_guard<std::mutex> lock(s_mu);
+  bool registered = false;
+  auto hip_ok = [](hipError_t e, const char* what) -> int {
+    if (e == hipSuccess) return 0;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return 1;
+  };
+  int rc = dev_alloc(&ap, (size_t)a_elems * 4);
+  if (!rc && out_kind) rc = dev_alloc(&cp, (size_t)m * n * 4);
+  if (!rc) rc = launch_f32_to_pairs(precision, a, ap, a_elems, s);
+  if (!rc && !(g_debug_keep_split && s_kept == w)) {
+    rc = split_weights_register(w, n, k, precision, s);
+    if (!rc) { s_kept = w; registered = true; }
+  } else if (!rc) {
+    registered = true;
+  }
   if (!rc) {
     GemmArgs g;
     g.A = ap; g.W = w; g.C = out_kind == 1 ? cp : (void*)c; g.bias = bias;
@@ -487,23 +503,22 @@ int svt_debug_gemm_pairs(int32_t precision, const float* a, int64_t a_elems, con
     if (out_kind == 2) { g.planes = (unsigned short*)cp; g.plane_stride = (long)m * n; }
     rc = launch_gemm(precision, g, s);
     if (!rc && time_iters > 0 && ms_out) {   // micro-benchmark: HIP events around `time_iters` more launches of the product alone
-      hipEvent_t e0, e1;
-      SVT_HIP(hipEventCreate(&e0)); SVT_HIP(hipEventCreate(&e1));
-      SVT_HIP(hipEventRecord(e0, s));
+      rc = hip_ok(hipEventCreate(&e0), "hipEventCreate") || hip_ok(hipEventCreate(&e1), "hipEventCreate") ||
+           hip_ok(hipEventRecord(e0, s), "hipEventRecord");
       for (int i = 0; i < time_iters && !rc; ++i) rc = launch_gemm(precision, g, s);
-      SVT_HIP(hipEventRecord(e1, s));
-      SVT_HIP(hipEventSynchronize(e1));
       float ms = 0.f;
-      SVT_HIP(hipEventElapsedTime(&ms, e0, e1));
-      *ms_out = ms / (float)time_iters;
-      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      if (!rc) rc = hip_ok(hipEventRecord(e1, s), "hipEventRecord") || hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") ||
+                    hip_ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+      if (!rc) *ms_out = ms / (float)time_iters;
     }
   }
   if (!rc && out_kind == 1) rc = launch_pairs_to_f32(precision, cp, nullptr, c, (int64_t)m * n, s);
   if (!rc && out_kind == 2) rc = launch_pairs_to_f32(precision, cp, (const unsigned short*)cp + (size_t)m * n, c, (int64_t)m * n, s);
   (void)hipStreamSynchronize(s);
-  if (!g_debug_keep_split) { split_weights_forget(w); s_kept = nullptr; }
-  dev_free(ap);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (registered && !g_debug_keep_split) { split_weights_forget(w); s_kept = nullptr; }
+  if (ap) dev_free(ap);
   if (cp) dev_free(cp);
   return rc ? SVT_ERR_INVALID : SVT_OK;
 }
@@ -1326,23 +1341,32 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     }
     final_x = w.xF;
   } else if (!c.stable_layer_norm && pk_enc) {
-    // split modes on pair rows: the layer input w.xb (pair rows) IS the residual stream -- LN(branch + (hi + lo)) -> (hi', lo') in place,
-    // 12 bytes per element and pass instead of 16 with an fp32 copy beside it (hi + lo carries 22 of fp32's 24 mantissa bits; the
-    // products see exactly these pieces either way); the last layer also writes the fp32 result for the whole-batch output norm
-    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, nullptr, s, nullptr,
+    // split modes on pair rows.  fp16 pieces (kind 3): the layer input w.xb (pair rows) IS the residual stream -- LN(branch + (hi + lo))
+    // -> (hi', lo') in place, 12 bytes per element and pass instead of 16 with an fp32 copy beside it: hi + lo of two IEEE halves
+    // carries 22 of fp32's 24 mantissa bits.  bf16 pieces (kind 2) carry 16: there the residual stream stays fp32 (w.xF, updated in
+    // place) beside the pair rows the products read, as in round 3.  The products see exactly the same pieces either way; the last
+    // layer also leaves the fp32 result for the whole-batch output norm.
+    const bool pair_resid = pk_enc == 3;
+    float* const keepF = pair_resid ? nullptr : w.xF;
+    if (int r = launch_layernorm(prec, w.preF, 1, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps, 0, nullptr, keepF, s, nullptr,
                                  nullptr, w.xb, pk_enc)) return r;
+    auto ln_resid = [&](const float* g_, const float* b_, bool want_f32) -> int {
+      if (pair_resid)
+        return launch_layernorm(prec, tmp, 1, rows, D, g_, b_, eps, 0, nullptr, want_f32 ? w.xF : nullptr, s, nullptr, nullptr, w.xb,
+                                pk_enc, w.xb);
+      // every lane holds its part of the row in registers before anything is stored: add and yF may be the same buffer
+      return launch_layernorm(prec, tmp, 1, rows, D, g_, b_, eps, 0, nullptr, w.xF, s, w.xF, nullptr, w.xb, pk_enc, nullptr);
+    };
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
       const bool last = l + 1 == c.num_layers;
       if (int r = gemm_rows(w.xb, D, Lw.wqkv, Lw.bqkv, 3 * D, w.qkv, 0, ACT_NONE, nullptr, qkv_pl)) return r;
       if (int r = attention()) return r;
       if (int r = gemm_rows(w.attn_o, D, Lw.wo, Lw.bo, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps, 0, nullptr, nullptr, s, nullptr,
-                                   nullptr, w.xb, pk_enc, w.xb)) return r;
+      if (int r = ln_resid(Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), false)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 1, ACT_GELU, nullptr, nullptr, 1)) return r;
       if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 1, ACT_NONE, nullptr)) return r;
-      if (int r = launch_layernorm(prec, tmp, 1, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps, 0, nullptr, last ? w.xF : nullptr, s,
-                                   nullptr, nullptr, w.xb, pk_enc, w.xb)) return r;
+      if (int r = ln_resid(Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), last)) return r;
     }
     final_x = w.xF;
   } else if (!c.stable_layer_norm) {

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restri
 
   // the requesting waves wait for their requests (vmcnt(0)) in front of the epilogue of their LAST triple of a frame: the requests are
   // a frame old by then, and the stores of that epilogue stay in flight across the barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: the bs stores reach the LDS before the first barrier lets readers through
   int buf = 0;
   for (long f = blockIdx.x; f < F; f += G, buf ^= 1) {
     if (pg >= NT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,7 +202,9 @@ __global__ __launch_bounds__(512) void conv3x3_c128_kernel(const bf16_t* __restr
   const int c0 = cq * 32 + kq * 8;  // the lane's 8 output channels
   const float rWp = 1.0f / (float)Wp;
   if (tid < 128) { bs[tid] = bias[tid]; bs[128 + tid] = slope[tid]; }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // vmcnt: the first frame's requests; lgkmcnt: the bs stores above -- a raw s_barrier does not wait for a wave's own LDS writes
+  // on gfx950 (back-off barrier: hipcc inserts no s_waitcnt in front of it), and the readers sit on other SIMDs
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   int buf = 0, fc = 0;
@@ -258,6 +260,9 @@ __global__ __launch_bounds__(512) void conv3x3_c128_kernel(const bf16_t* __restr
           for (int nb = 0; nb < 2; ++nb) *(f32x4*)(sc + (mb * 2 + nb) * 256) = acc[mb][nb];
       }
       if (t == NT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this frame's requests (a frame old) in front of its last barrier
+      // the parked accumulators must be IN the LDS before the partner wave (another SIMD) is let through: the raw barrier does not
+      // wait for this wave's ds_writes by itself
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (fin) {
         const float4 b0 = *(const float4*)(bs + c0), b1 = *(const float4*)(bs + c0 + 4);

@@ -480,6 +480,11 @@ int g_gemm_x3 = 1;
 // split-operand products (every other argument as for prec 0)
 int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
+  // pair rows are understood by the split-operand LDS-DMA kernels only: every other kernel would read them as fp32 words
+  if ((a.a_pairs || a.c_pairs) && (prec_in < 2 || !g_gemm_x3)) {
+    set_error("gemm: pair-row operands / outputs need a split-operand precision and the LDS-DMA split kernels (svt_debug_set key 11 = 1)");
+    return -1;
+  }
   if (a.planes) {
     // C as (hi, lo) planes (split-operand modes only): written by the LDS-DMA split kernel's epilogue; any other kernel writes the
     // fp32 C and the planes are cut from it afterwards
@@ -534,6 +539,7 @@ int launch_gemm(int prec_in, const GemmArgs& a, hipStream_t s) {
     const int r = launch_gemm_x3(prec_in, g, s);
     if (r <= 0) return r;
   }
+  if (a.a_pairs || a.c_pairs) { set_error("gemm: this geometry is outside the pair-row kernels' contract"); return -1; }
   // split engine: two slabs in flight per workgroup, capped at 256 registers so that two workgroups share a CU (measured
   // on the encoder's shapes, tools/gemm_bench.py --prec 2: one set 185-212, two sets 186-212, three sets (one workgroup per
   // CU) 150-192 TFLOP/s: the kernel is bound by issue / barrier stalls of its four-wave lockstep, not by the loads)

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void conv3d_front_pool_kernel(const bf16_t* __
     if (b != cur_b) {   // first frame of the run, or a new clip: all five planes
       for (int dt = 0; dt < 5; ++dt) request_plane(b, t + dt);
       cur_b = b;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: the bs stores of the kernel's head
       __builtin_amdgcn_s_barrier();
     }
     if (f + 1 < f1 && t + 1 < Tt && !STEM_DBG(4)) request_plane(b, t + 5);   // the next frame's new plane into the slot plane t - 1 left
@@ -288,6 +288,9 @@ __global__ __launch_bounds__(512) void conv3d_front_pool_kernel(const bf16_t* __
       }
       // the requests of this frame are waited for once, in front of the last band's barrier (a frame old by then)
       if (bi == nbands - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the band's ds_writes (and, on the first pass, the bs stores) land before any wave pools them: a raw s_barrier does not
+      // wait for a wave's own LDS stores on gfx950
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       // pool: slot = (pool row of the band, x1 padded to 32, chunk) -- shifts only; window coordinates clamped instead of skipped (a
       // duplicate does not change a maximum), so the nine reads go out together; the maximum is taken on the order-preserving int16
