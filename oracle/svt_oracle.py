@@ -504,8 +504,11 @@ def avhubert_video_forward(sd: Dict[str, torch.Tensor], cfg, video: torch.Tensor
     """``FairseqAVHubertPretrain.extract_features`` for {"video": video, "audio": None}
     (N20EMv2/video_only/fairseq_interface.py:461-476 over hubert.py:688-739): lip front-end -> cat([zeros, video], dim=C)
     -> LayerNorm(2E) -> post_extract_proj -> TransformerEncoder -> optional whole-tensor layer norm.
-    PARITY UNPINNED for the transformer part: fairseq (and hubert.py, which imports it) is not importable in the build
-    container; the restatement relies on the fairseq encoder being the module HF ported (pinned for the audio path)."""
+    PINNED (round 5) by tests/golden/video_glue.pt for everything the reference itself holds: make_golden.py runs the reference's
+    own ``FairseqAVHubertPretrain.forward`` -> ``AVHubertModel.extract_finetune`` / ``forward_features`` / ``SubModel.forward``
+    over the real ``resnet.ResEncoder`` (fairseq.* stubbed at import).  What cannot be pinned here: fairseq's
+    ``TransformerEncoder`` class (fairseq is absent; an HF ``Wav2Vec2Encoder[StableLayerNorm]`` -- the module HF ported from it,
+    pinned for the audio path -- stands in its place in the fixture)."""
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     fv = video_frontend_forward(sub, video, prefix="feature_extractor_video.")  # (B, T, E)
     feats = torch.cat([torch.zeros_like(fv), fv], dim=-1)                        # audio half first (hubert.py:706-707)

@@ -159,6 +159,11 @@ PRESETS = {
         name="tiny-avhubert-video", family="avhubert", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
         intermediate_size=128, conv_dim=(128,), conv_kernel=(), conv_stride=(), num_conv_pos_embeddings=16,
         num_conv_pos_embedding_groups=4, do_stable_layer_norm=True, feat_proj_layer_norm=True),
+    # the same branch over a post-LN transformer (fairseq layer_norm_first = False): the glue golden covers both encoder forms
+    "tiny-avhubert-video-postln": EncoderConfig(
+        name="tiny-avhubert-video-postln", family="avhubert", hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+        intermediate_size=128, conv_dim=(128,), conv_kernel=(), conv_stride=(), num_conv_pos_embeddings=16,
+        num_conv_pos_embedding_groups=4, do_stable_layer_norm=False, feat_proj_layer_norm=True),
 }
 
 

@@ -384,6 +384,150 @@ def make_video_front_cases():
     torch.save(out, os.path.join(HERE, "video_front.pt"))
 
 
+def import_reference_video():
+    """``N20EMv2/video_only/hubert.py`` and ``fairseq_interface.py`` THEMSELVES, with the third-party names they import at module
+    level (fairseq.*, omegaconf -- absent from the build container) stubbed in ``sys.modules`` for the duration of the import.
+    What then runs is the reference's own ``AVHubertModel.extract_finetune`` (hubert.py:688-739), ``forward_features`` (:532-541),
+    ``SubModel.forward`` (:318-326) over the real ``resnet.ResEncoder``, and ``FairseqAVHubertPretrain.forward / extract_features``
+    (fairseq_interface.py:454-485).  The one module that cannot be the reference's is fairseq's ``TransformerEncoder``: the stub
+    class below wraps HF's ``Wav2Vec2Encoder[StableLayerNorm]`` (the module HF ported from it; pinned for the audio path)."""
+    import dataclasses  # noqa: F401
+    import torch.nn as nn
+
+    def module(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    class HFTransformerEncoder(nn.Module):
+        """stands where fairseq.models.wav2vec.wav2vec2.TransformerEncoder stands: forward(x, padding_mask, layer) -> (x, None)"""
+
+        def __init__(self, hf_encoder):
+            super().__init__()
+            self.hf = hf_encoder
+
+        def forward(self, x, padding_mask=None, layer=None):
+            assert padding_mask is None and layer is None
+            return self.hf(x).last_hidden_state, None
+
+    class GradMultiply:
+        @staticmethod
+        def apply(x, scale):
+            return x
+
+    def layer_norm(normalized_shape, eps=1e-5, elementwise_affine=True):   # fairseq.modules.LayerNorm without apex = torch's
+        return nn.LayerNorm(normalized_shape, eps, elementwise_affine)
+
+    def register_model(name, dataclass=None):
+        return lambda cls: cls
+
+    names = {
+        "fairseq": module("fairseq", utils=module("fairseq.utils", get_available_activation_fns=lambda: ["relu", "gelu"])),
+        "fairseq.utils": None,
+        "fairseq.data": module("fairseq.data"),
+        "fairseq.data.data_utils": module("fairseq.data.data_utils", compute_mask_indices=None),
+        "fairseq.data.dictionary": module("fairseq.data.dictionary", Dictionary=object),
+        "fairseq.dataclass": module("fairseq.dataclass", ChoiceEnum=lambda choices: str, FairseqDataclass=object),
+        "fairseq.models": module("fairseq.models", BaseFairseqModel=nn.Module, register_model=register_model),
+        "fairseq.models.wav2vec": module("fairseq.models.wav2vec"),
+        "fairseq.models.wav2vec.wav2vec2": module("fairseq.models.wav2vec.wav2vec2", ConvFeatureExtractionModel=None,
+                                                  TransformerEncoder=HFTransformerEncoder),
+        "fairseq.modules": module("fairseq.modules", GradMultiply=GradMultiply, LayerNorm=layer_norm),
+        "omegaconf": module("omegaconf", II=lambda key: None),
+        "hubert_pretraining": module("hubert_pretraining", AVHubertPretrainingConfig=object, AVHubertPretrainingTask=object),
+        "hubert_asr": module("hubert_asr"),
+        "decoder": module("decoder", TransformerDecoder=None),
+        "utils": module("utils", compute_mask_indices=None),    # hubert.py's `from utils import ...` (video_only/utils.py imports fairseq)
+    }
+    names["fairseq.utils"] = names["fairseq"].utils
+    vdir = REF + "/N20EMv2/video_only"
+    saved = {k: sys.modules.get(k) for k in list(names) + ["resnet", "hubert", "fairseq_interface"]}
+    sys.modules.update(names)
+    for k in ("resnet", "hubert", "fairseq_interface"):
+        sys.modules.pop(k, None)
+    sys.path.insert(0, vdir)
+    try:
+        import speechbrain  # noqa: F401  (fairseq_interface imports speechbrain.utils.data_utils)
+        import hubert as ref_hubert
+        import fairseq_interface as ref_iface
+        import resnet as ref_resnet
+    finally:
+        sys.path.remove(vdir)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ref_hubert, ref_iface, ref_resnet, HFTransformerEncoder
+
+
+def make_video_glue_cases():
+    """a15 / f2: the AV-HuBERT video branch through the reference's OWN glue -- ``FairseqAVHubertPretrain.forward`` ->
+    ``extract_features`` -> ``AVHubertModel.extract_finetune({"video": v, "audio": None})``: real lip front-end, zeros for the audio
+    half, cat([audio, video]) order, LayerNorm(2E), post_extract_proj, encoder, the wrapper's whole-tensor output norm.  The
+    objects are built without their __init__ (those need fairseq configs / a checkpoint file): ``__new__`` + the attributes the
+    methods read, exactly the submodules ``AVHubertModel.__init__`` creates (hubert.py:344-394)."""
+    import torch.nn as nn
+    from transformers.models.wav2vec2.modeling_wav2vec2 import Wav2Vec2Encoder, Wav2Vec2EncoderStableLayerNorm, Wav2Vec2Config
+    ref_hubert, ref_iface, ref_resnet, HFEnc = import_reference_video()
+    out = {}
+    for name, cfg_name, B, T, HW, seed, output_norm in [("tiny_stable", "tiny-avhubert-video", 2, 9, 40, 6986, True),
+                                                         ("tiny_stable_t1", "tiny-avhubert-video", 1, 1, 32, 6987, False),
+                                                         ("tiny_postln", "tiny-avhubert-video-postln", 2, 7, 36, 6988, True)]:
+        cfg = PRESETS[cfg_name]
+        E = cfg.hidden_size
+        sd = W.seeded_avhubert_video_state_dict(cfg, seed=seed)
+        hc = Wav2Vec2Config(hidden_size=E, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                            intermediate_size=cfg.intermediate_size, do_stable_layer_norm=cfg.do_stable_layer_norm,
+                            num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                            num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups, layer_norm_eps=cfg.layer_norm_eps,
+                            hidden_dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0,
+                            attn_implementation="eager")
+        hf_enc = (Wav2Vec2EncoderStableLayerNorm if cfg.do_stable_layer_norm else Wav2Vec2Encoder)(hc).eval()
+        model = ref_hubert.AVHubertModel.__new__(ref_hubert.AVHubertModel)
+        nn.Module.__init__(model)
+        sub_cfg = types.SimpleNamespace(encoder_embed_dim=E, encoder_layers=0)
+        model.feature_extractor_video = ref_hubert.SubModel(resnet=ref_resnet.ResEncoder(relu_type="prelu", weights=None),
+                                                            input_dim=512, cfg=sub_cfg)
+        model.encoder_embed_dim, model.modality_fuse, model.embed = E, "concat", 2 * E
+        model.layer_norm = nn.LayerNorm(2 * E)
+        model.post_extract_proj = nn.Linear(2 * E, E)
+        model.dropout_input, model.dropout_features = nn.Dropout(0.0), nn.Dropout(0.0)
+        model.feature_grad_mult, model.masking_type = 1.0, "input"
+        model.encoder = HFEnc(hf_enc)
+        # the fairseq-named state dict goes in through the modules' own load_state_dict: front-end / layer_norm / post_extract_proj
+        # by their fairseq names, the encoder through the HF spelling of the same tensors (oracle.fairseq_to_hf_key is NOT used here)
+        model.feature_extractor_video.load_state_dict({k[len("feature_extractor_video."):]: v for k, v in sd.items()
+                                                       if k.startswith("feature_extractor_video.")}, strict=True)
+        model.layer_norm.load_state_dict({"weight": sd["layer_norm.weight"], "bias": sd["layer_norm.bias"]})
+        model.post_extract_proj.load_state_dict({"weight": sd["post_extract_proj.weight"], "bias": sd["post_extract_proj.bias"]})
+        hf_sd = W.seeded_encoder_state_dict(cfg, seed=seed + 1)    # the tensors seeded_avhubert_video_state_dict renamed
+        enc_sd = {k[len("encoder."):]: v for k, v in hf_sd.items() if k.startswith("encoder.")}
+        own = hf_enc.state_dict()
+        assert set(own) == set(enc_sd), (sorted(set(own) ^ set(enc_sd)))
+        for k in own:   # same values as the fairseq-named entries of `sd` (weight-norm g / v spelling aside)
+            fk = W.hf_to_fairseq_key("encoder." + k)
+            if fk in sd:
+                assert torch.equal(sd[fk], enc_sd[k]), k
+        hf_enc.load_state_dict(enc_sd, strict=True)
+        model.eval()
+        wrap = ref_iface.FairseqAVHubertPretrain.__new__(ref_iface.FairseqAVHubertPretrain)
+        nn.Module.__init__(wrap)
+        wrap.model, wrap.freeze, wrap.normalize, wrap.output_norm = model, True, False, output_norm
+        g = torch.Generator().manual_seed(seed + 7)
+        video = torch.randn(B, 1, T, HW, HW, generator=g)
+        with torch.no_grad():
+            y = wrap({"video": video, "audio": None})
+            front = model.forward_features(video, modality="video").transpose(1, 2).contiguous()   # (B, T, E): the video half
+        assert y.shape == (B, T, E)
+        out[name] = dict(cfg=cfg_name, B=B, T=T, HW=HW, weight_seed=seed, video_seed=seed + 7, output_norm=output_norm, out=y,
+                         front=front, sd_sha256=sd_digest(sd))
+        print("video_glue", name, tuple(y.shape), float(y.std()), float(front.std()))
+    torch.save(out, os.path.join(HERE, "video_glue.pt"))
+
+
 def make_dataio_cases():
     """speechbrain.utils.data_utils.batch_pad_right and speechbrain.dataio.batch.PaddedBatch on ragged 1-D signals and
     (frames, 4) annotations, as the recipes' DataLoader collates them (speechbrain/dataio/batch.py:101-137)."""
@@ -502,6 +646,7 @@ def main():
         "ctc_fbank": make_ctc_fbank_cases,
         "losses": make_loss_cases,
         "video_front": make_video_front_cases,
+        "video_glue": make_video_glue_cases,
         "dataio": make_dataio_cases,
         "fbank_ext": make_fbank_ext_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),

@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests of the N>1 path.  The per-rank forward is replaced by a deterministic function of the clip
+"""world_size-2 (and one world_size-8, uneven: 509 clips) gloo tests of the N>1 path.  The per-rank forward is replaced by a deterministic function of the clip
 index (the HIP path needs a GPU); what is under test is the distributed plumbing itself -- contiguous sharding, the
 preallocated all-gather of per-rank logits / compact frames (even and uneven shards), and ``distributed.run_sharded``,
 the very loop ``bench.py --gpus N`` times (lane alternation, warm-up, exactly K timed steps, max over ranks)."""
@@ -29,7 +29,7 @@ def _worker(rank, world, port, n_total, q):
     D.barrier(w)
     t = D.max_over_ranks(float(rank + 1), w, "cpu")
     ok = full.shape == (n_total, 5, 20) and all(float(full[i, 0, 0]) == float(i) for i in range(n_total)) and t == float(world)
-    ok = ok and D.gather_floats(float(rank) + 0.5, w, "cpu") == [0.5, 1.5]
+    ok = ok and D.gather_floats(float(rank) + 0.5, w, "cpu") == [i + 0.5 for i in range(world)]
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -95,7 +95,7 @@ def _sharded_worker(rank, world, port, n_total, T, q):
         gs = [D.RowGatherer(n_total, w, r, shape, dtype, "cpu") for _ in range(2)]
         res = D.run_sharded([make(0), make(1)], n_total, r, w, steps=5, warmup=2, device="cpu", lanes=[Lane(0), Lane(1)], gatherers=gs)
         out = res["out"]
-        ok = ok and out.shape == (n_total,) + shape and res["ranks"] == 2 and len(res["elapsed_per_rank"]) == 2
+        ok = ok and out.shape == (n_total,) + shape and res["ranks"] == world and len(res["elapsed_per_rank"]) == world
         ok = ok and res["elapsed"] == max(res["elapsed_per_rank"]) and res["elapsed"] > 0
         ok = ok and calls["ctx"] == [0, 1, 0, 1, 0, 1, 0]          # 2 warm-up + exactly 5 timed steps, lanes alternate
         if kind == "logits":
@@ -123,6 +123,16 @@ def _sharded_worker(rank, world, port, n_total, T, q):
 def test_run_sharded_two_ranks_uneven_and_even():
     for n_total in (7, 8):
         assert _spawn(_sharded_worker, 2, n_total, 6) == [(0, True), (1, True)]
+
+
+def test_run_sharded_eight_ranks_uneven_509_clips():
+    """SURVEY.md §8(e) at the node's real rank count, without the hardware: eight gloo ranks, 509 clips (five ranks own 64, three own
+    63), the same run_sharded loop and preallocated gathers as `bench.py --gpus 8`; every gathered row is checked on every rank."""
+    from svt_speechbrain_amd.distributed import shard_bounds
+    sizes = [b - a for a, b in (shard_bounds(509, r, 8) for r in range(8))]
+    assert sum(sizes) == 509 and sorted(set(sizes)) == [63, 64]
+    assert _spawn(_worker, 8, 509) == [(r, True) for r in range(8)]
+    assert _spawn(_sharded_worker, 8, 509, 3) == [(r, True) for r in range(8)]
 
 
 def test_run_sharded_single_rank_needs_no_process_group():

@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(port, *extra):
+def launch(port, *extra, nproc=2, batch=3):
     env = dict(os.environ, SVT_SHARE_GPU="1", SVT_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--batch", str(batch),
            "--seconds", "2", "--no-cpu-baseline", "--no-extra-legs", "--verify", *extra]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     if r.returncode != 0 and ("address already in use" in r.stderr.lower() or "rendezvous" in r.stderr.lower()
@@ -50,6 +50,16 @@ def test_two_ranks_frames_gather_with_global_norms():
     assert j["verified"] is True and j["rccl_ranks"] == 2
     c = j["collective"]
     assert c["payload"] == "frames" and c["bytes_per_rank_per_step"] == 3 * 99 * 16 and c["norm_all_reduce"]
+
+
+def test_eight_ranks_dry_run_of_the_drivers_scaling_command():
+    """`bench.py --gpus 8` exactly as the driver launches it for SCALE_rNN.json, on the one GPU of this box (eight ranks share device 0,
+    collectives on gloo): rank count, weak scaling, per-rank rates, gather size and the verification of every gathered row.  What it
+    cannot show is RCCL itself: the `nccl` branch of distributed._gather_into with more than one rank has never executed."""
+    j = launch(29551, nproc=8, batch=2)
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["scaling"] == "weak" and j["verified"] is True
+    assert len(j["per_rank_clips_per_s"]) == 8 and j["config"]["global_batch"] == 16 and j["config"]["per_gpu_batch"] == 2
+    assert j["collective"]["bytes_per_rank_per_step"] == 2 * 99 * 20 * 4 and j["collective"]["backend"] == "gloo"
 
 
 def test_plain_launch_starts_its_own_ranks():

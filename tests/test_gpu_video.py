@@ -191,6 +191,27 @@ def test_avhubert_video_encoder_vs_oracle(prec, tol):
         m.load_fairseq_model_state({"layer_norm.weight": torch.zeros(128)})
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("fp16x3", 1e-3), ("bf16", 0.35), ("fp16", 0.05)])
+@pytest.mark.parametrize("name", ["tiny_stable", "tiny_stable_t1", "tiny_postln"])
+def test_avhubert_video_encoder_vs_reference_glue_golden(golden, name, prec, tol):
+    """a15 / f2 pinned: FairseqAVHubertPretrain on the HIP path against what the REFERENCE's own ``FairseqAVHubertPretrain.forward`` ->
+    ``AVHubertModel.extract_finetune`` produced (tests/golden/video_glue.pt: real resnet.ResEncoder front-end, the reference's
+    zeros-for-audio / concat / LayerNorm(2E) / post_extract_proj glue, an HF encoder module in the place of fairseq's)."""
+    from svt_speechbrain_amd.video import FairseqAVHubertPretrain
+    fx = golden("video_glue")[name]
+    cfg = S.PRESETS[fx["cfg"]]
+    m = FairseqAVHubertPretrain(config=cfg, precision=prec, seed=1, output_norm=fx["output_norm"])
+    m.load_fairseq_model_state(W.seeded_avhubert_video_state_dict(cfg, seed=fx["weight_seed"]))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(fx["video_seed"])
+    video = torch.randn(fx["B"], 1, fx["T"], fx["HW"], fx["HW"], generator=g)
+    out = m({"video": video.to(DEV), "audio": None}).cpu()
+    assert out.shape == fx["out"].shape
+    err = (out - fx["out"]).abs().max().item()
+    print(f"AV-HuBERT video branch {prec}[{name}]: max |d| vs the reference's extract_finetune {err:.2e}")
+    assert err < tol, err
+
+
 def test_avhubert_per_clip_norm_batch_equals_batch1():
     """The video wrapper's output norm per clip: a batch of clips == the clips forwarded one at a time (fp32: to the last bits)."""
     from svt_speechbrain_amd.video import FairseqAVHubertPretrain

@@ -684,13 +684,20 @@ def test_committed_simulation_bounds_are_what_the_simulation_gives():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import sim_split
     table = json.load(open(os.path.join(ROOT, "tests", "golden", "sim_bounds.json")))
+    # the table is only as good as the sources it was computed from: a change of the oracle or of the simulation without a re-run
+    # of tests/golden/make_sim_bounds.py fails here (the large cases are not re-derived below)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_sim_bounds
+    assert table["_sources_sha256"] == make_sim_bounds.source_digest(), \
+        "oracle/svt_oracle.py or tools/sim_split.py changed: re-run python tests/golden/make_sim_bounds.py and commit sim_bounds.json"
     for name in ("tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"):
-        assert set(table[name]) == {"bf16x1", "f16x1"}
+        assert set(table[name]) == {"bf16x1", "f16x1"} and all(len(v) == 8 for v in table[name].values())
     torch.set_num_threads(8)
     for name in ("tiny_group", "tiny_layer", "base_c1"):
         fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
         for mode in ("bf16x1", "f16x1"):
-            mx, mean, mism, frames = sim_split.simulate(fx, mode)
+            mx, mean, mism, frames, n_ref, f_full, f_nooff, f_on = sim_split.simulate(fx, mode)
             t = table[name][mode]
+            assert n_ref == t[4] and abs(f_full - t[5]) <= 2.0 / max(1, n_ref) and abs(f_on - t[7]) <= 2.0 / max(1, n_ref), (name, mode)
             # another BLAS thread count may move the last bits of a sum, hence a near-tie frame
             assert abs(mx - t[0]) <= 0.02 * t[0] + 1e-5 and abs(mean - t[1]) <= 0.01 * t[1] + 1e-6 and abs(mism - t[2]) <= 1 and frames == t[3], (name, mode)

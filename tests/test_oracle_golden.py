@@ -152,6 +152,32 @@ def test_oracle_video_frontend_matches_reference_golden(golden, name):
     assert (y - fx["feats"]).abs().max() < 2e-5 * (1 + fx["feats"].abs().max())
 
 
+# ---- §8 a15 / f2: the AV-HuBERT video branch through the reference's own glue (hubert.py:688-739 extract_finetune, :532-541,
+# :318-326; fairseq_interface.py:454-485 -- tests/golden/make_golden.py::make_video_glue_cases runs those methods themselves over the
+# real lip front-end and an HF encoder module standing where fairseq's TransformerEncoder stands) ----
+@pytest.mark.parametrize("name", ["tiny_stable", "tiny_stable_t1", "tiny_postln"])
+def test_oracle_avhubert_video_glue_matches_reference_golden(golden, name):
+    fx = golden("video_glue")[name]
+    cfg = PRESETS[fx["cfg"]]
+    sd = W.seeded_avhubert_video_state_dict(cfg, seed=fx["weight_seed"])
+    assert sd_digest(sd) == fx["sd_sha256"], "seeded AV-HuBERT weight generator drifted from the golden fixtures"
+    g = torch.Generator().manual_seed(fx["video_seed"])
+    video = torch.randn(fx["B"], 1, fx["T"], fx["HW"], fx["HW"], generator=g)
+    with torch.no_grad():
+        y = O.avhubert_video_forward(sd, cfg, video, output_norm=fx["output_norm"])
+        front = O.video_frontend_forward(sd, video, prefix="feature_extractor_video.")
+    assert (front - fx["front"]).abs().max() < 2e-5 * (1 + fx["front"].abs().max())
+    assert y.shape == fx["out"].shape
+    assert (y - fx["out"]).abs().max() < 5e-5, float((y - fx["out"]).abs().max())
+    # the order of the two halves matters: video first would not match
+    swapped = dict(sd)
+    w = sd["post_extract_proj.weight"]
+    swapped["post_extract_proj.weight"] = torch.cat([w[:, w.shape[1] // 2:], w[:, :w.shape[1] // 2]], dim=1)
+    with torch.no_grad():
+        y2 = O.avhubert_video_forward(swapped, cfg, video, output_norm=fx["output_norm"])
+    assert (y2 - fx["out"]).abs().max() > 1e-2
+
+
 def test_oracle_fbank_deltas_and_context_match_reference_golden(golden):
     fx = golden("fbank_ext")
     for c in fx["deltas"]:

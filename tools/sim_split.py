@@ -59,7 +59,8 @@ def make_ops(mode):
 def simulate(fx, mode):
     """One golden case `fx` (tests/golden/<name>.pt, loaded) through the oracle with every dense product replaced by `mode`'s
     sum of piece products -> (max |dlogit|, mean |dlogit|, frames whose octave / pitch-class argmax differs from the reference,
-    over all clips, frames in total).  CPU; a few seconds per case."""
+    over all clips, frames in total, then the note level: notes of the reference, and the COnPOff / COnP / COn F1 of the simulated
+    notes against the reference's -- svt_speechbrain_amd/agreement.py::note_agreement).  CPU; a few seconds per case."""
     cfg = PRESETS[fx["cfg"]]
     sd = W.seeded_encoder_state_dict(cfg, seed=fx["weight_seed"])
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=fx["head_seed"])
@@ -75,11 +76,18 @@ def simulate(fx, mode):
     with torch.no_grad():
         logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
     err = (logits - fx["logits"]).abs()
-    _, _, octv, pc = O.decode_frames(logits)
+    p_on, p_off, octv, pc = O.decode_frames(logits)
     mism = 0
+    notes, ref_notes = [], []
     for b, d in enumerate(fx["decode"]):
         mism += int(((octv[b] != d["oct"]) | (pc[b] != d["pc"])).sum())
-    return float(err.max()), float(err.mean()), mism, int(octv.shape[0] * octv.shape[1])
+        info = list(zip(p_on[b].numpy(), p_off[b].numpy(), octv[b].tolist(), pc[b].tolist()))
+        notes.append(O.frame2note(info, 0.4, 0.5))
+        ref_notes.append(d["notes"])
+    from svt_speechbrain_amd.agreement import note_agreement
+    na = note_agreement(notes, ref_notes)
+    return (float(err.max()), float(err.mean()), mism, int(octv.shape[0] * octv.shape[1]), na["reference_notes"], na["COnPOff_f1"],
+            na["COnP_f1"], na["COn_f1"])
 
 
 def main():
@@ -87,8 +95,9 @@ def main():
     fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
     torch.set_num_threads(8)
     for mode in sys.argv[2:]:
-        mx, mn, mism, total = simulate(fx, mode)
-        print(f"{name} {mode}: max|dlogit| {mx:.3e} mean {mn:.3e} argmax mismatches {mism}/{total}", flush=True)
+        mx, mn, mism, total, n_ref, f_full, f_nooff, f_on = simulate(fx, mode)
+        print(f"{name} {mode}: max|dlogit| {mx:.3e} mean {mn:.3e} argmax mismatches {mism}/{total}; {n_ref} reference notes, "
+              f"F1 COnPOff {f_full:.3f} COnP {f_nooff:.3f} COn {f_on:.3f}", flush=True)
 
 
 if __name__ == "__main__":
