@@ -561,6 +561,410 @@ __global__ __launch_bounds__(512) void flash_attn_stag_kernel(const bf16_t* __re
     }
 }
 
+#ifdef SVT_DIAG
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form (round 5) -- AN EXPERIMENT, MEASURED SLOWER, built by `make DIAG=1` only (svt_debug_set key 21 = 43-45 / 83-86 / 85;
+// stamps: key 21 = 99, tools/attn_pipe_stamps.py; numbers: profiles/r05_attention_pipeline_experiment.txt).  The idea: the matrix pipe
+// works UNDER a wave's own softmax.
+// flash_attn_stag_kernel overlaps the pipes only across waves: inside a wave the phases S = K Q^T (8 MFMAs) -> softmax (~150 vector
+// instructions, 32 of them quarter-rate exponentials) -> O += V P (8 MFMAs) are a dependency chain, so a wave alone leaves the matrix
+// pipe idle during its softmax and the vector pipe idle during its products; with 768 workgroups of 8 waves on 512 resident slots the
+// launch is also 1.5 rounds deep (the second round runs half empty).  Here:
+//   * ONE wave carries two score accumulators: while it exponentiates tile j (S_j, finished an iteration ago) the matrix pipe runs the
+//     products that do not depend on that softmax -- O += V_{j-1} P_{j-1} (P of the previous tile, 16 registers) and S_{j+1} = K_{j+1} Q^T --
+//     INTERLEAVED with it in program order, one MFMA per slot of ~7 vector instructions (an MFMA keeps the matrix pipe busy for 32
+//     cycles and blocks the wave's vector issue for 8 of them: the rest of the slot is the softmax's);
+//   * the running maximum of tile j is settled BEFORE the interleaved region (it needs all of S_j, and its rare "raise the maximum"
+//     branch must not split the region): when it is raised the pending product O += V_{j-1} P_{j-1} is flushed first -- P_{j-1} was
+//     taken against the old maximum, like the O it adds to -- and the region then runs without it.  Every value is computed by the
+//     same operations in the same order as in flash_attn_kernel / flash_attn_stag_kernel: the outputs are bit-identical;
+//   * four waves (128 queries) per workgroup, ~160 registers: three workgroups per CU = 768 resident slots for 4 x 384 = 1 536
+//     workgroups at C2, exactly two rounds; a SIMD's three waves belong to three workgroups and drift out of phase by themselves;
+//   * K in a ring of three 8 KiB tiles, V in a ring of three: at the top of iteration j (behind the barrier) K_{j+3} and V_{j+1} are
+//     requested by LDS-DMA, each two iterations before its first read; the wait in front of the barrier is a counted vmcnt.
+template <int N> __device__ __forceinline__ void attn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most n of this wave's LDS-DMA requests are outstanding (n is wave-uniform; the instruction takes an immediate)
+__device__ __forceinline__ void attn_wait_vm_dyn(int n) {
+  switch (n) {
+    case 0: attn_wait_vm<0>(); break;
+    case 1: attn_wait_vm<1>(); break;
+    case 2: attn_wait_vm<2>(); break;
+    case 3: attn_wait_vm<3>(); break;
+    case 4: attn_wait_vm<4>(); break;
+    case 5: attn_wait_vm<5>(); break;
+    case 6: attn_wait_vm<6>(); break;
+    case 7: attn_wait_vm<7>(); break;
+    case 8: attn_wait_vm<8>(); break;
+    case 9: attn_wait_vm<9>(); break;
+    case 10: attn_wait_vm<10>(); break;
+    case 11: attn_wait_vm<11>(); break;
+    case 12: attn_wait_vm<12>(); break;
+    case 13: attn_wait_vm<13>(); break;
+    case 14: attn_wait_vm<14>(); break;
+    case 15: attn_wait_vm<15>(); break;
+    default: attn_wait_vm<16>(); break;
+  }
+}
+
+// NW waves (32 queries each) per workgroup, K and V in rings of NR tiles, WPE waves per SIMD
+template <int DH, int NW, int NR, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flash_attn_pipe_kernel(
+    const bf16_t* __restrict__ Q, long ldq, long q_bstride, const bf16_t* __restrict__ K, long ldk, long k_bstride,
+    const bf16_t* __restrict__ V, bf16_t* __restrict__ O, long ldo, long o_bstride, int T, int H, float c, int nqb, unsigned* stamps) {
+  const bool STAMP = stamps != nullptr;   // diagnostics (tools/attn_pipe_stamps.py): s_memtime stamps per wave instead of the result
+  static_assert(DH == 64 && (NW == 4 || NW == 8) && NR >= 3 && NR <= 8, "built for head_dim 64");
+  constexpr int DPW = 8 / NW;   // LDS-DMA instructions per wave, tile and operand (8 rows x 128 B each)
+  constexpr int KSD = DH / 16, DB = DH / 32, CPR = DH / 8, RB = 2 * DH;
+  constexpr int TILE16 = 64 * CPR;                   // uint4 per tile (8 KiB)
+  constexpr unsigned TILE_BYTES = TILE16 * 16;
+  __shared__ __attribute__((aligned(16))) uint4 KV[2 * NR * TILE16];   // K ring, then V ring
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned stamp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stamp[i] = 0;
+  if (STAMP) stamp[0] = (unsigned)__builtin_amdgcn_s_memtime();
+#define SVT_PST(I) if (STAMP) stamp[I] = (unsigned)__builtin_amdgcn_s_memtime();
+  const int L = blockIdx.x, BH = (int)gridDim.x / nqb;
+  int bh, qblk;
+  {   // the query blocks of one (clip, head) on one XCD (see flash_attn_stag_kernel)
+    const int full = (BH / 8) * 8 * nqb;
+    if (L < full) { bh = (L & 7) + 8 * (L / (8 * nqb)); qblk = (L >> 3) % nqb; }
+    else { const int r = L - full; bh = (BH / 8) * 8 + r / nqb; qblk = r % nqb; }
+  }
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = qblk * (32 * NW) + wave * 32;
+  const bf16_t* Qb = Q + (long)b * q_bstride + (long)h * DH;
+  const bf16_t* Kb = K + (long)b * k_bstride + (long)h * DH;
+  const bf16_t* Vb = V + (long)b * k_bstride + (long)h * DH;
+
+  bf16x8 qf[KSD];
+  int dkey[DPW], kch[DPW], vch[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int kk = (wave * DPW + i) * 8 + lane / CPR;
+    const int slot = lane % CPR;
+    dkey[i] = kk;
+    kch[i] = (slot ^ ((kk >> 1) & 7)) * 8;
+    vch[i] = (slot ^ (((kk >> 1) & 1) << 2)) * 8;
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(void __attribute__((address_space(3)))*)KV);
+  const int ntiles = (T + 63) / 64;
+  auto dma_k = [&](int tile, int slot) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      int key = tile * 64 + dkey[i];
+      if (key > T - 1) key = T - 1;
+      attn_dma16(Kb + (long)key * ldk + kch[i], lds0 + (unsigned)slot * TILE_BYTES + (unsigned)((wave * DPW + i) * 1024));
+    }
+  };
+  auto dma_v = [&](int tile, int slot) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      int key = tile * 64 + dkey[i];
+      if (key > T - 1) key = T - 1;
+      attn_dma16(Vb + (long)key * ldk + vch[i], lds0 + (unsigned)(NR + slot) * TILE_BYTES + (unsigned)((wave * DPW + i) * 1024));
+    }
+  };
+  // request schedule: "iteration" i (1 - NR <= i < ntiles; the negative ones are the head) asks for K_{i+NR} and V_{i+NR-2}, tile t into
+  // slot t mod NR -- K_{i+NR} takes the place of K_i (its scores were finished in iteration i - 1) and V_{i+NR-2} that of V_{i-2} (multiplied
+  // in iteration i - 1); both are first read in iteration i + NR - 1.  count(i) = requests of this wave in iteration i.
+  auto issued = [&](int i) -> int { return DPW * ((i + NR >= 1 && i + NR < ntiles ? 1 : 0) + (i + NR - 2 >= 0 && i + NR - 2 < ntiles ? 1 : 0)); };
+  auto issue = [&](int i, int kslot, int vslot) {
+    if (i + NR >= 1 && i + NR < ntiles) dma_k(i + NR, kslot);
+    if (i + NR - 2 >= 0 && i + NR - 2 < ntiles) dma_v(i + NR - 2, vslot);
+  };
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+  const int hh = lane >> 5;
+  const int kl = lane & 31;
+  const int kg = (kl >> 1) & 7;
+  unsigned vofs[DB];   // byte offset of this lane's transposed-read origin inside a V tile
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int key0 = 4 * (g >> 1) + q;
+    const int sw = ((q >> 1) & 1) << 2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = db * 4 + 2 * (g & 1) + (pp >> 1);
+      vofs[db] = (unsigned)(key0 * RB + ((chunk ^ sw) * 16) + 8 * (pp & 1));
+    }
+  }
+  const char* const lds_v = (const char*)&KV[NR * TILE16];
+  f32x16 s[2], sn[2];
+  bf16x8 pf[2][2];
+
+  auto k_frag = [&](int kslot, int kb, int ks) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, KV[kslot * TILE16 + (kb * 32 + kl) * CPR + ((2 * ks + hh) ^ kg)]);
+  };
+  auto v_frag = [&](int vslot, int db, int kb, int ss) -> bf16x8 {
+    const char* vp = lds_v + (unsigned)vslot * TILE_BYTES + vofs[db] + (kb * 32 + ss * 16) * RB;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vp + 8 * RB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  // O += V_prev P_prev as one block (the flush in front of a raised maximum, and the last tile's product)
+  auto pv_block = [&](int vslot) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = SVT_MFMA_32x32x16(v_frag(vslot, db, kb, ss), pf[kb][ss], o[db]);
+  };
+
+  // ---- head: K_0, then the requests of iterations 1 - NR .. -1, then the Q fragments (behind the requests: their latency runs beside
+  //      the tiles'); S_0 = K_0 Q^T once K_0 has landed ----
+  dma_k(0, 0);
+  {
+    int after_k0 = 0;
+#pragma unroll
+    for (int i = 1 - NR; i < 0; ++i) {
+      issue(i, (i + NR) % NR, (i + NR - 2 + NR) % NR);
+      after_k0 += issued(i);
+    }
+    {
+      int q = q0 + (lane & 31);
+      if (q > T - 1) q = T - 1;
+      const bf16_t* qp = Qb + (long)q * ldq + 8 * (lane >> 5);
+      // asm loads: the compiler must not count them (it cannot see the requests around them and would wait vmcnt(0) at their first use)
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[ks]) : "v"(qp), "n"(ks * 32) : "memory");
+    }
+    SVT_PST(1)
+    attn_wait_vm_dyn(after_k0 + KSD);   // K_0 has landed; the head's later requests and the Q fragments may still be in flight
+  }
+  __builtin_amdgcn_s_barrier();
+  attn_wait_vm<0>();   // Q (and, the only time, everything requested so far)
+#pragma unroll
+  for (int ks = 0; ks < KSD; ++ks) asm volatile("" : "+v"(qf[ks]));
+  SVT_PST(2)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) s[kb] = SVT_MFMA_32x32x16(k_frag(0, kb, ks), qf[ks], s[kb]);
+  }
+  SVT_PST(3)
+
+  // row maximum of a finished score tile in the scaled log2 domain (flash_attn_kernel's order of operations)
+  auto tile_max = [&](const f32x16 (&t)[2]) -> float {
+    float mx = fmaxf(t[0][0], t[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, t[0][r]), t[1][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+  };
+
+  // The interleaved region of iteration j: the softmax of S_j (16 units of two scores: one packed multiply-add, two exponentials, one
+  // packed addition, a conversion every fourth unit) against up to 16 MFMAs -- first the next tile's scores S_{j+1} = K_{j+1} Q^T, then
+  // the previous tile's product O += V_{j-1} P_{j-1}; between the MFMAs of the second half also the row maximum of S_{j+1} (MAXN:
+  // the next tile is a whole one; a partial last tile is masked and reduced at the top of its own iteration), and in the first slots
+  // the ring's requests of this iteration.  Returns the next tile's maximum.
+  auto region = [&](auto next_c, auto pv_c, auto max_c, int j, int kslot_next, int vslot_prev, int kslot_free, int vslot_free) -> float {
+    constexpr bool NEXT = decltype(next_c)::value, PVP = decltype(pv_c)::value, MAXN = decltype(max_c)::value;
+    constexpr int NM = (NEXT ? 8 : 0) + (PVP ? 8 : 0);
+    f32x2_t sab = {0.f, 0.f};
+    const f32x2_t cc = {c, c}, mm = {-m, -m};
+    bf16x8 pn[2][2];
+    float mxn = 0.f, mxa = 0.f;
+    auto unit = [&](int u) {   // scores (kb, r), (kb, r + 1): the arithmetic and the summation order of flash_attn_kernel
+      const int kb = u >> 3, r = 2 * (u & 7);
+      // the empty asm statements pin the unit to its slot: instruction selection orders a block's pure arithmetic by data dependence
+      // alone and would put all the multiply-adds in front of the first MFMA and all the additions behind the last one
+      asm volatile("" : "+v"(s[kb][r]), "+v"(s[kb][r + 1]));
+      const f32x2_t e = __builtin_elementwise_fma(f32x2_t{s[kb][r], s[kb][r + 1]}, cc, mm);
+      const float p0 = __builtin_amdgcn_exp2f(e.x);
+      const float p1 = __builtin_amdgcn_exp2f(e.y);
+      s[kb][r] = p0; s[kb][r + 1] = p1;
+      sab += f32x2_t{p0, p1};
+      if ((u & 3) == 3) {   // eight scores complete: their bf16 operand
+        const int ss = (u >> 2) & 1;
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) pn[kb][ss][j2] = (bf16_t)s[kb][ss * 8 + j2];
+        asm volatile("" : "+v"(pn[kb][ss]));
+      }
+      asm volatile("" : "+v"(sab));
+    };
+    if constexpr (NM == 0) {
+      issue(j, kslot_free, vslot_free);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) unit(u);
+    } else {
+      constexpr int UPS = 16 / NM;   // units per MFMA slot
+      auto frag = [&](int i) -> bf16x8 {
+        if (NEXT && i < 8) return k_frag(kslot_next, i >> 2, i & 3);
+        const int t = i - (NEXT ? 8 : 0);   // kb / ss outer: per accumulator the order of flash_attn_kernel
+        return v_frag(vslot_prev, t & 1, t >> 2, (t >> 1) & 1);
+      };
+      // fragments are read AHEAD slots in front of their MFMA (an LDS read returns after ~100-150 cycles, a slot lasts ~45)
+      constexpr int AHEAD = 3;
+      bf16x8 fr[AHEAD + 1];
+#pragma unroll
+      for (int i = 0; i < AHEAD && i < NM; ++i) fr[i] = frag(i);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i + AHEAD < NM) fr[(i + AHEAD) % (AHEAD + 1)] = frag(i + AHEAD);
+        if (NEXT && i < 8) {
+          const int kb = i >> 2, ks = i & 3;
+          if (ks == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[kb][r] = 0.f;
+          }
+          sn[kb] = SVT_MFMA_32x32x16(fr[i % (AHEAD + 1)], qf[ks], sn[kb]);
+        } else {
+          const int t = i - (NEXT ? 8 : 0);
+          o[t & 1] = SVT_MFMA_32x32x16(fr[i % (AHEAD + 1)], pf[t >> 2][(t >> 1) & 1], o[t & 1]);
+        }
+        if (i == 1) issue(j, kslot_free, vslot_free);   // this iteration's requests, in the shadow of the first MFMAs
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) unit(i * UPS + u);
+        if constexpr (NEXT && MAXN) {
+          // the next tile's row maximum, four scores per slot from slot 8 on (sn[0] is complete when MFMA 4 has retired, sn[1] with MFMA 8;
+          // without a product to hide behind -- the first iteration -- it follows the last unit)
+          constexpr int M0 = PVP ? 8 : NM;
+          if (i >= M0 || i == NM - 1) {
+            const int lo = i >= M0 ? (i - M0) * 2 : 0, hi = i == NM - 1 ? 16 : (i - M0) * 2 + 2;
+#pragma unroll
+            for (int r = lo; r < hi; ++r) {
+              if (r == 0) { mxn = fmaxf(sn[0][0], sn[1][0]); }
+              else mxn = fmaxf(fmaxf(mxn, sn[0][r]), sn[1][r]);
+            }
+            asm volatile("" : "+v"(mxn));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (NEXT && MAXN) mxa = fmaxf(mxn, __shfl_xor(mxn, 32, 64)) * c;
+    float sum = sab.x + sab.y;
+    sum += __shfl_xor(sum, 32, 64);
+    l += sum;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) pf[kb][ss] = pn[kb][ss];
+    return mxa;
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
+  int ks0 = 0, ks1 = 1 % NR, vs_prev = NR - 1, vs_free = NR - 2;   // slots of K_j, K_{j+1}, V_{j-1}, V_{j-2}
+  int allowed = 0;   // requests of iterations j + 2 - NR .. j - 1: what may still be in flight at the top of iteration j
+#pragma unroll
+  for (int i = 2 - NR; i < 0; ++i) allowed += issued(i);
+  const bool last_partial = (ntiles * 64 > T);
+  float mx = 0.f;
+  bool have_mx = false;
+  for (int j = 0; j < ntiles; ++j) {
+    // ---- top: K_{j+1} and V_{j-1} have landed (every wave waits for its own pieces, the barrier publishes them); behind the
+    //      barrier K_j's and V_{j-2}'s tiles are free: K_{j+NR} and V_{j+NR-2} go there (from inside the region) ----
+    if (STAMP) { if (j == 3) stamp[4] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    attn_wait_vm_dyn(allowed);
+    if (STAMP) { if (j == 3) stamp[5] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    __builtin_amdgcn_s_barrier();
+    if (STAMP) { if (j == 3) stamp[6] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    allowed += issued(j) - issued(j + 2 - NR);
+    // ---- the running maximum of tile j: taken inside the previous region unless this is the first or a partial last tile ----
+    if (!have_mx) {
+      if (j * 64 + 64 > T) {
+        const int kbase = j * 64 + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+            asm volatile("" : "+v"(s[kb][r]));
+            if (key >= T) s[kb][r] = -3e38f;
+          }
+      }
+      mx = tile_max(s);
+    }
+    if (STAMP) { if (j == 3) stamp[7] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    bool pending = j > 0;
+    if (!__all(mx - m <= 8.0f)) {
+      if (pending) { pv_block(vs_prev); pending = false; }
+      const float mnew = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      l *= alpha;
+      m = mnew;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAMP) { if (j == 3) stamp[8] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    if (j + 1 < ntiles) {
+      const bool maxn = !(last_partial && j + 2 == ntiles);   // the next tile is a whole one: its maximum comes out of the region
+      if (maxn) {
+        mx = pending ? region(yes{}, yes{}, yes{}, j, ks1, vs_prev, ks0, vs_free) : region(yes{}, no{}, yes{}, j, ks1, vs_prev, ks0, vs_free);
+      } else {
+        if (pending) region(yes{}, yes{}, no{}, j, ks1, vs_prev, ks0, vs_free); else region(yes{}, no{}, no{}, j, ks1, vs_prev, ks0, vs_free);
+      }
+      have_mx = maxn;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) s[kb] = sn[kb];
+    } else {
+      if (pending) region(no{}, yes{}, no{}, j, ks1, vs_prev, ks0, vs_free); else region(no{}, no{}, no{}, j, ks1, vs_prev, ks0, vs_free);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAMP) { if (j == 3) stamp[9] = (unsigned)__builtin_amdgcn_s_memtime(); }
+    ks0 = ks1; ks1 = ks1 + 1 == NR ? 0 : ks1 + 1;
+    vs_free = vs_prev; vs_prev = vs_prev + 1 == NR ? 0 : vs_prev + 1;
+  }
+  SVT_PST(10)
+  // ---- the last tile's product: V_{n-1} was requested an iteration ago and is covered by no barrier yet ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  pv_block(vs_prev);
+  SVT_PST(11)
+  if (STAMP) {
+    asm volatile("" ::"v"(o[0][0]), "v"(o[1][0]), "v"(l));   // (a 64-byte "v" operand is refused by the HOST pass, which then drops the kernel stub without a word)
+    stamp[12] = (unsigned)__builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned* rec = stamps + ((long)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rec[i] = i == 15 ? 0x5A5A0000u | (unsigned)ntiles : stamp[i];
+    }
+    return;
+  }
+#undef SVT_PST
+
+  const int q = q0 + (lane & 31);
+  if (q >= T) return;
+  const float inv = 1.f / l;
+  bf16_t* op = O + (long)b * o_bstride + (long)q * ldo + (long)h * DH;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      unsigned w[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x4 v;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) v[j2] = (bf16_t)(o[db][(g + u) * 4 + j2] * inv);
+        const uint2 pk = __builtin_bit_cast(uint2, v);
+        w[u][0] = pk.x; w[u][1] = pk.y;
+      }
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2) {
+        const auto r = __builtin_amdgcn_permlane32_swap(w[0][d2], w[1][d2], false, false);
+        w[0][d2] = r[0]; w[1][d2] = r[1];
+      }
+      *(uint4*)(op + db * 32 + 8 * (g + hh)) = uint4{w[0][0], w[0][1], w[1][0], w[1][1]};
+    }
+}
+
+#endif  // SVT_DIAG
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Split-operand fused attention (precision "bf16x3" / "fp16x3").  Q, K, V arrive as 16-bit (hi, lo) PLANES of the fp32
 // projections (split_planes_kernel below; plane = same (rows, ld) layout, lo plane `plane` elements after the hi plane);
@@ -1139,7 +1543,7 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   // eight-wave workgroups (256 queries) halve the K / V traffic per query; used when a head has more than 128 queries
   // (measured 45.7 vs 46.9 us at 32 x 12 heads x 499 frames, 114.2 vs 118.7 us at 64 x 16; with few workgroups -- one 5 s
   // utterance: 12 -- the four-wave form spreads over more CUs and stays)
-  const bool wide = g_flash_wide && dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512;
+  const bool wide = g_flash_wide && dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512 && !(g_attn_variant >= 5 && g_attn_variant <= 7);
   if (wide) grid.x = (T + 255) / 256;
   const double flops = 4.0 * B * H * (double)T * T * dh;
   if (gate && pb) {
@@ -1164,8 +1568,32 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   else
 #endif
-  if (dh == 64 && wide && g_attn_variant == 0) {
-    // staggered form (flash_attn_stag_kernel): three K / V stages, waves 4-7 half a tile behind waves 0-3
+#ifdef SVT_DIAG
+  if (dh == 64 && wide && g_attn_variant == 85) {
+    // software-pipelined form (flash_attn_pipe_kernel, round 5)
+    const int nqb = (T + 255) / 256;
+    hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 8, 5, 2>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr);
+  } else if (dh == 64 && wide && g_attn_variant == 99) {   // stamps (tools/attn_pipe_stamps.py)
+    const int nqb = (T + 127) / 128;
+    hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 4, 3, 2>), dim3((unsigned)(nqb * B * H)), dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
+                       (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)O);
+  } else if (dh == 64 && wide && g_attn_variant >= 40 && g_attn_variant < 50) {   // experiments: 4x = 128-query workgroups, ring depth x
+    const int nqb = (T + 127) / 128;
+#define SVT_PIPE4(NR_) hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 4, NR_, 2>), dim3((unsigned)(nqb * B * H)), dim3(256), 0, s, (const bf16_t*)Q, ldq, \
+                       q_bstride, (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr)
+    if (g_attn_variant == 43) SVT_PIPE4(3); else if (g_attn_variant == 44) SVT_PIPE4(4); else SVT_PIPE4(5);
+#undef SVT_PIPE4
+  } else if (dh == 64 && wide && g_attn_variant >= 80 && g_attn_variant < 90) {   // experiments: 8x = 256-query workgroups, ring depth x
+    const int nqb = (T + 255) / 256;
+#define SVT_PIPE8(NR_) hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 8, NR_, 2>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, \
+                       q_bstride, (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr)
+    if (g_attn_variant == 83) SVT_PIPE8(3); else if (g_attn_variant == 84) SVT_PIPE8(4); else SVT_PIPE8(6);
+#undef SVT_PIPE8
+  } else
+#endif
+  if (dh == 64 && wide && (g_attn_variant == 3 || g_attn_variant == 0)) {
+    // staggered form (flash_attn_stag_kernel, round 4): three K / V stages, waves 4-7 half a tile behind waves 0-3
     const int nqb = (T + 255) / 256;
     hipLaunchKernelGGL((flash_attn_stag_kernel<64, false>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
@@ -1180,6 +1608,15 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   else if (dh == 64 && wide)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
+  else if (dh == 64 && g_attn_variant >= 5 && g_attn_variant <= 7) {
+    // experiment: four-wave workgroups with the residency capped by an LDS pad (5: three per CU = 768 slots, two exact rounds of the
+    // 1 536 workgroups of C2; 6: two per CU; 7: four, the uncapped default of the narrow form)
+    const size_t pad = g_attn_variant == 5 ? 20480 : g_attn_variant == 6 ? 40960 : 0;
+    if (ensure_dyn_lds((const void*)flash_attn_kernel<64>, (int)pad)) return -1;
+    dim3 g4((T + 127) / 128, H, B);
+    hipLaunchKernelGGL((flash_attn_kernel<64>), g4, dim3(256), pad, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
+                       ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
+  }
   else if (dh == 64)
     hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
