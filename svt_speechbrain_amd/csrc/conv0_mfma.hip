@@ -5,7 +5,8 @@
 // vector operations per output in the layer-norm form).  Here the taps are ONE v_mfma_f32_16x16x32 per 16 frames x 16 channels:
 //     K = 32 = [ x_hi(10) | x_lo(10) | x_hi(10) | 1 | 1 ]  against  [ w_hi(10) | w_hi(10) | w_lo(10) | b_hi | b_lo ]
 // i.e. x w + b with BOTH operands carried as 16-bit (hi, lo) pairs (x_hi w_hi + x_lo w_hi + x_hi w_lo: 2^-16 relative with bf16
-// pieces, 2^-22 with IEEE-half ones -- far below the 2^-9 / 2^-12 rounding of the stored result), the matrix pipe is busy for 3 % of
+// pieces, 2^-22 with IEEE-half ones -- the raw samples of the GroupNorm form are scaled per wave by a power of two first, so that this
+// holds for quiet and for loud audio alike -- far below the 2^-9 / 2^-12 rounding of the stored result), the matrix pipe is busy for 3 % of
 // the kernel, and what is left per output is the normalisation, the polynomial GELU and the conversion.
 //   * the weight side is a 32 KiB table per clip (GroupNorm form: the 11 coefficients per (clip, channel) of conv0_group_coef_kernel,
 //     which already fold the whole-batch waveform norm and the GroupNorm statistics) or one table for all clips (LayerNorm form: the
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     const uint4* tg = (const uint4*)(table + (long)b * table_clip_stride);
     for (int i = tid; i < TBL16; i += 256) tbl[i] = tg[i];
   }
-  float mu = 0.f, rn = 1.f;
+  float mu = 0.f, rn = 1.f, xscale = 1.f;
   if (MODE == 1 && wav_mom) {
     const double* wm = wav_mom + 2 * (b / cpg);
     const double m = wm[0] / (double)n_wav;
@@ -121,12 +122,30 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
   if (nfr > 0) {
     const float* x = wav + (int64_t)b * L + t0 * stride;
     const int ns = (nfr - 1) * stride + K0;
-    for (int i = lane; i < ns; i += 64) xs[wave][i] = MODE == 1 ? (x[i] - mu) * rn : x[i];
+    float amax = 0.f;
+    for (int i = lane; i < ns; i += 64) {
+      const float v = MODE == 1 ? (x[i] - mu) * rn : x[i];
+      xs[wave][i] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+    if constexpr (MODE == 0) {
+      // GroupNorm form: the samples are RAW (the waveform norm lives in the coefficient table), and a 16-bit (hi, lo) pair only carries
+      // fp32-grade precision while lo is a normal number: IEEE-half pieces of audio peaking at 0.01 have subnormal lo pieces (3e-6
+      // relative instead of 2^-22), and samples above 65 504 overflow.  The wave's strip is therefore scaled by the power of two that
+      // brings its peak to [0.5, 1) -- exact, as is taking it out of the accumulators again: A = 2^k [x_hi | x_lo | x_hi | 1 | 1].
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      int e = 0;
+      if (amax > 0.f && amax < 3e38f) { (void)frexpf(amax, &e); }      // amax = f * 2^e, f in [0.5, 1)
+      e = e > 14 ? 14 : (e < -14 ? -14 : e);                             // 2^-e stays a normal IEEE half
+      xscale = ldexpf(1.f, -e);
+    }
   }
   __syncthreads();
   if (nfr <= 0) return;
+  const float unscale = 1.f / xscale;   // a power of two as well
   const int g = lane >> 4, j = lane & 15;
-  const bf16_t one = (bf16_t)1.0f;
+  const bf16_t one = (bf16_t)xscale;
   for (int chunk = 0; chunk * 16 < nfr; ++chunk) {
     // ---- A fragment: frame (row) j of the chunk, k = 8 g .. 8 g + 7 of [ x_hi | x_lo | x_hi | 1 | 1 ]
     bf16x8 a;
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
       bf16_t h[K0], l[K0];
 #pragma unroll
       for (int i = 0; i < K0; ++i) {
-        const float v = xp[i];
+        const float v = xp[i] * xscale;
         h[i] = (bf16_t)v;
         l[i] = (bf16_t)(v - (float)h[i]);
       }
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
         for (int r = 0; r < 4; ++r) {
           f32x2_t p[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) p[i] = f32x2_t{acc[2 * i][r], acc[2 * i + 1][r]};
+          for (int i = 0; i < 4; ++i) p[i] = f32x2_t{acc[2 * i][r], acc[2 * i + 1][r]} * unscale;
           if (fr0 + r < nfr) c0_store8<PK>(out, e0 + (int64_t)r * C0 + 128 * q, p);
         }
       }

@@ -102,6 +102,28 @@ def test_full_size_fp32_vs_reference_golden(golden, name, prec):
     assert mism <= 2, mism   # bf16x3: at most a near-tie frame or two per golden (fp32 / fp16x3: exact, asserted above)
 
 
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16"])
+@pytest.mark.parametrize("gain", [2.0 ** -10, 3e-4, 2.0 ** 17])
+def test_quiet_and_loud_audio_with_ieee_half_pieces(golden, prec, gain):
+    """Conv layer 0 of the GroupNorm extractor cuts the RAW samples into 16-bit (hi, lo) pieces (csrc/conv0_mfma.hip): with IEEE-half
+    pieces audio peaking at 1e-3 would have subnormal lo pieces and samples above 65 504 would overflow, had the kernel not scaled each
+    strip by a power of two.  The wrapper normalises the waveform, so a gain must not change the logits: the quiet / loud clip is held
+    to the SAME golden as the original (fp16x3: the 1e-3 bar; fp16: its usual bound)."""
+    fx = golden("base_c1")
+    cfg, enc, head = build(fx["cfg"], fx["weight_seed"], fx["head_seed"], prec)
+    wav = golden_wav(fx)
+    ref = head(enc(wav.to(DEV)))
+    out = head(enc((wav * gain).to(DEV)))
+    assert torch.isfinite(out).all()
+    d_gain = (out - ref).abs().max().item()
+    err = (out.cpu() - fx["logits"]).abs().max().item()
+    print(f"{prec} gain {gain:g}: max|dlogit| vs the same clip at gain 1: {d_gain:.2e}; vs the reference golden {err:.2e}")
+    if prec == "fp16x3":
+        assert err < 1e-3 and d_gain < 5e-4
+    else:
+        assert d_gain < 0.05
+
+
 _SIM_CACHE = {}
 
 
