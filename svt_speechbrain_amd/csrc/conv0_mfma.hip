@@ -65,9 +65,28 @@ template <int PK> __device__ __forceinline__ void c0_store8(void* out, int64_t e
 }
 
 // table[(clip,) block = q * 8 + nb][lane][8]: lane (g = lane >> 4, j = lane & 15) holds k = 8 g .. 8 g + 7 of channel 128 q + 8 j + nb
+// per clip: e with max |tap coefficient| = f * 2^e, f in [0.5, 1) (GroupNorm form: the coefficients carry 1 / (standard deviation of the
+// waveform), so their magnitude follows the recording level; the table stores them times 2^-e and the kernel takes the factor back out)
+__global__ __launch_bounds__(256) void conv0_coef_exp_kernel(const float* __restrict__ coef, int* __restrict__ exps) {
+  const int b = blockIdx.x;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < C0 * K0; i += 256) mx = fmaxf(mx, fabsf(coef[((long)b * C0 + i / K0) * (K0 + 1) + i % K0]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    int e = 0;
+    if (mx > 0.f && mx < 3e38f) (void)frexpf(mx, &e);
+    exps[b] = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+}
+
 template <int PK>
 __global__ void conv0_table_kernel(const float* __restrict__ w, long w_clip_stride, int w_row, const float* __restrict__ bias,
-                                   void* __restrict__ table_) {
+                                   void* __restrict__ table_, const int* __restrict__ tap_exp) {
   typedef typename C0T<PK>::piece bf16_t;   // (shadows the build's operand type inside this kernel)
   typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
   bf16_t* table = (bf16_t*)table_;
@@ -78,11 +97,12 @@ __global__ void conv0_table_kernel(const float* __restrict__ w, long w_clip_stri
   const int c = 128 * q + 8 * j + nb;
   const float* wc = w + (long)b * w_clip_stride + (long)c * w_row;
   const float bv = bias ? bias[c] : (w_row == K0 + 1 ? wc[K0] : 0.f);
+  const float tap_scale = tap_exp ? ldexpf(1.f, -tap_exp[b]) : 1.f;   // exact; the bias column keeps its own magnitude (O(1))
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int k = 8 * g + i;
-    const float src = k < 30 ? wc[k % 10] : bv;
+    const float src = k < 30 ? wc[k % 10] * tap_scale : bv;
     const bf16_t hi = (bf16_t)src;
     const bf16_t lo = (bf16_t)(src - (float)hi);
     o[i] = (k < 20 || k == 30) ? hi : lo;
@@ -95,7 +115,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
                                                          const void* __restrict__ table_, long table_clip_stride,
                                                          const double* __restrict__ wav_mom, int64_t n_wav, float eps_wav,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int cpg,
-                                                         void* __restrict__ out) {
+                                                         void* __restrict__ out, const int* __restrict__ tap_exp) {
   typedef typename C0T<PK>::piece bf16_t;   // piece type of this instantiation
   typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
   const bf16_t* table = (const bf16_t*)table_;
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     const uint4* tg = (const uint4*)(table + (long)b * table_clip_stride);
     for (int i = tid; i < TBL16; i += 256) tbl[i] = tg[i];
   }
-  float mu = 0.f, rn = 1.f, xscale = 1.f;
+  float mu = 0.f, rn = 1.f, xscale = 1.f, bscale = 1.f;
   if (MODE == 1 && wav_mom) {
     const double* wm = wav_mom + 2 * (b / cpg);
     const double m = wm[0] / (double)n_wav;
@@ -131,21 +151,28 @@ __global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict
     if constexpr (MODE == 0) {
       // GroupNorm form: the samples are RAW (the waveform norm lives in the coefficient table), and a 16-bit (hi, lo) pair only carries
       // fp32-grade precision while lo is a normal number: IEEE-half pieces of audio peaking at 0.01 have subnormal lo pieces (3e-6
-      // relative instead of 2^-22), and samples above 65 504 overflow.  The wave's strip is therefore scaled by the power of two that
-      // brings its peak to [0.5, 1) -- exact, as is taking it out of the accumulators again: A = 2^k [x_hi | x_lo | x_hi | 1 | 1].
+      // relative instead of 2^-22), samples above 65 504 overflow, and the coefficients (~ 1 / level) leave the range the other way.
+      // Both sides are therefore scaled by powers of two -- exact, as is taking them out of the accumulators again: the wave's strip by
+      // the 2^kx that brings its peak to [0.5, 1), the clip's tap coefficients by 2^ka (conv0_coef_exp_kernel), and the two bias
+      // columns of A hold 2^(kx + ka) against the unscaled bias:  acc = 2^(kx + ka) (x a + b).
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
       int e = 0;
       if (amax > 0.f && amax < 3e38f) { (void)frexpf(amax, &e); }      // amax = f * 2^e, f in [0.5, 1)
-      e = e > 14 ? 14 : (e < -14 ? -14 : e);                             // 2^-e stays a normal IEEE half
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      int tot = -e - (tap_exp ? tap_exp[b] : 0);                         // kx + ka: ~ log2(level / peak) - 3, a small negative number
+      tot = tot > 15 ? 15 : (tot < -14 ? -14 : tot);                     // 2^tot is a normal IEEE half
       xscale = ldexpf(1.f, -e);
+      bscale = ldexpf(1.f, tot);
+      // (if tot had to be clamped the strip scale follows, so that all three column groups keep ONE common factor)
+      xscale = ldexpf(1.f, tot + (tap_exp ? tap_exp[b] : 0));
     }
   }
   __syncthreads();
   if (nfr <= 0) return;
-  const float unscale = 1.f / xscale;   // a power of two as well
+  const float unscale = 1.f / bscale;   // a power of two as well
   const int g = lane >> 4, j = lane & 15;
-  const bf16_t one = (bf16_t)xscale;
+  const bf16_t one = (bf16_t)bscale;
   for (int chunk = 0; chunk * 16 < nfr; ++chunk) {
     // ---- A fragment: frame (row) j of the chunk, k = 8 g .. 8 g + 7 of [ x_hi | x_lo | x_hi | 1 | 1 ]
     bf16x8 a;
@@ -241,7 +268,7 @@ int g_conv0_mfma = 1;   // svt_debug_set key 22: 0 = the vector-ALU conv0 kernel
 bool conv0_mfma_ok(int prec, int pair_kind, int k, int stride, int C) {
   return g_conv0_mfma && (prec == 1 || pair_kind == 2 || pair_kind == 3) && k == K0 && stride >= 1 && stride <= 5 && C == C0;
 }
-size_t conv0_mfma_table_bytes(int B) { return (size_t)B * TBL16 * 16; }
+size_t conv0_mfma_table_bytes(int B) { return (size_t)B * TBL16 * 16 + (((size_t)B * 4 + 255) & ~(size_t)255); }   // tables + one exponent per clip
 
 #define SVT_C0_DISPATCH(PKV, STMT)                 \
   if ((PKV) == 3) { constexpr int PK_ = 3; STMT }  \
@@ -253,11 +280,13 @@ int launch_conv0_mfma_group(const float* wav, int B, int64_t L, int stride, int6
                             hipStream_t s, int pair_kind) {
   if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 127)) { set_error("conv0_mfma: alignment"); return -1; }
   dim3 grid((unsigned)((T1 + 255) / 256), B);
+  int* exps = (int*)((char*)table_ws + (size_t)B * TBL16 * 16);
+  hipLaunchKernelGGL(conv0_coef_exp_kernel, dim3(B), dim3(256), 0, s, coef, exps);
   SVT_C0_DISPATCH(pair_kind,
     hipLaunchKernelGGL((conv0_table_kernel<PK_>), dim3(TBL16 / 256, B), dim3(256), 0, s, coef, (long)C0 * (K0 + 1), K0 + 1, (const float*)nullptr,
-                       table_ws);
+                       table_ws, (const int*)exps);
     hipLaunchKernelGGL((conv0_mfma_kernel<0, PK_>), grid, dim3(256), 0, s, wav, L, stride, T1, (const void*)table_ws, (long)TBL16 * 8,
-                       (const double*)nullptr, (int64_t)1, 0.f, (const float*)nullptr, (const float*)nullptr, 0.f, 1, out);)
+                       (const double*)nullptr, (int64_t)1, 0.f, (const float*)nullptr, (const float*)nullptr, 0.f, 1, out, (const int*)exps);)
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -269,9 +298,9 @@ int launch_conv0_mfma_layer(const float* wav, int B, int64_t L, int stride, int6
   if (((uintptr_t)table_ws & 15) || ((uintptr_t)out & 127) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) { set_error("conv0_mfma: alignment"); return -1; }
   dim3 grid((unsigned)((T1 + 255) / 256), B);
   SVT_C0_DISPATCH(pair_kind,
-    hipLaunchKernelGGL((conv0_table_kernel<PK_>), dim3(TBL16 / 256, 1), dim3(256), 0, s, w0, 0L, K0, b0, table_ws);
+    hipLaunchKernelGGL((conv0_table_kernel<PK_>), dim3(TBL16 / 256, 1), dim3(256), 0, s, w0, 0L, K0, b0, table_ws, (const int*)nullptr);
     hipLaunchKernelGGL((conv0_mfma_kernel<1, PK_>), grid, dim3(256), 0, s, wav, L, stride, T1, (const void*)table_ws, 0L, wav_moments, n_wav,
-                       eps_wav, gamma, beta, eps, cpg, out);)
+                       eps_wav, gamma, beta, eps, cpg, out, (const int*)nullptr);)
   SVT_LAUNCH_CHECK();
   return 0;
 }
