@@ -240,6 +240,11 @@ int svt_video_load_param(svt_video* v, const char* key, const void* data_host, i
 /* folds the eval-mode batch norms into the conv weights, re-lays the weights out tap-major / as MFMA fragments, uploads */
 int svt_video_finalize(svt_video* v);
 int64_t svt_video_workspace_bytes(const svt_video* v, int32_t batch, int32_t t, int32_t h, int32_t w);
+/* keep != 0: the caller OWNS the workspace it passes to svt_video_forward -- between two calls nothing else writes it.  The zero halos
+ * of the padded stage buffers (which no kernel of the path overwrites) are then written once per (workspace pointer, geometry, stream)
+ * instead of on every call: 12 launches, 1.3 GB of stores, 0.25 ms per 16 x 500 frames of 88 x 88.  Default 0: the workspace is scratch
+ * and every call rewrites them.  A host-side setting: no device work. */
+int svt_video_keep_workspace(svt_video* v, int keep);
 /* video (B,1,T,H,W) f32 on the device -> out (B,T,embed_dim) f32 */
 int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);

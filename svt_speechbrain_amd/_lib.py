@@ -94,6 +94,7 @@ SYMBOLS = {
     "svt_video_destroy": (None, [C.c_void_p]),
     "svt_video_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "svt_video_finalize": (C.c_int, [C.c_void_p]),
+    "svt_video_keep_workspace": (C.c_int, [C.c_void_p, C.c_int]),
     "svt_video_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "svt_video_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

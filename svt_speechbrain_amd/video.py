@@ -74,6 +74,9 @@ class SubModel(ReplicaAware, nn.Module):
             h = C.c_void_p()
             _lib.check(lib.svt_video_create(self.embed_dim, PRECISIONS[self.precision], idx, C.byref(h)), "svt_video_create", lib)
             slot.handle = h
+            # the slot's workspace tensor belongs to this handle alone (DeviceSlot.workspace): the stage buffers' zero halos survive
+            # from call to call and are written once per geometry instead of on every forward
+            _lib.check(lib.svt_video_keep_workspace(slot.handle, 1), "svt_video_keep_workspace", lib)
         for name, t in src._tensors():
             if name.endswith("num_batches_tracked"):
                 continue

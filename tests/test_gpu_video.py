@@ -162,6 +162,36 @@ def test_video_frontend_errors():
         m.load_state_dict({"proj.weight": torch.zeros(64, 512)})
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_kept_workspace_writes_the_zero_halos_once_and_again_when_it_must(prec):
+    """svt_video_keep_workspace: the module owns its workspace, so the zero halos of the stage buffers are written on the first call of
+    a geometry only.  Same input -> bit-identical output on the kept halos; another geometry in between -> rewritten; with keep = 0 (the
+    C-ABI default: the workspace is scratch) a workspace full of NaN patterns in front of every call changes nothing."""
+    from svt_speechbrain_amd import _lib
+    lib = _lib.load()
+    m = SubModel(512, 128, "prelu", precision=prec, seed=4991).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(2, 1, 6, 88, 88, generator=g).to(DEV)
+    b = torch.randn(1, 1, 3, 60, 60, generator=g).to(DEV)
+    ya = m(a).clone()
+    assert torch.isfinite(ya).all() and torch.equal(m(a), ya) and torch.equal(m(a), ya)        # second and third call: halos kept
+    yb = m(b).clone()                                                                           # another geometry, same (larger) workspace
+    assert torch.equal(m(a), ya) and torch.equal(m(b), yb) and torch.equal(m(a), ya)
+    slot = m._sync(a.device)
+    _lib.check(lib.svt_video_keep_workspace(slot.handle, 0), "svt_video_keep_workspace")
+    for _ in range(2):
+        slot.ws.fill_(0xFF)                                                                     # bf16 / fp32 NaN patterns everywhere
+        assert torch.equal(m(a), ya)
+    _lib.check(lib.svt_video_keep_workspace(slot.handle, 1), "svt_video_keep_workspace")       # forgets what it had written
+    slot.ws.fill_(0xFF)
+    assert torch.equal(m(a), ya) and torch.equal(m(a), ya)
+    side = torch.cuda.Stream()                                                                  # another stream: written again, in ITS order
+    with torch.cuda.stream(side):
+        yc = m(a)
+    side.synchronize()
+    assert torch.equal(yc, ya)
+
+
 # ---- AV-HuBERT video encoder end to end (front-end pinned above; transformer checked against the oracle restatement,
 # which is parity-unpinned for fairseq: see oracle/svt_oracle.py::avhubert_video_forward) ----
 @pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.35), ("fp16", 0.05)])
