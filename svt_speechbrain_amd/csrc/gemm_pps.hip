@@ -43,8 +43,9 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 // an empty asm that "reads and writes" every register of a fragment array: whatever loads them must have completed here
 template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
-  static_assert(N >= 2 && N <= 4, "fragment arrays of 2..4 blocks");
-  if constexpr (N == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+  static_assert((N >= 2 && N <= 4) || N == 8, "fragment arrays of 2..4 or 8 blocks");
+  if constexpr (N == 8) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+  else if constexpr (N == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
   else if constexpr (N == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
   else asm volatile("" : "+v"(r[0]), "+v"(r[1]));
 }
@@ -52,7 +53,8 @@ template <int N> __device__ __forceinline__ void touch_regs(bf16x8 (&r)[N]) {
 // STAUX: cache policy of the epilogue stores (buffer instruction aux bits: 0 = default write-back, 2 = nt, 16 = sc1 write-through)
 // STAMP (tools/gemm_trace.py --slots): s_memtime at both ends of every slot of one slab of the stream, per wave
 // HB: four barriers per slab instead of eight (see the loops)
-template <int BM, int ACT, int STAUX, int STAMP = 0, bool HB = false>
+// TWO (round 5): two slots per slab instead of four -- see the schedule in front of its loops
+template <int BM, int ACT, int STAUX, int STAMP = 0, bool HB = false, bool TWO = false>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 64;        // 16-row blocks per wave (wave tile BM/4 x 128)
@@ -131,6 +133,25 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                  : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
   }
+  // TWO: LDS = A ring of three BM-row units, then two rings of two 128-row HALF units of W: half h holds output columns 128 h .. + 127, the
+  // columns of wave group h alone
+  constexpr unsigned A_BYTES = BM * 128u, WH_BYTES = 128 * 128u;
+  auto lds_a2 = [&](int slot, int i) -> unsigned { return lds0 + (unsigned)slot * A_BYTES + (unsigned)(wave + 8 * i) * 1024u; };
+  auto lds_w2 = [&](int slot, int i) -> unsigned {   // piece i of a W unit: half i >> 1, rows (wave + 8 (i & 1)) * 8 .. + 7 of that half
+    return lds0 + 3 * A_BYTES + (unsigned)((i >> 1) * 2 + slot) * WH_BYTES + (unsigned)(wave + 8 * (i & 1)) * 1024u;
+  };
+  if constexpr (TWO) {
+    // head: A_0, W_0 (both halves), A_1, W^0_1
+#pragma unroll
+    for (int i = 0; i < GA; ++i) dma(aofE[i], gA, lds_a2(0, i));
+#pragma unroll
+    for (int i = 0; i < GW; ++i) dma(wofE[i], gW, lds_w2(0, i));
+#pragma unroll
+    for (int i = 0; i < GA; ++i) dma(aofE[i], gA + BK * 2, lds_a2(1, i));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(wofE[i], gW + BK * 2, lds_w2(1, i));
+    wait_vm<GA + 2>();
+  } else {
   // head of the stream: A_0 -> slot 0, W_0 -> slot 1, A_1 -> slot 2
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aofE[i], gA, lds_unit(0, i));
@@ -139,15 +160,18 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
   for (int i = 0; i < GA; ++i) dma(aofE[i], gA + BK * 2, lds_unit(2, i));
   wait_vm<GA>();   // the bias loads are older than every request of the head
+  }
   asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
+  if constexpr (!TWO) {
   __builtin_amdgcn_s_barrier();
   if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
+  }
 
-  bf16x8 wfr[4], xfr[MB];
+  bf16x8 wfr[TWO ? 8 : 4], xfr[MB];
   int sa = 0, sw = 1, kt = 0, ti = 0;
   const int grp = wave >> 2;   // = wn
   // slot stamps of slab gs (dbg 5: middle of the second tile, 6: last slab of the first tile, 7: first slab of the second)
@@ -311,6 +335,125 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   sw = sw + 2 >= NSLOT ? sw + 2 - NSLOT : sw + 2;                                                                   \
   if (++kt == nk) kt = 0;
 
+  if constexpr (TWO) {
+    // ---- two slots per slab (round 5) ----
+    // A slab is two intervals, S_g .. M_g .. S_{g+1}, with ONE barrier at each bound.  Waves 0-3 (columns 0-127) multiply k-step 0 and
+    // read k-step 1 in the first interval, multiply k-step 1 and read the NEXT slab's k-step 0 in the second; waves 4-7 (columns
+    // 128-255) read and then multiply k-step 0 in the first, k-step 1 in the second: on every SIMD one wave issues 6 MB MFMAs
+    // (24 / 32) while its partner reads MB + 8 fragments and issues the ring's requests.  Half the barriers, half the fragment
+    // waits and half the slot turn-arounds of the four-slot schedule per slab.
+    // Because waves 0-3 read slab g + 1 half a slab before waves 4-7 do, the two wave groups need different things at different
+    // times, and W is therefore kept in HALF units (the 128 columns of one group): with g the slab,
+    //    needed by M_g:      A_{g+1}, W^0_{g+1}            needed by S_{g+1}:   W^1_{g+1}
+    //    free from S_g:      the tiles of A_{g-1}, W^1_{g-1}   free from M_g:   the tile of W^0_g
+    // so the first interval of slab g requests W^1_{g+1} and the first half of A_{g+2}, the second W^0_{g+2} and the rest of A_{g+2}:
+    // every request is issued a whole slab before its first read, out of 3 A tiles + 2 + 2 W half tiles = exactly the 160 KiB (BM = 256).
+    constexpr int GA1 = (GA + 1) / 2, GA2 = GA - GA1;
+    int a0 = 0, w0s = 0;   // A ring slot of slab g; W ring slot (both halves) of slab g
+    auto frag_read = [&](int aslot_, int wslot_, int ks) {
+      const uint4* xa = lds + aslot_ * (A_BYTES / 16) + xoff;
+      const uint4* wa = lds + (3 * A_BYTES + (unsigned)(grp * 2 + wslot_) * WH_BYTES) / 16;
+#pragma unroll
+      for (int jj = 0; jj < MB; ++jj) xfr[jj] = __builtin_bit_cast(bf16x8, xa[jj * 128 + (ks ? frag1 : frag0)]);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) wfr[nb] = __builtin_bit_cast(bf16x8, wa[nb * 128 + (ks ? frag1 : frag0)]);
+    };
+    auto frag_wait = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      touch_regs(xfr);
+      touch_regs(wfr);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int jj = 0; jj < MB; ++jj) acc[nb][jj] = SVT_MFMA_16x16x32(xfr[jj], wfr[nb], acc[nb][jj]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // the requests of slab (kt_, ti_): first interval (W^1 of the next slab, first half of A two slabs on) / second interval
+    auto req1 = [&](int kt_, int ti_, int a0_, int w0_) {
+      const bool t_even = (ti_ & 1) == 0;
+      const bool w_cur = kt_ + 1 < nk, a_cur = kt_ + 2 < nk;
+      const bool w_even = w_cur == t_even, a_even = a_cur == t_even;
+      const char* wb = gW + (long)(w_cur ? kt_ + 1 : 0) * (BK * 2);
+      const char* ab = gA + (long)(a_cur ? kt_ + 2 : kt_ + 2 - nk) * (BK * 2);
+      const int aslot = a0_ + 2 >= 3 ? a0_ - 1 : a0_ + 2;
+      if (kt_ + 1 == nk && has_bias) {   // the next tile's bias: older than this interval's requests, covered by the wait in front of M_g
+        const float* bp = p.bias + ((((ti_ + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
+      }
+#pragma unroll
+      for (int i = 2; i < 4; ++i) dma(w_even ? wofE[i] : wofO[i], wb, lds_w2(w0_ ^ 1, i));
+#pragma unroll
+      for (int i = 0; i < GA1; ++i) dma(a_even ? aofE[i] : aofO[i], ab, lds_a2(aslot, i));
+    };
+    auto req2 = [&](int kt_, int ti_, int a0_, int w0_) {
+      const bool t_even = (ti_ & 1) == 0;
+      const bool w_cur = kt_ + 2 < nk, a_cur = kt_ + 2 < nk;
+      const bool w_even = w_cur == t_even, a_even = a_cur == t_even;
+      const char* wb = gW + (long)(w_cur ? kt_ + 2 : kt_ + 2 - nk) * (BK * 2);
+      const char* ab = gA + (long)(a_cur ? kt_ + 2 : kt_ + 2 - nk) * (BK * 2);
+      const int aslot = a0_ + 2 >= 3 ? a0_ - 1 : a0_ + 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma(w_even ? wofE[i] : wofO[i], wb, lds_w2(w0_, i));
+#pragma unroll
+      for (int i = GA1; i < GA; ++i) dma(a_even ? aofE[i] : aofO[i], ab, lds_a2(aslot, i));
+    };
+    __builtin_amdgcn_s_barrier();   // the head has landed for everyone
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
+    if (grp == 0) {
+      frag_read(0, 0, 0);
+      frag_wait();
+      for (int g = 0; g < G; ++g) {
+        const bool last_k = kt + 1 == nk;
+        __builtin_amdgcn_s_barrier();                       // S_g
+        mma();                                             // k-step 0
+        frag_read(a0, w0s, 1);
+        req1(kt, ti, a0, w0s);
+        frag_wait();
+        wait_vm<2 + GA1>();                                // A_{g+1} and W^0_{g+1} (requested a slab ago) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                       // M_g
+        mma();                                             // k-step 1
+        req2(kt, ti, a0, w0s);                              // with this slab's indices, in front of the epilogue's stores
+        const int a1 = a0 + 1 == 3 ? 0 : a0 + 1;
+        if (last_k) epilogue();
+        if (g + 1 < G) { frag_read(a1, w0s ^ 1, 0); frag_wait(); }
+        if (last_k && !no_epi) wait_vm<2 + GA2 + MB * 4>(); else wait_vm<2 + GA2>();   // W^1_{g+1} has landed
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a1; w0s ^= 1;
+        if (++kt == nk) kt = 0;
+      }
+    } else {
+      for (int g = 0; g < G; ++g) {
+        const bool last_k = kt + 1 == nk;
+        __builtin_amdgcn_s_barrier();                       // S_g
+        frag_read(a0, w0s, 0);
+        req1(kt, ti, a0, w0s);
+        frag_wait();
+        mma();
+        wait_vm<2 + GA1>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                       // M_g
+        frag_read(a0, w0s, 1);
+        req2(kt, ti, a0, w0s);
+        frag_wait();
+        mma();
+        if (last_k) epilogue();
+        if (last_k && !no_epi) wait_vm<2 + GA2 + MB * 4>(); else wait_vm<2 + GA2>();
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a0 + 1 == 3 ? 0 : a0 + 1; w0s ^= 1;
+        if (++kt == nk) kt = 0;
+      }
+    }
+  } else
   if constexpr (HB) {
     // Four barriers per slab.  An interval between two barriers holds a LOAD slot AND an MFMA slot of every wave, in opposite
     // order for the two groups: waves 0-3 multiply group q and then read group q + 1, waves 4-7 read group q and then multiply
@@ -422,17 +565,17 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #undef PPS_ADVANCE
 }
 
-template <int BM, int ACT, int STAUX = 0, int STAMP = 0, bool HB = false>
+template <int BM, int ACT, int STAUX = 0, int STAMP = 0, bool HB = false, bool TWO = false>
 int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB, TWO>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB, TWO>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -446,6 +589,7 @@ static unsigned long a_span_bytes(const GemmArgs& a) {
   return (unsigned long)(((last / a.a_rpb) * a.a_bstride + (last % a.a_rpb) * a.a_rstride + a.K) * 2);
 }
 
+int g_pps_two_slots = 0;
 bool gemm_pps_eligible(const GemmArgs& a) {
   return !a.gen && a.nz == 1 && !a.resid && !a.out_f32 && !a.planes && a.alpha == 1.f && (a.act == ACT_NONE || a.act == ACT_GELU) &&
          a.K % 64 == 0 && a.K >= 128 && a.N % 256 == 0 && a.M >= 128 && a.c_vec && a.ldc % 8 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
@@ -501,6 +645,10 @@ int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) 
 // The dispatched form: write-through (sc1) stores, four barriers per slab (measured against the eight-barrier form and the default
 // store policy in round 3: profiles/r03_gemm_pps_slots.txt; those and the slot-stamp instantiations are built by `make DIAG=1`).
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy*/) {
+  if (g_pps_two_slots && (bm == 192 || bm == 256) && !a.trace) {   // svt_debug_set key 28: the two-slot schedule (round 5)
+    if (a.act == ACT_GELU) return bm == 256 ? launch_pps_t<256, ACT_GELU, 16, 0, false, true>(a, s) : launch_pps_t<192, ACT_GELU, 16, 0, false, true>(a, s);
+    return bm == 256 ? launch_pps_t<256, ACT_NONE, 16, 0, false, true>(a, s) : launch_pps_t<192, ACT_NONE, 16, 0, false, true>(a, s);
+  }
   if (a.act == ACT_GELU) {
     if (bm == 256) return launch_pps_t<256, ACT_GELU, 16, 0, true>(a, s);
     if (bm == 192) return launch_pps_t<192, ACT_GELU, 16, 0, true>(a, s);

@@ -161,6 +161,7 @@ if __name__ == "__main__":
     ap.add_argument("--nobias", action="store_true")
     ap.add_argument("--no-x3-dma", action="store_true", help="split-operand modes: register-staged kernel instead of the LDS-DMA one (A/B)")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
+    ap.add_argument("--set", action="append", default=[], help="key=value for svt_debug_set (repeatable), e.g. --set 28=1: two-slot schedule of gemm_pps_kernel")
     a = ap.parse_args()
     _lib.load().svt_debug_set(0, a.dbg)
     _lib.load().svt_debug_set(1, a.bm)
@@ -170,6 +171,8 @@ if __name__ == "__main__":
     _lib.load().svt_debug_set(7, a.skinny_max_tiles)
     _lib.load().svt_debug_set(11, 0 if a.no_x3_dma else 1)
     _lib.load().svt_debug_set(12, 1)
+    for kv in a.set:
+        _lib.load().svt_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     for s in SHAPES:
         if a.only and a.only not in s[0]:
             continue
