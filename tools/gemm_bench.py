@@ -162,7 +162,10 @@ if __name__ == "__main__":
     ap.add_argument("--no-x3-dma", action="store_true", help="split-operand modes: register-staged kernel instead of the LDS-DMA one (A/B)")
     ap.add_argument("--pad", type=int, default=0, help="extra elements of row pitch for A and W (plain GEMM shapes)")
     ap.add_argument("--set", action="append", default=[], help="key=value for svt_debug_set (repeatable), e.g. --set 28=1: two-slot schedule of gemm_pps_kernel")
+    ap.add_argument("--lib-suffix", default=None, help="load libsvt_mi355_<suffix>.so (an experimental build of the bf16 library) instead")
     a = ap.parse_args()
+    if a.lib_suffix:
+        _lib.LIB_PATH = _lib.LIB_PATH.replace("libsvt_mi355.so", f"libsvt_mi355_{a.lib_suffix}.so")
     _lib.load().svt_debug_set(0, a.dbg)
     _lib.load().svt_debug_set(1, a.bm)
     _lib.load().svt_debug_set(2, a.ring)
