@@ -1,0 +1,49 @@
+#!/bin/bash
+# round-5 measurement set -> gpurun_out/r05_final (copied into profiles/ afterwards).  One box, one session.
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repo copy)}"
+cd "$GRAFT_REPO_ROOT"
+O="gpurun_out/r05_final"
+mkdir -p "$O"
+FILT='^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path'
+B="python bench.py --no-cpu-baseline"
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+(time python -m pytest tests -q -m gpu -x 2>&1 | grep -v "$FILT" | tail -6) > "$O/r05_gputests.log" 2>&1
+fi
+python bench.py > "$O/r05_bench.json" 2> "$O/bench.err"
+$B --streams 1 > "$O/r05_bench_streams1.json" 2>> "$O/bench.err"
+$B --precision fp16 > "$O/r05_bench_fp16.json" 2>> "$O/bench.err"
+$B --precision fp16x3 --steps 10 > "$O/r05_bench_fp16x3.json" 2>> "$O/bench.err"
+$B --precision bf16x3 --steps 10 > "$O/r05_bench_bf16x3.json" 2>> "$O/bench.err"
+$B --precision fp32 --steps 5 --no-extra-legs > "$O/r05_bench_fp32.json" 2>> "$O/bench.err"
+$B --model hubert-large-ll60k --batch 64 --steps 10 > "$O/r05_bench_c3_hubert_large_b64.json" 2>> "$O/bench.err"
+$B --model hubert-large-ll60k --batch 64 --steps 10 --precision fp16 > "$O/r05_bench_c3_hubert_large_b64_fp16.json" 2>> "$O/bench.err"
+$B --model wav2vec2-large-lv60 --batch 64 --steps 10 > "$O/r05_bench_c5_wav2vec2_large_b64.json" 2>> "$O/bench.err"
+$B --model hubert-large-ll60k --batch 64 --steps 4 --precision fp16x3 > "$O/r05_bench_c3_hubert_large_b64_fp16x3.json" 2>> "$O/bench.err"
+$B --batch 1 --seconds 5 --steps 100 --warmup 10 > "$O/r05_bench_c1_b1_5s.json" 2>> "$O/bench.err"
+$B --batch 1 --seconds 5 --steps 100 --warmup 10 --streams 1 > "$O/r05_bench_c1_b1_5s_one_stream.json" 2>> "$O/bench.err"
+(python tools/av_bench.py; python tools/rca_bench.py; python tools/video_bench.py) 2>/dev/null > "$O/r05_c4_av_bench.txt"
+(python tools/soak.py --iters 1000; python tools/soak.py --precision fp16x3 --iters 300; python tools/soak.py --precision fp16 --iters 300; python tools/soak.py --model hubert-large-ll60k --batch 64 --iters 150; python tools/soak.py --batch 1 --seconds 5 --iters 1000; python tools/soak.py --video --iters 300) 2>&1 | grep forwards > "$O/r05_soak.txt"
+python tools/gemm_yardstick.py --iters 30 > "$O/r05_gemm_vendor_library_yardstick.txt" 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+P="rocprofv3 --kernel-trace --stats --output-format csv"
+$P -d "$GRAFT_REPO_ROOT/$O/prof_s1" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-extra-legs --streams 1 > /dev/null 2>&1
+$P -d "$GRAFT_REPO_ROOT/$O/prof_s2" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-extra-legs > /dev/null 2>&1
+$P -d "$GRAFT_REPO_ROOT/$O/prof_c3" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-extra-legs --streams 1 --model hubert-large-ll60k --batch 64 --steps 5 --warmup 2 > /dev/null 2>&1
+cd "$GRAFT_REPO_ROOT"
+BA="$GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs"
+bash tools/pmc.sh r05_final/pmc_fetch FETCH_SIZE -- $BA
+bash tools/pmc.sh r05_final/pmc_write WRITE_SIZE -- $BA
+bash tools/pmc.sh r05_final/pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $BA --streams 1
+python tools/trace_summary.py "$O/prof_s1" 43 > "$O/r05_bench_kernel_trace_summary.txt"
+python tools/trace_summary.py "$O/prof_s2" 43 > "$O/r05_bench_2streams_kernel_trace_summary.txt"
+python tools/trace_summary.py "$O/prof_c3" 12 > "$O/r05_c3_hubert_large_kernel_trace_summary.txt"
+cp "$(ls $O/prof_s1/*/*kernel_stats.csv | head -1)" "$O/r05_bench_kernel_stats.csv"
+cp "$(ls $O/prof_c3/*/*kernel_stats.csv | head -1)" "$O/r05_c3_hubert_large_kernel_stats.csv"
+python tools/pmc_summary.py "$O/pmc_fetch" "$O/pmc_write" --json "$O/r05_pmc_hbm_traffic.json" > "$O/r05_pmc_hbm_traffic.txt"
+python tools/pmc_summary.py "$O/pmc_mfma" --json "$O/r05_pmc_mfma_busy.json" > "$O/r05_pmc_mfma_busy.txt"
+rm -rf "$O/prof_s1" "$O/prof_s2" "$O/prof_c3" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_mfma"
+tail -3 "$O/bench.err"
+for f in r05_bench r05_bench_streams1 r05_bench_fp16 r05_bench_fp16x3 r05_bench_bf16x3 r05_bench_fp32 r05_bench_c3_hubert_large_b64 r05_bench_c3_hubert_large_b64_fp16 r05_bench_c5_wav2vec2_large_b64 r05_bench_c3_hubert_large_b64_fp16x3 r05_bench_c1_b1_5s r05_bench_c1_b1_5s_one_stream; do python -c "
+import json; r=json.load(open('$O/$f.json')); p=r.get('parity') or {}; print('$f', r['value'], r['ms_per_step'], r['roofline']['achieved'], r['roofline']['frac'], r['config']['end_to_end_mfma_frac'], r.get('sustained_clips_per_s'), r.get('notes_out_clips_per_s'), r.get('parity_grade_clips_per_s'), 'parity:', p.get('max_abs_dlogit'), p.get('frames_argmax_mismatch'), p.get('COnPOff_f1'), r.get('verified'))"; done
+cat "$O/r05_gputests.log" 2>/dev/null
