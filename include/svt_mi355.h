@@ -209,6 +209,14 @@ int svt_fbank(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t sa
               int32_t win_length, int32_t hop_length, int32_t n_mels, float f_min, float f_max, float top_db,
               float* out_dev, void* workspace_dev, size_t workspace_bytes, int device, void* stream);
 
+/* ======================================================================================================================
+ * DIAGNOSTIC SURFACE: svt_debug_* and svt_prof_*.  These entry points exist for the unit tests of single kernels, the micro-benchmarks
+ * under tools/ and the bench's per-launch timing.  They are the ONE exception to the conventions of the product entry points above:
+ * a svt_debug_* call may allocate and free device memory and may synchronise its stream (hipMalloc / hipStreamSynchronize inside), and
+ * svt_debug_set changes process-wide kernel selection.  No product entry point (svt_encoder_*, svt_linear_*, svt_rca_*, svt_video_*,
+ * svt_decode_frames, svt_ctc_greedy, svt_fbank, svt_deltas, svt_context_window, svt_bce_loss, svt_nll_loss, svt_softmax) calls them, and
+ * none of those allocates or synchronises.
+ * ====================================================================================================================== */
 /* ---- test / micro-benchmark hook: the dense contraction kernel on caller-supplied operands ----
  * C (M,N) = act(A W^T + bias) + resid with A (M,K) and W (N,K) in the operand type of `precision`
  * (fp32, or bf16 bits for SVT_PREC_BF16; the split-operand precisions take fp32 operands), C in the operand type unless out_f32.  a_rpb/a_bstride/a_rstride describe the

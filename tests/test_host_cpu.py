@@ -265,6 +265,45 @@ def test_manifest_slicing_rules(tmp_path):
     assert D.slice_annotation(anno, 1, 2).shape[0] == 249 and D.slice_annotation(anno, 2, 3).shape[0] == 249  # round(249) .. round(498)
 
 
+def test_transcription_scores_against_an_independent_maximum_matching():
+    """scoring.py is PARITY UNPINNED (mir_eval absent), but every precision / recall / F number it returns depends only on the SIZE of a
+    maximum bipartite matching of a hit graph whose rule is three comparisons -- and the size of a maximum matching is unique.  Here the
+    hit graphs are rebuilt independently (plain loops over mir_eval's published rules) and matched by scipy's Hopcroft-Karp
+    (scipy.sparse.csgraph.maximum_bipartite_matching, a third implementation): 300 random transcriptions with dense near-collisions."""
+    import math
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from svt_speechbrain_amd import scoring as SC
+    rng = np.random.default_rng(77)
+
+    def size(hit):
+        if hit.size == 0 or not hit.any():
+            return 0
+        return int((maximum_bipartite_matching(csr_matrix(hit.astype(np.int8)), perm_type="column") >= 0).sum())
+
+    for trial in range(300):
+        n_ref, n_est = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        # onsets on a 30 ms grid inside a short song: many notes within each other's 50 ms window; few distinct pitches; 10-cent detunings
+        def notes(n):
+            on = np.sort(rng.integers(0, 60, n) * 0.03 + rng.normal(0, 0.004, n).round(4)).clip(0, None)
+            dur = rng.choice([0.06, 0.12, 0.3, 0.9], n)
+            pitch = rng.choice([60, 60, 62, 64], n) + rng.choice([0.0, 0.1, 0.45, 0.55], n)
+            return [[float(a), float(a + d), float(p)] for a, d, p in zip(on, dur, pitch)]
+        ref, est = notes(n_ref), notes(n_est)
+        on_hit = np.zeros((n_ref, n_est), bool); full = on_hit.copy(); nooff = on_hit.copy(); off_hit = on_hit.copy()
+        for i, (ro, rf, rp) in enumerate(ref):
+            for j, (eo, ef, ep) in enumerate(est):
+                o = round(abs(ro - eo), 4) <= 0.05
+                pch = abs(1200 * (math.log2(SC.midi_to_hz(rp)) - math.log2(SC.midi_to_hz(ep)))) <= 50.0
+                f = round(abs(rf - ef), 4) <= max(0.2 * (rf - ro), 0.05)
+                on_hit[i, j], nooff[i, j], full[i, j], off_hit[i, j] = o, o and pch, o and pch and f, f
+        m = SC.score_song(est, ref)
+        for key_p, key_r, hit in (("Precision", "Recall", full), ("Precision_no_offset", "Recall_no_offset", nooff),
+                                  ("Onset_Precision", "Onset_Recall", on_hit), ("Offset_Precision", "Offset_Recall", off_hit)):
+            k = size(hit)
+            assert m[key_p] == pytest.approx(k / n_est) and m[key_r] == pytest.approx(k / n_ref), (trial, key_p, k)
+
+
 def test_transcription_scores_hand_derived():
     # PARITY UNPINNED (mir_eval is not installed here): known answers derived by hand from mir_eval's published rules
     from svt_speechbrain_amd import scoring as SC
