@@ -66,6 +66,23 @@ def mode_agreement(logits: torch.Tensor, frames, ref_logits: torch.Tensor, ref_f
     if fr.shape != rf.shape:
         raise ValueError(f"mode_agreement: frame arrays of different shape {fr.shape} vs {rf.shape}")
     differ = (fr["octave"] != rf["octave"]) | (fr["pitch_class"] != rf["pitch_class"])
+    # a differing frame is a NEAR TIE when, in the reference mode's own logits, the class the other mode picked is within 2e-3 of the
+    # winner: two forwards that both sit within the north star's 1e-3 of the truth cannot be expected to break such a tie the same way
+    n_oct = int(max(fr["octave"].max(initial=0), rf["octave"].max(initial=0))) + 1
+    near_tie = 0
+    if differ.any() and d.numel():
+        tol = 2e-3
+        rl = ref_logits.detach().float().cpu().reshape(-1, ref_logits.shape[-1])
+        n_oct_logits = rl.shape[-1] - 2 - 13 if rl.shape[-1] >= 16 else n_oct      # 2 onset / offset logits, then octaves, then 13 classes
+        idx = np.flatnonzero(differ.reshape(-1))
+        for i in idx:
+            row = rl[i]
+            ok = True
+            for lo, hi, a, b in ((2, 2 + n_oct_logits, int(fr["octave"].reshape(-1)[i]), int(rf["octave"].reshape(-1)[i])),
+                                 (2 + n_oct_logits, rl.shape[-1], int(fr["pitch_class"].reshape(-1)[i]), int(rf["pitch_class"].reshape(-1)[i]))):
+                if a != b and float(row[lo + b] - row[lo + a]) > tol:
+                    ok = False
+            near_tie += int(ok)
     notes = frames2note_batch(fr, onset_thres, offset_thres, frame_size, lengths)
     ref_notes = frames2note_batch(rf, onset_thres, offset_thres, frame_size, lengths)
     out: Dict[str, object] = {
@@ -73,10 +90,13 @@ def mode_agreement(logits: torch.Tensor, frames, ref_logits: torch.Tensor, ref_f
         "mean_abs_dlogit": float(d.mean().item()) if d.numel() else 0.0,
         "frames": int(differ.size),
         "frames_argmax_mismatch": int(differ.sum()),
+        "frames_argmax_mismatch_beyond_near_ties": int(differ.sum()) - near_tie,
         "max_abs_dp_onset": float(np.abs(fr["p_on"] - rf["p_on"]).max()) if differ.size else 0.0,
         "max_abs_dp_offset": float(np.abs(fr["p_off"] - rf["p_off"]).max()) if differ.size else 0.0,
     }
     out.update(note_agreement(notes, ref_notes))
     out["meets_1e-3_and_identical_notes"] = bool(out["max_abs_dlogit"] <= 1e-3 and out["frames_argmax_mismatch"] == 0 and
                                                  out["clips_with_identical_notes"] == out["clips"])
+    out["meets_1e-3_and_identical_argmax_up_to_near_ties"] = bool(out["max_abs_dlogit"] <= 1e-3 and
+                                                                  out["frames_argmax_mismatch_beyond_near_ties"] == 0)
     return out

@@ -589,7 +589,7 @@ static unsigned long a_span_bytes(const GemmArgs& a) {
   return (unsigned long)(((last / a.a_rpb) * a.a_bstride + (last % a.a_rpb) * a.a_rstride + a.K) * 2);
 }
 
-int g_pps_two_slots = 2;
+int g_pps_two_slots = 0;
 bool gemm_pps_eligible(const GemmArgs& a) {
   return !a.gen && a.nz == 1 && !a.resid && !a.out_f32 && !a.planes && a.alpha == 1.f && (a.act == ACT_NONE || a.act == ACT_GELU) &&
          a.K % 64 == 0 && a.K >= 128 && a.N % 256 == 0 && a.M >= 128 && a.c_vec && a.ldc % 8 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
@@ -645,9 +645,10 @@ int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) 
 // The dispatched form: write-through (sc1) stores, four barriers per slab (measured against the eight-barrier form and the default
 // store policy in round 3: profiles/r03_gemm_pps_slots.txt; those and the slot-stamp instantiations are built by `make DIAG=1`).
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy*/) {
-  // svt_debug_set key 28: the two-slot schedule (round 5).  0 = never, 1 = wherever it applies, 2 (default) = the one launch family it
-  // measured faster on: the FFN-1 of the LARGE models (N = 4096, K = 1024, GELU, 256-row tiles: 284 -> 273 us; every C2 shape is 1-6 %
-  // slower with it, profiles/r05_gemm_two_slot_ab.txt)
+  // svt_debug_set key 28: the two-slot schedule (round 5).  0 (default) = never, 1 = wherever it applies, 2 = the one launch family it
+  // measured faster on in isolation: the FFN-1 of the LARGE models (N = 4096, K = 1024, GELU, 256-row tiles: 284 -> 273 us; every C2 shape
+  // is 1-6 % slower with it) -- which did not carry over to the step: C3 2 476 clips/s with it against 2 505 without
+  // (profiles/r05_gemm_two_slot_ab.txt)
   const bool two = g_pps_two_slots == 1 || (g_pps_two_slots == 2 && a.act == ACT_GELU && bm == 256 && a.N == 4096 && a.K == 1024 && a.M >= 16384);
   if (two && (bm == 192 || bm == 256) && !a.trace) {
     if (a.act == ACT_GELU) return bm == 256 ? launch_pps_t<256, ACT_GELU, 16, 0, false, true>(a, s) : launch_pps_t<192, ACT_GELU, 16, 0, false, true>(a, s);

@@ -265,6 +265,41 @@ def test_manifest_slicing_rules(tmp_path):
     assert D.slice_annotation(anno, 1, 2).shape[0] == 249 and D.slice_annotation(anno, 2, 3).shape[0] == 249  # round(249) .. round(498)
 
 
+def test_mode_agreement_levels_and_near_ties():
+    """svt_speechbrain_amd/agreement.py (what bench.py's parity leg and the 16-bit bounds of the GPU suite report), on hand-made logits:
+    a flip across a 1e-5 margin is a near tie, a flip across a 1.0 margin is not; identical inputs agree at every level; the note
+    metrics are micro-averaged over the clips."""
+    from svt_speechbrain_amd.agreement import mode_agreement, note_agreement
+    from svt_speechbrain_amd.decode import FRAME_DTYPE
+    torch.manual_seed(0)
+    ref = torch.randn(2, 60, 20)
+    ref[..., 0] = -3.0
+    ref[0, 10:14, 0] = 3.0; ref[0, 30, 1] = 3.0; ref[1, 5, 0] = 3.0          # a few onsets / an offset: notes exist
+    ref[0, 3, 2], ref[0, 3, 3] = 5.0, 5.0 - 1e-5
+
+    def frames(lg):
+        fr = np.zeros(lg.shape[:2], dtype=FRAME_DTYPE)
+        fr["p_on"], fr["p_off"] = torch.sigmoid(lg[..., 0]).numpy(), torch.sigmoid(lg[..., 1]).numpy()
+        fr["octave"], fr["pitch_class"] = lg[..., 2:7].argmax(-1).numpy(), lg[..., 7:].argmax(-1).numpy()
+        return fr
+
+    same = mode_agreement(ref, frames(ref), ref, frames(ref))
+    assert same["frames_argmax_mismatch"] == 0 and same["clips_with_identical_notes"] == 2 and same["COnPOff_f1"] == 1.0
+    assert same["meets_1e-3_and_identical_notes"] and same["reference_notes"] > 0
+    own = ref.clone()
+    own[0, 3, 3] += 3e-5                                                       # breaks the near tie the other way
+    r = mode_agreement(own, frames(own), ref, frames(ref))
+    assert r["frames_argmax_mismatch"] == 1 and r["frames_argmax_mismatch_beyond_near_ties"] == 0 and r["max_abs_dlogit"] < 1e-3
+    assert not r["meets_1e-3_and_identical_notes"] and r["meets_1e-3_and_identical_argmax_up_to_near_ties"]
+    own[1, 7, 8] = ref[1, 7, 7:].max() + 1.0                                   # a hard flip of a pitch class
+    r = mode_agreement(own, frames(own), ref, frames(ref))
+    assert r["frames_argmax_mismatch"] == 2 and r["frames_argmax_mismatch_beyond_near_ties"] == 1
+    assert not r["meets_1e-3_and_identical_argmax_up_to_near_ties"]
+    # micro-average: 1 of 2 notes matched in one clip, 0 of 0 in the other -> precision 1/2, not the mean of (1/2, 1)
+    na = note_agreement([[[0.0, 1.0, 60], [2.0, 3.0, 70]], []], [[[0.0, 1.0, 60], [2.5, 3.0, 64]], []])
+    assert na["COnPOff_precision"] == 0.5 and na["COnPOff_recall"] == 0.5 and na["clips_with_identical_notes"] == 1
+
+
 def test_transcription_scores_against_an_independent_maximum_matching():
     """scoring.py is PARITY UNPINNED (mir_eval absent), but every precision / recall / F number it returns depends only on the SIZE of a
     maximum bipartite matching of a hit graph whose rule is three comparisons -- and the size of a maximum matching is unique.  Here the
