@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvt_mi355.so")
+# SVT_LIB_PATH: load another build of the bf16 library (kernel experiments: tools/*_bench.py, bench.py); default = the in-tree one
+LIB_PATH = os.environ.get("SVT_LIB_PATH") or os.path.join(_HERE, "libsvt_mi355.so")
 MAX_CONV = 8
 
 
