@@ -267,6 +267,8 @@ extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
 extern int g_stamp_ends;
 extern int g_pps_half_barriers;
+extern int g_gemm_p1w;       // svt_debug_set key 29: the single-wave-per-SIMD kernel (gemm_p1w.hip) where gemm_pps_kernel is dispatched
+int launch_gemm_p1w(const GemmArgs& a, int bm, hipStream_t s);
 extern int g_pps_two_slots;   // gemm_pps_kernel: two slots per slab (svt_debug_set key 28)
 extern int g_attn_stamp;
 extern int g_attn_variant;

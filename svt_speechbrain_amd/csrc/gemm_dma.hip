@@ -1352,8 +1352,12 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
     b.stamp_ends = g_stamp_ends;
     return launch_gemm_pps(b, g_gemm_force_bm ? g_gemm_force_bm : (best < 128 ? 128 : best), s, (g_gemm_variant - 50) / 10);
   }
-  if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 100 && gemm_pps_eligible(a))
+  if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 100 && gemm_pps_eligible(a)) {
+    // single-wave-per-SIMD kernel (gemm_p1w.hip, round 5): 5-11 % faster per launch wherever its un-overlapped epilogue is small beside the
+    // tile -- everything except GELU launches with fewer than 16 K slabs (FFN-1 of the base model: 12 slabs, 72.8 us here against 81.9)
+    if (g_gemm_p1w && a.K >= 192 && !a.trace && !(a.act == ACT_GELU && a.K < 1024)) return launch_gemm_p1w(a, best, s);
     return launch_gemm_pps(a, best, s, 2);
+  }
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&
                        a.a_z1 == 0 && a.a_z2 == 0 && a.w_z1 == 0 && a.w_z2 == 0;
   int mode = g_gemm_ring;
