@@ -1355,7 +1355,7 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 100 && gemm_pps_eligible(a)) {
     // single-wave-per-SIMD kernel (gemm_p1w.hip, round 5): 5-11 % faster per launch wherever its un-overlapped epilogue is small beside the
     // tile -- everything except GELU launches with fewer than 16 K slabs (FFN-1 of the base model: 12 slabs, 72.8 us here against 81.9)
-    if (g_gemm_p1w && a.K >= 192 && !a.trace && !(a.act == ACT_GELU && a.K < 1024)) return launch_gemm_p1w(a, best, s);
+    if (g_gemm_p1w && a.K >= 192 && (!a.trace || g_gemm_p1w == 2) && (g_gemm_p1w == 2 || !(a.act == ACT_GELU && a.K < 1024))) return launch_gemm_p1w(a, best, s);   // key 29 = 2: everywhere, traced launches included (tools/gemm_trace.py --p1w)
     return launch_gemm_pps(a, best, s, 2);
   }
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&

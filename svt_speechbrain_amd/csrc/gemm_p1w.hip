@@ -34,7 +34,7 @@ __device__ __forceinline__ void p1_dma(unsigned voff, const void* sbase, unsigne
 
 typedef unsigned p1_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int ACT>
+template <int BM, int ACT, bool TR = false>   // TR: the diagnostic instantiation (stamps; may spill a register or two: timing only)
 __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, int ntiles) {
   constexpr int BN = 256, BK = 64, NSLOT = 5;
   constexpr int MB = BM / 32;        // 16-row blocks per wave (wave tile BM/2 x 128)
@@ -95,6 +95,11 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   const int nk = p.K / BK;             // >= 2 (launcher)
   const int G = my_tiles * nk;         // slabs in this workgroup's stream
   const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
+  // diagnostics (tools/gemm_trace.py --p1w; dbg = 9 sets p.trace): wall-clock stamps at entry / first slab / exit, the epilogues' share, core
+  // cycles over the stream and the cycles the wave spent between reaching a slab's counted wait and leaving its barrier
+  constexpr bool tr = TR;
+  long long t_begin = 0, t_first = 0, t_epi = 0, c_first = 0, c_wait = 0;
+  if (tr) t_begin = wall_clock64();
   setup(lbase, aofE, wofE);
   setup(my_tiles > 1 ? nblk + lbase : lbase, aofO, wofO);   // always rows that exist: the stream's surplus requests read them
   f32x4 bq[2];
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   p1_wait_vm<GA + GW>();   // A_0 and W_0 (and the bias loads, older still) have landed
   asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
   __builtin_amdgcn_s_barrier();
+  if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -130,6 +136,8 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   // ---- the tile's epilogue (gemm_pps_kernel's, for a BM/2 x 128 wave tile): accumulators -> (+ bias at start, activation) -> bf16 ->
   //      buffer stores; re-arms the accumulators with the next tile's bias and rotates the source offsets ----
   auto epilogue = [&]() {
+    long long t_e0 = 0;
+    if (tr) t_e0 = wall_clock64();
     const int logical = ti * nblk + lbase;
     const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
       for (int i = 0; i < GA; ++i) { aofO[i] = into_odd ? na[i] : aofO[i]; aofE[i] = into_odd ? aofE[i] : na[i]; }
       wofO = into_odd ? nw : wofO; wofE = into_odd ? wofE : nw;
     }
+    if (tr) t_epi += wall_clock64() - t_e0;
   };
 
   // fragments of k-step ks of the slab whose A unit sits in ring slot `slot`
@@ -235,10 +244,13 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   auto slot_add = [](int s_, int d) { const int t = s_ + d; return t >= NSLOT ? t - NSLOT : t; };
   // barrier B_g with its counted wait (OUT = requests / stores that may stay in flight)
   auto mid_barrier = [&](auto out_c) {
+    long long c0_ = 0;
+    if (tr) c0_ = __builtin_amdgcn_s_memtime();
     p1_wait_vm<decltype(out_c)::value>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if (tr) c_wait += __builtin_amdgcn_s_memtime() - c0_;
   };
   using w_a = std::integral_constant<int, GA>;
   using w_as = std::integral_constant<int, GA + MB * 4>;
@@ -296,20 +308,30 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   }
   // the surplus requests of the stream's tail must have landed before the workgroup gives its LDS back; the last epilogue's stores, younger,
   // need not be waited for
+  long long t_loop = 0;
+  if (tr) t_loop = wall_clock64();
   if (no_epi) p1_wait_vm<0>(); else p1_wait_vm<MB * 4>();
+  if (tr && lane == 0) {   // record layout of gemm_pps_kernel (tools/gemm_trace.py); waves 0 / 2 stand for its two wave groups
+    if ((wave & 1) == 0) {
+      long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 1)) * 8;
+      o[0] = t_begin; o[1] = t_first; o[2] = t_loop - t_first - t_epi; o[3] = t_epi; o[4] = t_loop; o[5] = my_tiles;
+      o[6] = __builtin_amdgcn_s_memtime() - c_first; o[7] = BM;
+    }
+    p.trace[524288 + (long)blockIdx.x * 4 + wave] = c_wait;   // cycles between reaching a slab's counted wait and leaving its barrier, summed
+  }
 }
 
-template <int BM, int ACT>
+template <int BM, int ACT, bool TR = false>
 int launch_p1w_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
-  if (int r_ = ensure_dyn_lds((const void*)gemm_p1w_kernel<BM, ACT>, (int)lds_bytes)) return r_;
+  if (int r_ = ensure_dyn_lds((const void*)gemm_p1w_kernel<BM, ACT, TR>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_p1w_kernel<BM, ACT>), dim3(nblk), dim3(256), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_p1w_kernel<BM, ACT, TR>), dim3(nblk), dim3(256), lds_bytes, s, a, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -320,6 +342,10 @@ int launch_p1w_t(const GemmArgs& a, hipStream_t s) {
 int g_gemm_p1w = 1;   // svt_debug_set key 29: 1 (default) = this kernel where it measured faster than gemm_pps_kernel (gemm_dma.hip), 0 = never
 
 int launch_gemm_p1w(const GemmArgs& a, int bm, hipStream_t s) {
+  if (a.trace) {   // tools/gemm_trace.py --p1w: the two tile heights of the encoder's launches, without activation
+    if (bm == 256) return launch_p1w_t<256, ACT_NONE, true>(a, s);
+    return launch_p1w_t<192, ACT_NONE, true>(a, s);
+  }
   if (a.act == ACT_GELU) {
     if (bm == 256) return launch_p1w_t<256, ACT_GELU>(a, s);
     if (bm == 192) return launch_p1w_t<192, ACT_GELU>(a, s);

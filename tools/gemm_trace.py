@@ -107,15 +107,21 @@ def main():
     ap.add_argument("--one-tile", action="store_true", help="with --x3-slots: gemm_x3s_kernel (one tile per workgroup) instead of the persistent kernel")
     ap.add_argument("--x3-slots", action="store_true", help="slot stamps of gemm_x3p_kernel (fp16x3, the persistent split-operand kernel): four "
                     "launches, two slots each")
+    ap.add_argument("--p1w", action="store_true", help="trace gemm_p1w_kernel (svt_debug_set key 29 = 2) instead of gemm_pps_kernel; adds the "
+                    "cycles its waves spend at the slab barriers")
     a = ap.parse_args()
     if a.x3_slots:
         return x3_slots(a)
+    if a.p1w:
+        a.force_variant = a.force_variant or 70   # the persistent kernels' record layout
     if a.slots:
         a.force_variant = 70 + a.slots
     lib = _lib.load()
     lib.svt_debug_set(1, a.bm)
     lib.svt_debug_set(2, a.ring)
-    lib.svt_debug_set(3, a.force_variant)
+    lib.svt_debug_set(3, 0 if a.p1w else a.force_variant)
+    if a.p1w:
+        lib.svt_debug_set(29, 2)
     dev = torch.device("cuda:0")
     for name, M, N, K, conv, act, out_f32, resid in SHAPES:
         if a.only != name and not (a.only not in [x[0] for x in SHAPES] and a.only in name):
@@ -188,6 +194,12 @@ def main():
                   f"(min {mhz.min():.0f}, max {mhz.max():.0f}); MFMA pipe busy for {busy.mean():.2f} of the main-loop cycles "
                   f"(1024 bf16 FLOP/clk/SIMD)")
         print(f"  tiles per workgroup: min {int(t[:,5].min())} max {int(t[:,5].max())}")
+        if a.p1w:
+            cw = trace[524288:524288 + 1024].cpu().double()
+            cw = cw[cw > 0]
+            slabs = (t[:, 5] * (K // 64)).mean().item()
+            print(f"  gemm_p1w_kernel: core cycles between reaching a slab's counted wait and leaving its barrier: mean {cw.mean().item() / slabs:.0f} per slab "
+                  f"(the matrix pipe idles for them; {int(t[0, 7].item()) // 32 * 8 * 2 * 16} = its own cycles per slab)")
         if a.slots:
             def stamps():
                 r = trace[65536:65536 + 256 * 8 * 32].view(256, 8, 32).cpu()
