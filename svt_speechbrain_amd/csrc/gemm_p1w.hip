@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   const int woff = (wn * 8) * 128;    // ... of the W unit
 
   const int nk = p.K / BK;             // >= 2 (launcher)
-  const int G = my_tiles * nk;         // slabs in this workgroup's stream
   const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
   // diagnostics (tools/gemm_trace.py --p1w; dbg = 9 sets p.trace): wall-clock stamps at entry / first slab / exit, the epilogues' share, core
   // cycles over the stream and the cycles the wave spent between reaching a slab's counted wait and leaving its barrier
@@ -123,72 +122,14 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
   __builtin_amdgcn_s_barrier();
   if (tr) { t_first = wall_clock64(); c_first = __builtin_amdgcn_s_memtime(); }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
 
   // A fragments of the k-step being multiplied and of the one being read; W fragments in ONE buffer: block nb of the next k-step is read
   // into its own registers right behind the last group that multiplies with it (14 groups = ~900 cycles before its next use)
   bf16x8 xf[2][MB], wf[8];
   int sa = 0, ti = 0;   // ring slot of A_g (W_g sits in the next one); tile index
 
-  // ---- the tile's epilogue (gemm_pps_kernel's, for a BM/2 x 128 wave tile): accumulators -> (+ bias at start, activation) -> bf16 ->
-  //      buffer stores; re-arms the accumulators with the next tile's bias and rotates the source offsets ----
-  auto epilogue = [&]() {
-    long long t_e0 = 0;
-    if (tr) t_e0 = wall_clock64();
-    const int logical = ti * nblk + lbase;
-    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const long rows_left = (long)p.M - m0;
-    const unsigned long nbytes = (unsigned long)rows_left * p.ldc * 2;
-    const unsigned nrec = nbytes > 0xFFFFFFF0ul ? 0xFFFFFFF0u : (unsigned)nbytes;
-    char* cbase = (char*)p.C + (long)m0 * p.ldc * 2;
-    const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);
-    // this lane: rows 4 (lane >> 4) + r of every 16-row block of the wave, columns 8 (lane & 15) .. + 7 of the wave's 128
-    const unsigned off0 = (unsigned)((((long)(wm * (BM / 2) + 4 * (lane >> 4))) * p.ldc + n0 + wn * 128 + (lane & 15) * 8) * 2);
-    const unsigned row_pitch = (unsigned)(p.ldc * 2);
-    if (!no_epi) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        // the accumulators live in AGPRs and the conversions read VGPRs: without this anchor hipcc copies ALL of them to VGPRs at the top of
-        // the epilogue (256 registers at once -> hundreds of spills, and scratch traffic is VMEM traffic that breaks every counted vmcnt)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[j][mb]));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          bf16x8 o;
-          if constexpr (ACT == ACT_GELU) {
-            f32x2_t g[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = f32x2_t{acc[2 * j][mb][r], acc[2 * j + 1][mb][r]};
-            gelu_bf16x2_x4(g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              o[2 * j] = (bf16_t)g[j].x;
-              o[2 * j + 1] = (bf16_t)g[j].y;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j][mb][r];
-          }
-          // the row goes into the VECTOR offset (range check of a raw buffer; see gemm_pps_kernel for the soffset hazard)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, 16);
-          __builtin_amdgcn_sched_barrier(0);   // one row at a time: eight accumulator reads, their conversion, the store
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) asm volatile("" ::"v"(acc[i][j]));
-    }
-    asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3], bq[i >> 2][i & 3]};
+  // ---- a tile's end: the next tile index, and the finished tile's offset set re-pointed at the tile after next ----
+  auto tile_end = [&]() {
     ++ti;
     if (ti + 1 < my_tiles) {   // the finished tile's offset set now belongs to tile ti + 1 (same parity)
       unsigned na[GA], nw;
@@ -198,7 +139,6 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
       for (int i = 0; i < GA; ++i) { aofO[i] = into_odd ? na[i] : aofO[i]; aofE[i] = into_odd ? aofE[i] : na[i]; }
       wofO = into_odd ? nw : wofO; wofE = into_odd ? wofE : nw;
     }
-    if (tr) t_epi += wall_clock64() - t_e0;
   };
 
   // fragments of k-step ks of the slab whose A unit sits in ring slot `slot`
@@ -220,27 +160,110 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   // them to the accumulator registers, four copies per MFMA): MPG MFMAs on fragment buffer BUF, then the group's share of the OTHER
   // buffer's fragment reads (slot rs, k-step rks) and of the requests.  REQ: 0 none; 1 the A unit (odd groups); 2 the W unit (odd groups);
   // 3 the W unit in groups 0-7 and THEN an A unit in groups 8-15 (a tile's last k-step: all W pieces older than all A pieces)
-  auto kstep = [&](auto buf_c, auto req_c, auto rd_c, int rs, int rks, bool ev_a, const char* srcA, int slotA, bool ev_w, const char* srcW, int slotW) {
+  auto kstep = [&](auto buf_c, auto req_c, auto first_c, int rs, int rks, bool ev_a, const char* srcA, int slotA, bool ev_w, const char* srcW, int slotW) {
     constexpr int BUF = decltype(buf_c)::value, REQ = decltype(req_c)::value;
-    constexpr bool RD = decltype(rd_c)::value != 0;   // read the other buffer's fragments during this k-step
+    constexpr bool FIRST = decltype(first_c)::value != 0;   // a tile's first k-step: the accumulators START from the bias (the MFMA's C operand)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int nb = i >> 1, mb0 = (i & 1) * MPG;
+      if constexpr (FIRST) {
+        const float bv = bq[nb >> 2][nb & 3];
+        const f32x4 b4 = {bv, bv, bv, bv};
 #pragma unroll
-      for (int j = 0; j < MPG; ++j) acc[nb][mb0 + j] = SVT_MFMA_16x16x32(xf[BUF][mb0 + j], wf[nb], acc[nb][mb0 + j]);
-      if (RD && (i & 1)) read_w(rs, rks, nb);                 // block nb is done for this k-step: its registers take the next k-step's
-      if (RD && i < MB) read_x(rs, rks, BUF ^ 1, i);
+        for (int j = 0; j < MPG; ++j) acc[nb][mb0 + j] = SVT_MFMA_16x16x32(xf[BUF][mb0 + j], wf[nb], b4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < MPG; ++j) acc[nb][mb0 + j] = SVT_MFMA_16x16x32(xf[BUF][mb0 + j], wf[nb], acc[nb][mb0 + j]);
+      }
+      if (i & 1) read_w(rs, rks, nb);                 // block nb is done for this k-step: its registers take the next k-step's
+      if (i < MB) read_x(rs, rks, BUF ^ 1, i);
       if (REQ == 1 && (i & 1) && (i >> 1) < GA) p1_dma(ev_a ? aofE[i >> 1] : aofO[i >> 1], srcA, lds_unit(slotA, i >> 1));
       if (REQ == 2 && (i & 1) && (i >> 1) < GW) p1_dma(ev_w ? wofE : wofO, srcW + w_piece(i >> 1), lds_unit(slotW, i >> 1));
-      if (REQ == 3 && i < 8 && i < GW) p1_dma(ev_w ? wofE : wofO, srcW + w_piece(i), lds_unit(slotW, i));
-      if (REQ == 3 && i >= 8 && i - 8 < GA) p1_dma(ev_a ? aofE[i - 8] : aofO[i - 8], srcA, lds_unit(slotA, i - 8));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // A tile's LAST k-step, row block by row block: the 8 MFMAs of block mb finish its 16 rows x 128 columns, which are converted and stored
+  // while the matrix pipe works on block mb + 1 -- the epilogue runs INSIDE the stream (as its own phase it cost 2.6-4 us per tile: 256
+  // accumulator reads, their conversions and 32 stores per lane with no partner wave to multiply beside them).  The MFMA results of a block
+  // are taken in VGPRs (they are read by vector instructions next; the accumulators proper are not written again: the next tile starts from
+  // its bias).  Requests: W of the next tile's slab 1, then A of its slab 2 -- every W piece older than every A piece, NREQ per block --,
+  // the stores of a block at its end.  STORES_AFTER_W = stores issued behind the last W piece: with the A pieces they are what the next
+  // barrier's counted wait leaves in flight.
+  constexpr bool FIN_VGPR = !(BM == 256 && ACT == ACT_GELU);
+  constexpr int NREQ = (GW + GA + MB - 1) / MB;
+  constexpr int LAST_W_BLOCK = (GW - 1) / NREQ;                 // row block in which the last W piece is issued
+  constexpr int STORES_AFTER_W = (MB - LAST_W_BLOCK) * 4;       // that block's stores (issued at its end) and all later ones
+  auto kstep_last = [&](int rs, bool ev, const char* srcA, int slotA, const char* srcW, int slotW) {
+    const int logical = ti * nblk + lbase;
+    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long rows_left = (long)p.M - m0;
+    const unsigned long nbytes = (unsigned long)rows_left * p.ldc * 2;
+    const unsigned nrec = nbytes > 0xFFFFFFF0ul ? 0xFFFFFFF0u : (unsigned)nbytes;
+    char* cbase = (char*)p.C + (long)m0 * p.ldc * 2;
+    const auto crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, nrec, 0x00020000);   // rows >= M land beyond num_records and are dropped
+    // this lane: rows 4 (lane >> 4) + r of every 16-row block of the wave, columns 8 (lane & 15) .. + 7 of the wave's 128
+    const unsigned off0 = (unsigned)((((long)(wm * (BM / 2) + 4 * (lane >> 4))) * p.ldc + n0 + wn * 128 + (lane & 15) * 8) * 2);
+    const unsigned row_pitch = (unsigned)(p.ldc * 2);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      f32x4 fin[8];
+      if constexpr (FIN_VGPR) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) fin[nb] = SVT_MFMA_16x16x32(xf[1][mb], wf[nb], acc[nb][mb]);
+      } else {
+        // 256-row tiles with GELU: no 32 spare VGPRs beside the polynomial's temporaries -- the block's results stay in the accumulator
+        // registers and are read from there row by row (a spill would put the compiler's own vmcnt(0) waits into the stream)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) acc[nb][mb] = SVT_MFMA_16x16x32(xf[1][mb], wf[nb], acc[nb][mb]);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) asm volatile("" : "+a"(acc[nb][mb]));
+      }
+      read_x(rs, 0, 0, mb);                            // the next tile's first A fragments (buffer 0 is free in this k-step)
+#pragma unroll
+      for (int q = 0; q < NREQ; ++q) {
+        const int rq = mb * NREQ + q;                  // requests 0 .. GW - 1: W pieces; GW .. GW + GA - 1: A pieces
+        if (rq < GW) p1_dma(ev ? wofE : wofO, srcW + w_piece(rq), lds_unit(slotW, rq));
+        else if (rq < GW + GA) p1_dma(ev ? aofE[rq - GW] : aofO[rq - GW], srcA, lds_unit(slotA, rq - GW));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!no_epi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bf16x8 o;
+          if constexpr (ACT == ACT_GELU) {
+            f32x2_t g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = FIN_VGPR ? f32x2_t{fin[2 * j][r], fin[2 * j + 1][r]} : f32x2_t{acc[2 * j][mb][r], acc[2 * j + 1][mb][r]};
+            if constexpr (FIN_VGPR) {
+              gelu_bf16x2_x4(g);
+            } else {   // one pair at a time: a quarter of the polynomial's temporaries (the next row block's MFMAs fill the gaps of the chain)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { g[j] = gelu_bf16x2(g[j]); asm volatile("" : "+v"(g[j])); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              o[2 * j] = (bf16_t)g[j].x;
+              o[2 * j + 1] = (bf16_t)g[j].y;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(FIN_VGPR ? fin[j][r] : acc[j][mb][r]);
+          }
+          // the row goes into the VECTOR offset (range check of a raw buffer; see gemm_pps_kernel for the soffset hazard)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, 16);
+          if constexpr (ACT == ACT_GELU) __builtin_amdgcn_sched_barrier(0);   // one row's polynomial at a time (register pressure)
+        }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) { if constexpr (FIN_VGPR) asm volatile("" ::"v"(fin[nb])); else asm volatile("" ::"a"(acc[nb][mb])); }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   using c0 = std::integral_constant<int, 0>;
   using c1 = std::integral_constant<int, 1>;
   using c2 = std::integral_constant<int, 2>;
-  using c3 = std::integral_constant<int, 3>;
   auto slot_add = [](int s_, int d) { const int t = s_ + d; return t >= NSLOT ? t - NSLOT : t; };
   // barrier B_g with its counted wait (OUT = requests / stores that may stay in flight)
   auto mid_barrier = [&](auto out_c) {
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
     if (tr) c_wait += __builtin_amdgcn_s_memtime() - c0_;
   };
   using w_a = std::integral_constant<int, GA>;
-  using w_as = std::integral_constant<int, GA + MB * 4>;
+  using w_as = std::integral_constant<int, GA + STORES_AFTER_W>;
 
   // The stream, tile by tile.  Slab kt of tile ti (ring slot sa) requests, two slabs ahead, A (during k-step 0) and W (during k-step 1):
   // kt + 2 < nk -> this tile's slab kt + 2 (this parity's offsets), else the next tile's slab kt + 2 - nk (the other parity's).  The
@@ -262,18 +285,19 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   for (int t = 0; t < my_tiles; ++t) {
     const bool te = (ti & 1) == 0;   // this tile's offsets are the even set
     const bool first_tile = t == 0;
-    // ---- slab 0 ----
+    asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));   // this tile's bias: fetched a slab before the previous tile's end, covered by a counted wait since
+    // ---- slab 0: the accumulators start from the bias; the stream's very first slab issues its own A request ----
     {
       const char* sA = gA + 2L * (BK * 2);
       const char* sW = gW + 2L * (BK * 2);
-      if (first_tile) {   // the stream's very first slab issues its own A request
+      if (first_tile) {
         kstep(c0{}, c1{}, c1{}, sa, 1, te, sA, slot_add(sa, 4), te, sW, sa);
         mid_barrier(w_a{});
       } else {
         kstep(c0{}, c0{}, c1{}, sa, 1, te, sA, slot_add(sa, 4), te, sW, sa);
-        if (no_epi) mid_barrier(w_a{}); else mid_barrier(w_as{});
+        if (no_epi) mid_barrier(w_a{}); else mid_barrier(w_as{});   // (the previous tile's later stores stay in flight)
       }
-      kstep(c1{}, c2{}, c1{}, slot_add(sa, 2), 0, te, sA, 0, te, sW, sa);
+      kstep(c1{}, c2{}, c0{}, slot_add(sa, 2), 0, te, sA, 0, te, sW, sa);
       sa = slot_add(sa, 2);
     }
     // ---- slabs 1 .. nk - 2 ----
@@ -281,36 +305,38 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
       const bool cur2 = k + 2 < nk;
       const bool ev = cur2 == te;
       const long ko = (long)(cur2 ? k + 2 : k + 2 - nk) * (BK * 2);
-      kstep(c0{}, c1{}, c1{}, sa, 1, ev, gA + ko, slot_add(sa, 4), ev, gW + ko, sa);
+      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + ko, slot_add(sa, 4), ev, gW + ko, sa);
       mid_barrier(w_a{});
-      kstep(c1{}, c2{}, c1{}, slot_add(sa, 2), 0, ev, gA + ko, 0, ev, gW + ko, sa);
+      kstep(c1{}, c2{}, c0{}, slot_add(sa, 2), 0, ev, gA + ko, 0, ev, gW + ko, sa);
       sa = slot_add(sa, 2);
     }
-    // ---- slab nk - 1: its requests belong to the next tile's slab 1 (A, W) and -- in front of the stores -- slab 2 (A) ----
+    // ---- slab nk - 1: its requests belong to the next tile's slab 1 (A, W) and slab 2 (A); its second k-step carries the tile's epilogue ----
     {
       if (has_bias) {
-        // the NEXT tile's bias (the accumulators' initial value, taken at this tile's epilogue): fetched in front of this k-step's
-        // requests, so that the counted wait of the barrier -- which leaves only those requests in flight -- covers it
+        // the NEXT tile's bias: fetched in front of this k-step's requests, so that the counted wait of the barrier -- which leaves only
+        // those requests in flight -- covers it
         const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                      : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
       }
       const bool ev = !te;            // the other parity: the next tile
-      kstep(c0{}, c1{}, c1{}, sa, 1, ev, gA + 1L * (BK * 2), slot_add(sa, 4), ev, gW, sa);
+      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + 1L * (BK * 2), slot_add(sa, 4), ev, gW, sa);
       mid_barrier(w_a{});
-      // W of the next tile's slab 1 into A_g's slot; then A of the next tile's slab 2 into the slot behind it (W_g's: slot sa + 1 = the
-      // new first slab's sa' + 4) -- free as well behind this barrier
-      // (it also reads the next tile's first fragments: A and W of that slab were published by this slab's barrier)
-      kstep(c1{}, c3{}, c1{}, slot_add(sa, 2), 0, ev, gA + 2L * (BK * 2), slot_add(sa, 1), ev, gW + 1L * (BK * 2), sa);
+      long long t_e0 = 0;
+      if (tr) t_e0 = wall_clock64();
+      // W of the next tile's slab 1 into A_g's slot, A of its slab 2 into W_g's (= the new first slab's "two ahead" slot): both free behind
+      // this barrier; the next tile's first A fragments are read here too, its W fragments behind the k-step (their registers are in use)
+      kstep_last(slot_add(sa, 2), ev, gA + 2L * (BK * 2), slot_add(sa, 1), gW + 1L * (BK * 2), sa);
       sa = slot_add(sa, 2);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) read_w(sa, 0, nb);
+      if (tr) t_epi += wall_clock64() - t_e0;
     }
-    epilogue();
+    tile_end();
   }
-  // the surplus requests of the stream's tail must have landed before the workgroup gives its LDS back; the last epilogue's stores, younger,
-  // need not be waited for
   long long t_loop = 0;
   if (tr) t_loop = wall_clock64();
-  if (no_epi) p1_wait_vm<0>(); else p1_wait_vm<MB * 4>();
+  if (no_epi) p1_wait_vm<0>(); else p1_wait_vm<STORES_AFTER_W>();   // the surplus requests are older than these stores
   if (tr && lane == 0) {   // record layout of gemm_pps_kernel (tools/gemm_trace.py); waves 0 / 2 stand for its two wave groups
     if ((wave & 1) == 0) {
       long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 1)) * 8;
