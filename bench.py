@@ -413,6 +413,31 @@ def main():
             # shards with reduced statistics -> identical in the exact modes (tests/test_gpu_global_norm.py), bf16 rounds differently
             tol = 0.0 if not (args.global_norm and world > 1) else (1e-5 if args.precision != "bf16" else 0.5)
             verified = bool((gathered - ref_rows).abs().max().item() <= tol)
+        if not verified:   # which shards differ, and by how much (stderr: the JSON line stays the only thing on stdout)
+            for r_ in range(world):
+                a_, b_ = D.shard_bounds(n_total, r_, world)
+                d_ = (gathered[a_:b_].double() - ref_rows.reshape(gathered.shape)[a_:b_].double()).abs()
+                if d_.numel() and d_.max().item() > 0:
+                    print(f"[bench] rank {rank}: gathered rows of shard {r_} differ from the local recomputation: max {d_.max().item():.3e}, "
+                          f"{int((d_ > 0).sum())} of {d_.numel()} elements", file=sys.stderr)
+        if not verified and os.environ.get("SVT_VERIFY_DIAG") == "1":
+            # diagnostics of a failed verification: are this rank's host parameters / inputs those of the other ranks, and does a FRESH
+            # encoder object (new upload of the same parameters) reproduce this rank's result?
+            import hashlib
+            hp = hashlib.sha1()
+            for p_ in enc.model.state_dict().values():
+                hp.update(p_.detach().cpu().contiguous().numpy().tobytes())
+            fresh = S.HuggingFaceWav2Vec2(args.model, None, config=cfg, precision=args.precision, normalize_wav=True, seed=1986).to(dev)
+            a_, b_ = D.shard_bounds(n_total, 0, world)
+            fr_f = torch.empty((b_ - a_, T, 4), dtype=torch.int32, device=dev)
+            lf = fresh.forward_head(full[a_:b_], head, frames=fr_f)
+            lo_ = enc.forward_head(full[a_:b_], head, frames=fr_f)
+            l2 = encs[-1].forward_head(full[a_:b_], head, frames=fr_f)
+            torch.cuda.synchronize()
+            print(f"[bench] rank {rank} diag: params sha1 {hp.hexdigest()[:12]}  input sha1 {hashlib.sha1(full.cpu().numpy().tobytes()).hexdigest()[:12]}  "
+                  f"shard-0 logits sha1: lane-0 encoder {hashlib.sha1(lo_.cpu().numpy().tobytes()).hexdigest()[:12]}  last-lane encoder "
+                  f"{hashlib.sha1(l2.cpu().numpy().tobytes()).hexdigest()[:12]}  fresh encoder {hashlib.sha1(lf.cpu().numpy().tobytes()).hexdigest()[:12]}  "
+                  f"gathered shard 0 {hashlib.sha1(gathered[a_:b_].cpu().numpy().tobytes()).hexdigest()[:12]}", file=sys.stderr)
         flags = D.gather_floats(1.0 if verified else 0.0, world, dev)
         verified = all(f == 1.0 for f in flags)
         if args.global_norm and world > 1:

@@ -304,7 +304,9 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * the frame-resident direct convolution (1, default; conv3x3_c64.hip) or on the GEMM kernels (0), 24 = query: returns the number of
  * direct-convolution launches of this process so far (value ignored), 25 = timing-ablation bits of the direct convolution (DIAG builds),
  * 26 = stem + max-pool of the lip front-end as one persistent kernel (1, default) or as two kernels (0), 27 = stage 2's 1x1 stride-2
- * downsample inside conv1's product (1, default) or as its own product (0).
+ * downsample inside conv1's product (1, default) or as its own product (0), 28 = two-slot schedule of gemm_pps_kernel (0, default: four
+ * slots), 29 = gemm_p1w_kernel (one wave per SIMD) for the 16-bit products it measured faster on (1, default), everywhere (2) or never (0),
+ * 30 = gemm_p1x_kernel (the same loop for the split-operand products on pair rows; 1, default) or gemm_x3q_kernel (0).
  * Returns 0 (key 24: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);
 
@@ -328,6 +330,13 @@ int svt_debug_clock(int64_t* out_dev, int device, void* stream);
  * of the mapping: an out-of-bounds access by a kernel on that side faults instead of landing in a neighbour
  * (tests/test_gpu_guard.py runs the forward passes with weights, workspace and inputs placed this way). */
 int svt_debug_alloc(void** out, size_t bytes, int device);
+/* Diagnostics (tools/determinism_stress.py): byte offsets of the regions svt_encoder_forward* carves out of the caller's workspace for
+ * (batch, n_samples), in carve order -- 0 moments + ordered-sum scratch, 1 conv0 coefficients, 2 conv0 tables, 3 / 4 conv activations
+ * (ping-pong), 5 fp32 conv output (layer-norm extractors), 6 projection input, 7 hF, 8 preF, 9 layer input, 10 fp32 residual, 11 low half
+ * of the residual, 12 / 13 positional-conv operand / result, 14 QKV, 15 / 16 scores / probabilities (non-fused attention), 17 V transposed,
+ * 18 QKV planes (split modes), 19 attention output, 20 FFN hidden, 21 gate, 22 relative-position bias, 23 head dots, 24 total.  A region the
+ * configuration does not use has offset -1.  Writes min(n, 25) entries; returns the number written or a negative svt_status. */
+int svt_debug_encoder_layout(const svt_encoder* e, int32_t batch, int64_t n_samples, int64_t* offsets, int n);
 int svt_debug_free(void* p, int device);
 
 #ifdef __cplusplus

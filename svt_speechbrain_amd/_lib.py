@@ -110,6 +110,7 @@ SYMBOLS = {
                                       C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "svt_debug_set": (C.c_int, [C.c_int, C.c_int]),
     "svt_debug_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "svt_debug_encoder_layout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "svt_operand_type": (C.c_int, []),
     "svt_encoder_set_norm_reduce": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_int64]),
     "svt_frames_to_notes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_int32, C.c_int32,

@@ -144,6 +144,7 @@ struct DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
   DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
   int alloc(size_t n) {
+    if (p && bytes == n) return 0;   // a re-upload of the same tensor keeps its buffer (no free / allocate pair: see upload_operand)
     release();
     bytes = n;
     return dev_alloc(&p, n);
@@ -157,12 +158,30 @@ static int upload_f32(DevBuf& b, const float* h, size_t n) {
   SVT_HIP(hipMemcpy(b.p, h, n * 4, hipMemcpyHostToDevice));
   return 0;
 }
+// fp32 staging of the 16-bit uploads: ONE grow-only buffer per device, kept for the life of the process.  Round 4 used a temporary per
+// tensor (~75 hipMalloc / hipFree pairs per encoder object).  With eight processes uploading to one GPU at the same time that corrupted
+// the weights of 12 of 1 152 objects (tools/determinism_stress.py --encoders 24 --procs 8: an object whose logits are off by O(1) for
+// its whole life; seen first as a rank of `bench.py --gpus 8 --verify` on a shared GPU disagreeing with the other seven); with the
+// staging buffer kept: 0 of 1 152.  An address range handed back by hipFree and out again by the next hipMalloc is, on this stack under
+// that load, not always the same memory for the kernel that runs next (the guard allocator above met the same thing with the
+// virtual-memory API).  Rule for this file: no free / allocate pair on a path that launches kernels -- buffers are kept and reused.
+static std::mutex g_stage_mu;
+static std::map<int, std::pair<void*, size_t>> g_stage;
 static int upload_operand(int prec, DevBuf& b, const float* h, size_t n) {
   if (!prec) return upload_f32(b, h, n);
-  DevBuf tmp;
-  if (int r = upload_f32(tmp, h, n)) return r;
+  int dev = 0;
+  SVT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_stage_mu);   // (held over the synchronous conversion: uploads are not a concurrent path)
+  auto& st = g_stage[dev];
+  if (st.second < n * 4) {
+    if (st.first) { SVT_HIP(hipDeviceSynchronize()); dev_free(st.first); st.first = nullptr; st.second = 0; }
+    const size_t want = std::max(n * 4, (size_t)32 << 20);
+    if (int r = dev_alloc(&st.first, want)) return r;
+    st.second = want;
+  }
+  SVT_HIP(hipMemcpy(st.first, h, n * 4, hipMemcpyHostToDevice));
   if (int r = b.alloc(n * 2)) return r;
-  if (int r = launch_f32_to_bf16(tmp.as<float>(), b.as<bf16_t>(), (int64_t)n, 0)) return r;
+  if (int r = launch_f32_to_bf16((const float*)st.first, b.as<bf16_t>(), (int64_t)n, 0)) return r;
   SVT_HIP(hipDeviceSynchronize());
   return 0;
 }
@@ -485,6 +504,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 16) g_pps_half_barriers = value;
   else if (key == 28) g_pps_two_slots = value;
   else if (key == 29) g_gemm_p1w = value;
+  else if (key == 30) g_gemm_p1x = value;
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
@@ -601,8 +621,7 @@ int svt_encoder_finalize(svt_encoder* e) {
   const int prec = storage_prec(c.precision);
   const ParamMap& P = e->params;
   const Param* p = nullptr;
-  e->conv.clear();
-  e->conv.resize(c.num_conv_layers);
+  if ((int)e->conv.size() != c.num_conv_layers) { e->conv.clear(); e->conv.resize(c.num_conv_layers); }   // a re-upload keeps the buffers
   int cin = c.num_conv_layers == 0 ? c.conv_dim[0] : 1;  // features-in mode: the projection reads the given features
   for (int i = 0; i < c.num_conv_layers; ++i) {
     const std::string pre = "feature_extractor.conv_layers." + std::to_string(i) + ".";
@@ -649,8 +668,7 @@ int svt_encoder_finalize(svt_encoder* e) {
     // data2vec-audio: plain grouped convs "encoder.pos_conv_embed.layers.<i>.conv.{weight,bias}", (D, cg, kp) -> per group
     // (cg_out, kp*cg_in) tap-major like the single-layer form
     const int kp = c.pos_conv_kernel, G = c.pos_conv_groups, cg = D / G;
-    e->pos_ws.clear(); e->pos_bs.clear();
-    e->pos_ws.resize(c.pos_conv_depth); e->pos_bs.resize(c.pos_conv_depth);
+    if ((int)e->pos_ws.size() != c.pos_conv_depth) { e->pos_ws.clear(); e->pos_bs.clear(); e->pos_ws.resize(c.pos_conv_depth); e->pos_bs.resize(c.pos_conv_depth); }
     for (int i = 0; i < c.pos_conv_depth; ++i) {
       const std::string pl = "encoder.pos_conv_embed.layers." + std::to_string(i) + ".conv.";
       if (int r = need(P, pl + "weight", {D, cg, kp}, &p)) return r;
@@ -743,8 +761,7 @@ int svt_encoder_finalize(svt_encoder* e) {
   if (int r = need(P, "encoder.layer_norm.bias", {D}, &p)) return r;
   if (int r = upload_f32(e->enc_b, p->v.data(), p->v.size())) return r;
 
-  e->layers.clear();
-  e->layers.resize(c.num_layers);
+  if ((int)e->layers.size() != c.num_layers) { e->layers.clear(); e->layers.resize(c.num_layers); }
   for (int l = 0; l < c.num_layers; ++l) {
     const std::string pre = "encoder.layers." + std::to_string(l) + ".";
     EncLayerW& L = e->layers[l];
@@ -821,6 +838,8 @@ namespace {
 struct EncWs {
   double* mom;      // [0..1] wav, [2..3] out, [4 ..] window moments B*65
   size_t mom_bytes;
+  size_t mom_scr[4];  // byte offsets in mom of the ordered sums' scratch: waveform moments, output moments, conv0 window moments, fused tail
+  size_t mom_zero;    // leading bytes of mom a forward zeroes (statistics + every ticket)
   float* coef;
   void* c0tab;      // conv layer 0 on the matrix pipe: weight-side tables (32 KiB per clip), 16-bit modes
   void* act[2];
@@ -849,7 +868,19 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   const size_t es = esize(sp);
   Carver cv(base);
   EncWs w;
-  w.mom_bytes = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments
+  // 2 x (sum, sumsq) per norm group (<= B groups) + conv0 window moments, then the scratch of the three ordered sums (tickets + per-workgroup
+  // partials: kernels.hip, last_workgroup); the whole region is zeroed at the start of every forward (the tickets must be)
+  {
+    const int64_t t1 = c.num_conv_layers > 0 ? (L - c.conv_kernel[0]) / c.conv_stride[0] + 1 : 1;
+    w.mom_scr[0] = align_up((4 * (size_t)B + (size_t)B * 65) * sizeof(double));
+    w.mom_scr[1] = w.mom_scr[0] + align_up(moments_scratch_bytes(B));
+    w.mom_scr[2] = w.mom_scr[1] + align_up(moments_scratch_bytes(B));
+    w.mom_scr[3] = w.mom_scr[2] + align_up(conv0_window_moments_scratch_bytes(B, t1 > 0 ? t1 : 1));
+    w.mom_zero = w.mom_scr[3] + 256;   // ... up to and including the fused tail's ticket: what a forward zeroes
+    int64_t t = L;
+    for (int i = 0; i < c.num_conv_layers; ++i) t = (t - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+    w.mom_bytes = w.mom_scr[3] + align_up(head_scratch_bytes((int64_t)B * (t > 0 ? t : 1), B));
+  }
   w.mom = (double*)cv.take(w.mom_bytes);
   w.coef = (float*)cv.take((size_t)B * c.conv_dim[0] * 11 * 4);
   w.c0tab = (sp || c.precision >= 2) ? cv.take(conv0_mfma_table_bytes(B)) : nullptr;
@@ -902,6 +933,19 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
 }  // namespace
 
 extern "C" {
+
+int svt_debug_encoder_layout(const svt_encoder* e, int32_t batch, int64_t n_samples, int64_t* offsets, int n) {
+  if (!e || batch < 1 || !offsets || n < 1) { set_error("svt_debug_encoder_layout: bad argument"); return SVT_ERR_INVALID; }
+  if (svt_encoder_num_frames(e, n_samples) < 1) { set_error("waveform shorter than the receptive field"); return SVT_ERR_INVALID; }
+  char* const fake = (char*)(uintptr_t)(1ull << 40);   // never dereferenced: carve_encoder only adds offsets to it
+  const EncWs w = carve_encoder(e, batch, n_samples, fake);
+  const void* r[24] = {w.mom, w.coef, w.c0tab, w.act[0], w.act[1], w.convF, w.xln, w.hF, w.preF, w.xb, w.xF, w.xlo, w.posg, w.posy, w.qkv,
+                       w.ab.S, w.ab.P, w.ab.Vt, w.ab.pl_qkv, w.attn_o, w.ffn, w.gate, w.relpb, w.dots};
+  int k = 0;
+  for (; k < 24 && k < n; ++k) offsets[k] = r[k] == nullptr ? -1 : (int64_t)((const char*)r[k] - fake);
+  if (k < n) offsets[k++] = (int64_t)w.total;
+  return k;
+}
 
 int64_t svt_encoder_workspace_bytes(const svt_encoder* e, int32_t batch, int64_t n_samples) {
   if (!e || batch < 1) { set_error("workspace_bytes: bad argument"); return -1; }
@@ -985,13 +1029,13 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     set_error("encoder_forward: features-in mode has no input norm to group");
     return SVT_ERR_INVALID;
   }
-  SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_bytes, s));
+  SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_zero, s));
   double* wav_mom = c.normalize_wav ? w.mom : nullptr;
   double* out_mom = w.mom + 2 * (size_t)B;
   double* wm = w.mom + 4 * (size_t)B;
   int64_t n_wav = (int64_t)cpg * L;
   if (c.normalize_wav)
-    if (int r = launch_moments(wav, n_wav, wav_mom, s, groups)) return r;
+    if (int r = launch_moments(wav, n_wav, wav_mom, (char*)w.mom + w.mom_scr[0], B, s, groups)) return r;
   // "global-batch-equivalent" norms (optional): the batch is a shard of a larger one; the caller's function sums the
   // (sum, sum of squares) pair over the ranks -- 16 bytes per norm -- and the statistics are then those of the whole global batch
   struct ReduceCtx { svt_encoder* e; double* mom; hipStream_t s; } rctx{e, nullptr, s};
@@ -1051,7 +1095,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
   int64_t t1 = (L - c.conv_kernel[0]) / c.conv_stride[0] + 1;
   const ConvLayerW& c0 = e->conv[0];
   if (c.feat_extract_norm == SVT_NORM_GROUP) {
-    if (int r = launch_conv0_window_moments(wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, wm, s)) return r;
+    if (int r = launch_conv0_window_moments(wav, B, L, c.conv_kernel[0], c.conv_stride[0], t1, wm, (char*)w.mom + w.mom_scr[2], s)) return r;
     if (int r = launch_conv0_group_coef(wav_mom, n_wav, wm, B, t1, c.conv_dim[0], c.conv_kernel[0], c0.w.as<float>(),
                                         c.conv_bias ? c0.bias.as<float>() : nullptr, c0.gamma.as<float>(),
                                         c0.beta.as<float>(), 1e-5f, 1e-5f, w.coef, s, cpg)) return r;
@@ -1350,11 +1394,12 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     if (launch_head_fused(final_x, rows, D, tail.head->w.as<float>(), tail.head->wsum.as<float>(),
                           tail.head->has_bias ? tail.head->b.as<float>() : nullptr, tail.head->out_f, w.dots,
                           c.output_norm ? out_mom : nullptr, rows / groups, 1e-5f, tail.logits, (FrameOut*)tail.frames, tail.n_oct,
-                          tail.n_cls, s, n_out_stat, global_norm && c.output_norm ? +reduce_now : nullptr, &rctx)) return SVT_ERR_HIP;
+                          tail.n_cls, s, n_out_stat, global_norm && c.output_norm ? +reduce_now : nullptr, &rctx,
+                          (char*)w.mom + w.mom_scr[3])) return SVT_ERR_HIP;
     return SVT_OK;
   }
   if (c.output_norm) {
-    if (int r = launch_moments(final_x, n_out / groups, out_mom, s, groups)) return r;
+    if (int r = launch_moments(final_x, n_out / groups, out_mom, (char*)w.mom + w.mom_scr[1], B, s, groups)) return r;
     if (global_norm) { if (int r = reduce_now(&rctx)) return r; }
     if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups, n_out_stat)) return r;
   } else {

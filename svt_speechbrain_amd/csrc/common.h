@@ -259,6 +259,8 @@ int launch_gemm_x3p(int kind, const GemmArgs& a, const void* packed, hipStream_t
 // both operands pre-cut (pair rows): the schedule of gemm_pps_kernel with three MFMAs per block (gemm_x3q.hip)
 bool gemm_x3q_eligible(const GemmArgs& a);
 int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);
+int launch_gemm_p1x(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);   // gemm_p1x.hip: the same product, one wave per SIMD (K >= 96)
+extern int g_gemm_p1x;   // svt_debug_set key 30
 extern int g_x3_pairs;  // 1 (default): the split modes keep product operands as pair rows; 0: fp32 activations cut inside the product kernels (svt_debug_set key 19)
 extern int g_ln_two_rows;  // (hi, lo) LayerNorm: half a wave per row, 16-byte accesses (1, default) or a wave per row (0)
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
@@ -296,8 +298,10 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // fp32 <-> pair rows (GemmArgs::a_pairs); lo_plane != nullptr: `in` / `lo_plane` are separate (hi, lo) planes instead
 int launch_f32_to_pairs(int kind, const float* x, void* out, int64_t n, hipStream_t s);
 int launch_pairs_to_f32(int kind, const void* in, const void* lo_plane, float* y, int64_t n, hipStream_t s);
-// moments[0] += sum(x), moments[1] += sum(x^2) over n fp32 values (fp64 accumulation); caller zeroes moments
-int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
+// moments[0] = sum(x), moments[1] = sum(x^2) over n fp32 values (fp64 accumulation, workgroup partials added in a fixed order: the
+// result is reproducible bit for bit); scratch = moments_scratch_bytes(groups_max) bytes whose first 4 * groups_max bytes are ZERO
+int launch_moments(const float* x, int64_t n, double* moments, void* scratch, int groups_max, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
+size_t moments_scratch_bytes(int groups_max);
 // y = (x - mean) * rsqrt(var + eps) from global moments over n elements (no affine)
 int launch_global_norm(const float* x, float* y, int64_t n, const double* moments, float eps, hipStream_t s, int groups = 1,
                        double n_stat = 0);  // n_stat > 0: the moments were summed over n_stat elements (cross-rank reduction), not n
@@ -313,7 +317,8 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
 
 // conv layer 0 (Cin = 1) in "group" mode: per-(clip,channel) GroupNorm folded into 11 coefficients
 int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1,
-                                double* wm /*B x 65*/, hipStream_t s);
+                                double* wm /*B x 65*/, void* scratch /*conv0_window_moments_scratch_bytes; first 4 B bytes ZERO*/, hipStream_t s);
+size_t conv0_window_moments_scratch_bytes(int B, int64_t T1);
 int launch_conv0_group_coef(const double* wav_moments /*2, or null*/, int64_t n_wav, const double* wm, int B,
                             int64_t T1, int C, int k, const float* w0 /*C x k*/, const float* b0 /*C or null*/,
                             const float* gamma, const float* beta, float eps_wav, float eps_gn,
@@ -417,11 +422,13 @@ bool linear_head_eligible(int K, int N);
 int launch_linear_head(const float* x, int64_t rows, int K, const float* w, const float* b, int N, float* y, hipStream_t s);
 struct FrameOut { float p_on, p_off; int32_t octave, pitch_class; };
 // fused tail: whole-batch output norm (moments taken in the same pass) + frame head + optional per-frame decode, from the
-// UN-normalised encoder output x (rows x K); dots = rows x N scratch; mom = 2 doubles per norm group (zeroed) or null
+// UN-normalised encoder output x (rows x K); dots = rows x N scratch; mom = 2 doubles per norm group (written, reproducible bit for
+// bit) or null; scratch (needed with mom) = head_scratch_bytes(rows, groups) bytes whose first 4 are ZERO
 int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
                       double* mom, int64_t rows_per_group, float eps, float* logits, FrameOut* frames, int n_oct, int n_cls,
                       hipStream_t s,
-                      double n_stat = 0, int (*between)(void*) = nullptr, void* between_arg = nullptr);
+                      double n_stat = 0, int (*between)(void*) = nullptr, void* between_arg = nullptr, void* scratch = nullptr);
+size_t head_scratch_bytes(int64_t rows, int groups_max);
 int launch_decode_frames(const float* logits, int64_t rows, int n_out, int n_oct, int n_cls, FrameOut* out,
                          hipStream_t s);
 int launch_ctc_greedy(const float* probs, int B, int T, int V, const float* rel_lens, int blank, int32_t* tokens,

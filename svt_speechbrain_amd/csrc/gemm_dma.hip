@@ -1132,14 +1132,22 @@ int split_weights_register(const void* w_f32, long n_rows, int K, int kind, hipS
   if (kind != 2 && kind != 3) return 0;
   if (K % 32 || n_rows < 1) return 0;   // K tails stay on the register-staged split kernel
   void* packed = nullptr;
-  if (int r = dev_alloc(&packed, (size_t)n_rows * K * 4)) return r;
+  {
+    // a re-upload of the same matrix packs into the buffer it already has (no free / allocate pair beside kernels: api.hip, upload_operand)
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_w.find(w_f32);
+    if (it != g_split_w.end() && it->second.N == (int)n_rows && it->second.K == K) packed = it->second.packed;
+  }
+  const bool reused = packed != nullptr;
+  if (!reused)
+    if (int r = dev_alloc(&packed, (size_t)n_rows * K * 4)) return r;
   const long pieces = n_rows * (K / 8);
   if (kind == 3) hipLaunchKernelGGL((split_pack_kernel<true>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
   else hipLaunchKernelGGL((split_pack_kernel<false>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, (const float*)w_f32, n_rows, K, (unsigned short*)packed);
   SVT_LAUNCH_CHECK();
   std::lock_guard<std::mutex> lk(g_split_mu);
   auto it = g_split_w.find(w_f32);
-  if (it != g_split_w.end()) dev_free(it->second.packed);
+  if (it != g_split_w.end() && !reused) dev_free(it->second.packed);
   g_split_w[w_f32] = SplitW{packed, (int)n_rows, K, kind};
   return 0;
 }
@@ -1185,7 +1193,8 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
     prof_begin(s);
-    if (int r_ = launch_gemm_x3q(kind, g, packed, best, s)) return r_;
+    if (g_gemm_p1x && g.K >= 96) { if (int r_ = launch_gemm_p1x(kind, g, packed, best, s)) return r_; }   // one wave per SIMD (gemm_p1x.hip; svt_debug_set key 30)
+    else if (int r_ = launch_gemm_x3q(kind, g, packed, best, s)) return r_;
     prof_end(s, flops, bytes, 0);
     return 0;
   }

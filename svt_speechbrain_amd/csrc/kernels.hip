@@ -20,6 +20,32 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- sums over the workgroups of a launch, reproducible bit for bit ----
+// fp64 atomicAdd gives a sum whose last bits depend on the order in which the workgroups arrive.  Harmless for a mean, but conv layer 0's
+// GroupNorm variance is a quadratic form of the window moments with heavy cancellation (low-pass audio against random filters: 1e3-1e5),
+// so a changed last bit of a moment flips the last bit of an fp32 coefficient about once per hundred forwards, and one flipped bf16
+// rounding downstream moves every logit by ~1e-4 -- seen as soon as eight processes shared one GPU (tests/test_gpu_bench_two_ranks.py).
+// Instead every workgroup stores its partial sums and takes a ticket; the one that draws the last ticket adds the partials in workgroup
+// order and writes the result (no zeroed accumulator needed; the ticket must be 0 at launch and is put back to 0).
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_groups) {
+  __shared__ unsigned s_last;
+  __threadfence();   // this thread's partials are visible device-wide (across XCDs) before the ticket is taken
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == n_groups - 1 ? 1u : 0u;
+    if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __threadfence();
+  return last;
+}
+// a partial written by another workgroup (possibly on another XCD): read past the non-coherent caches
+__device__ __forceinline__ double ld_partial(const double* p) {
+  return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 template <typename T> __device__ __forceinline__ float ld(const T* p, long i);
 template <> __device__ __forceinline__ float ld<float>(const float* p, long i) { return p[i]; }
 template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p, long i) { return (float)p[i]; }
@@ -63,11 +89,13 @@ __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, int64_t n) {
 }
 
 // sum / sum of squares in fp64 (two whole-batch layer norms of the wrapper)
-// blockIdx.y = norm group: group g covers x[g*n, (g+1)*n) and accumulates into mom[2g], mom[2g+1]
-__global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n, double* mom) {
+// blockIdx.y = norm group: group g covers x[g*n, (g+1)*n) and WRITES mom[2g], mom[2g+1] (the last workgroup of the group adds the
+// per-workgroup partials `part[(g * gridDim.x + block) * 2 ..]` in block order: last_workgroup above)
+__global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n, double* mom, double* part, unsigned* ticket) {
   __shared__ double sh[2][4];
   x += (int64_t)blockIdx.y * n;
   mom += 2 * blockIdx.y;
+  part += (size_t)blockIdx.y * gridDim.x * 2;
   double s = 0.0, ss = 0.0;
   const int64_t n4 = n >> 2;
   const float4* x4 = (const float4*)x;
@@ -90,8 +118,19 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n,
   if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&mom[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomicAdd(&mom[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    part[blockIdx.x * 2] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    part[blockIdx.x * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+  if (!last_workgroup(ticket + blockIdx.y, gridDim.x)) return;
+  s = 0.0; ss = 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) { s += ld_partial(part + b * 2); ss += ld_partial(part + b * 2 + 1); }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mom[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    mom[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
 
@@ -429,7 +468,7 @@ constexpr int K0 = 10;
 constexpr int NWM = K0 + K0 * (K0 + 1) / 2;  // 65
 
 __global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* wav, int64_t L, int stride, int64_t T1,
-                                                                   double* wm) {
+                                                                   double* wm, double* part, unsigned* ticket) {
   __shared__ double sh[4][NWM];
   const int b = blockIdx.y;
   const float* x = wav + (int64_t)b * L;
@@ -459,9 +498,16 @@ __global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* 
     if (lane == 0) sh[wave][i] = r;
   }
   __syncthreads();
+  // per-workgroup partials, added in workgroup order by the clip's last workgroup (last_workgroup above): wm is written, not accumulated
+  part += (size_t)b * gridDim.x * NWM;
   if (threadIdx.x < NWM)
-    atomicAdd(&wm[b * NWM + threadIdx.x],
-              sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    part[blockIdx.x * NWM + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (!last_workgroup(ticket + b, gridDim.x)) return;
+  if (threadIdx.x < NWM) {
+    double t = 0.0;
+    for (unsigned k = 0; k < gridDim.x; ++k) t += ld_partial(part + k * NWM + threadIdx.x);
+    wm[b * NWM + threadIdx.x] = t;
+  }
 }
 
 __global__ void conv0_group_coef_kernel(const double* wav_mom, int64_t n_wav, const double* wm, int64_t T1, int C,
@@ -885,7 +931,8 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const float* __restric
 // at 32 x 10 s) by one read.
 template <int KC>
 __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict__ x, int64_t rows, const float* __restrict__ w, int N,
-                                                        float* __restrict__ dots, double* __restrict__ mom, int64_t rows_per_group) {
+                                                        float* __restrict__ dots, double* __restrict__ mom, int64_t rows_per_group,
+                                                        double* __restrict__ slots, unsigned* __restrict__ ticket, int slots_per_group) {
   constexpr int K = KC * 256;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   for (int i = threadIdx.x * 4; i < N * K; i += 1024) *(float4*)(wl + i) = *(const float4*)(w + i);
@@ -893,14 +940,25 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
   const int myrow = (hi32 ? 2 : 0) + (hi16 ? 1 : 0);
-  // per-lane running (sum, sum of squares) of the norm group this wave is in: folded across the wave and flushed with two fp64
-  // atomics only when the wave's rows cross into another group (and at the end) -- no shuffles and no division per row
+  // per-lane running (sum, sum of squares) of the norm group this wave is in: folded across the wave and stored when the wave's rows
+  // cross into another group (and at the end) -- no shuffles and no division per row.  The statistics are reproducible bit for bit
+  // (last_workgroup above): wave W = 4 blockIdx.x + wave owns the 4-row chunks W, W + NW, W + 2 NW ... (NW = waves of the launch), so the
+  // waves that meet norm group g are those of the chunks ja = first row of g / 4 ... jb = last row of g / 4, taken modulo NW; a wave stores
+  // its (sum, sum of squares) for g ONCE, in slot (g, (W - ja) mod NW) -- every slot 0 .. min(NW, jb - ja + 1) - 1 of a group is written by
+  // exactly one wave, none needs zeroing -- and the launch's last workgroup adds each group's slots in slot order.
+  const int NW = (int)gridDim.x * 4, W = (int)blockIdx.x * 4 + wave;
   int64_t cur_g = -1, g_end = 0;
   float la = 0.f, lq = 0.f;
   auto flush = [&]() {
     if (cur_g < 0) return;
     const double sa = wave_sum((double)la), sq = wave_sum((double)lq);
-    if (lane == 0) { atomicAdd(&mom[2 * cur_g], sa); atomicAdd(&mom[2 * cur_g + 1], sq); }
+    if (lane == 0) {
+      const int64_t ja = (cur_g * rows_per_group) >> 2;
+      const int p = (int)(((W - ja) % NW + NW) % NW);
+      double* sl = slots + ((size_t)cur_g * slots_per_group + p) * 2;
+      sl[0] = sa;
+      sl[1] = sq;
+    }
     la = 0.f; lq = 0.f;
   };
   for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
@@ -908,8 +966,20 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int64_t row = r0 + rr < rows ? r0 + rr : rows - 1;
+      // 16-byte loads the compiler cannot take apart (raw buffer loads).  Round 4 wrote `*(const float4*)`; hipcc split the first chunk of
+      // every row into an OVERLAPPING pair -- global_load_dwordx3 at byte 4 + global_load_dwordx2 at byte 0 -- and placed its own counted
+      // `s_waitcnt vmcnt(14 / 13 / 12 ...)` in front of the packed squares.  With other processes loading the same GPU the sum of squares
+      // then came out short by 12-35 elements' worth in ~0.15 % of the forwards (sum and dots intact; every logit moved by 2e-4 .. 1e-3
+      // through the output norm): tools/determinism_stress.py, 10 of 6 400 forwards.  Three rebuilds, 6 400 forwards each, all clean: a
+      // full wait in front of the statistics; scalar FMAs; and this one -- the same packed arithmetic and the same counted waits behind
+      // UNSPLIT loads.  So the counted wait is not safe behind that split pair on this chip; tests/test_build_isa.py keeps such pairs out.
+      const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
-      for (int c = 0; c < KC; ++c) xv[rr][c] = *(const float4*)(x + row * K + c * 256 + lane * 4);
+      for (int c = 0; c < KC; ++c) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v t = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (unsigned)((row * K + c * 256 + lane * 4) * 4), 0, 0));
+        xv[rr][c] = float4{t[0], t[1], t[2], t[3]};
+      }
     }
     if (mom) {
 #pragma unroll
@@ -963,24 +1033,20 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
     }
   }
   if (mom) {
-    // end of the sweep: the four waves of a workgroup are (almost always) in the same norm group -- fold them through LDS so
-    // that the two fp64 atomics are issued once per workgroup, not once per wave (2 048 same-address atomics serialise at
-    // the memory side: measured 75 us for this kernel against 29 us for the head alone)
-    const double sa = wave_sum((double)la), sq = wave_sum((double)lq);
-    __syncthreads();  // everyone is done with the weights in LDS
-    double* red = (double*)wl;
-    if (lane == 0) { red[wave * 3] = (double)cur_g; red[wave * 3 + 1] = sa; red[wave * 3 + 2] = sq; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < 4; ++i) {
-        const long g = (long)red[i * 3];
-        if (g < 0) continue;
-        double ta = red[i * 3 + 1], tq = red[i * 3 + 2];
-        for (int j = i + 1; j < 4; ++j)
-          if ((long)red[j * 3] == g) { ta += red[j * 3 + 1]; tq += red[j * 3 + 2]; red[j * 3] = -1.0; }
-        atomicAdd(&mom[2 * g], ta);
-        atomicAdd(&mom[2 * g + 1], tq);
-      }
+    flush();
+    if (!last_workgroup(ticket, gridDim.x)) return;
+    // the last workgroup: group g's slots in slot order, one wave per group (lane-strided partial sums, then the shuffle tree: a fixed shape)
+    const int64_t n_groups = (rows + rows_per_group - 1) / rows_per_group;
+    for (int64_t g = wave; g < n_groups; g += 4) {
+      const int64_t a = g * rows_per_group, b = (g + 1) * rows_per_group < rows ? (g + 1) * rows_per_group : rows;
+      const int64_t nj = ((b - 1) >> 2) - (a >> 2) + 1;
+      const int n = (int)(nj < NW ? nj : NW);
+      const double* sl = slots + (size_t)g * slots_per_group * 2;
+      double ta = 0.0, tq = 0.0;
+      for (int i = lane; i < n; i += 64) { ta += ld_partial(sl + 2 * i); tq += ld_partial(sl + 2 * i + 1); }
+      ta = wave_sum(ta);
+      tq = wave_sum(tq);
+      if (lane == 0) { mom[2 * g] = ta; mom[2 * g + 1] = tq; }
     }
   }
 }
@@ -1448,10 +1514,25 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
   return 0;
 }
 
-int launch_moments(const float* x, int64_t n, double* moments, hipStream_t s, int groups) {
+// scratch of one launch_moments call over at most `groups_max` groups: a ticket per group, then two fp64 partials per workgroup
+static int moments_grid(int64_t n, int groups) {
+  return groups > 1 ? grid_for(n / 4 + 1, 256, 512 / (groups < 64 ? groups : 64) + 1) : grid_for(n / 4 + 1, 256, 512);
+}
+static size_t moments_ticket_bytes(int groups) { return ((size_t)groups * 4 + 255) & ~(size_t)255; }
+size_t moments_scratch_bytes(int groups_max) {
+  // groups < 64: groups * (512 / groups + 1) <= 512 + groups workgroups; otherwise 9 per group
+  const size_t wgs = (size_t)(groups_max < 64 ? 512 + groups_max : 576) + 9 * (size_t)groups_max;
+  return moments_ticket_bytes(groups_max) + wgs * 2 * sizeof(double);
+}
+
+int launch_moments(const float* x, int64_t n, double* moments, void* scratch, int groups_max, hipStream_t s, int groups) {
   if (groups > 1 && (n & 3)) { set_error("moments: per-group length must be a multiple of 4 elements"); return -1; }
-  const int gx = groups > 1 ? grid_for(n / 4 + 1, 256, 512 / (groups < 64 ? groups : 64) + 1) : grid_for(n / 4 + 1, 256, 512);
-  hipLaunchKernelGGL(moments_kernel, dim3(gx, groups), dim3(256), 0, s, x, n, moments);
+  if (groups > groups_max || !scratch || ((uintptr_t)scratch & 7)) { set_error("moments: scratch"); return -1; }
+  const int gx = moments_grid(n, groups);
+  if (moments_ticket_bytes(groups_max) + (size_t)gx * groups * 2 * sizeof(double) > moments_scratch_bytes(groups_max)) { set_error("moments: scratch too small"); return -1; }
+  unsigned* ticket = (unsigned*)scratch;
+  double* part = (double*)((char*)scratch + moments_ticket_bytes(groups_max));
+  hipLaunchKernelGGL(moments_kernel, dim3(gx, groups), dim3(256), 0, s, x, n, moments, part, ticket);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -1579,12 +1660,21 @@ int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* 
   return 0;
 }
 
-int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1, double* wm,
+// scratch: a ticket per clip, then 65 fp64 partials per workgroup
+size_t conv0_window_moments_scratch_bytes(int B, int64_t T1) {
+  const size_t gx = (size_t)((T1 + 2047) / 2048);
+  return moments_ticket_bytes(B) + (size_t)B * gx * NWM * sizeof(double);
+}
+
+int launch_conv0_window_moments(const float* wav, int B, int64_t L, int k, int stride, int64_t T1, double* wm, void* scratch,
                                 hipStream_t s) {
   if (k != K0) { set_error("conv layer 0 kernel size must be 10"); return -1; }
+  if (!scratch || ((uintptr_t)scratch & 7)) { set_error("conv0 window moments: scratch"); return -1; }
   const int per_block = 256 * 8;
   dim3 grid((unsigned)((T1 + per_block - 1) / per_block), B);
-  hipLaunchKernelGGL(conv0_window_moments_kernel, grid, dim3(256), 0, s, wav, L, stride, T1, wm);
+  unsigned* ticket = (unsigned*)scratch;
+  double* part = (double*)((char*)scratch + moments_ticket_bytes(B));
+  hipLaunchKernelGGL(conv0_window_moments_kernel, grid, dim3(256), 0, s, wav, L, stride, T1, wm, part, ticket);
   SVT_LAUNCH_CHECK();
   return 0;
 }
@@ -1765,24 +1855,49 @@ int launch_linear_head(const float* x, int64_t rows, int K, const float* w, cons
   return -1;
 }
 
+static unsigned head_dots_grid(int64_t rows) {
+  const int64_t blocks = (rows + 15) / 16;
+  return (unsigned)(blocks < 512 ? blocks : 512);
+}
+// scratch of the output-norm statistics (head_dots_kernel): a ticket, then one (sum, sum of squares) slot per wave and norm group it meets:
+// at most rows / 4 + 2 slots per group, never more than the launch has waves
+static int head_slots_per_group(int64_t rows, int64_t rpg) {
+  const int64_t nw = (int64_t)head_dots_grid(rows) * 4, per = (rpg + 3) / 4 + 1;
+  return (int)(per < nw ? per : nw);
+}
+size_t head_scratch_bytes(int64_t rows, int groups_max) {
+  // for any group size: groups * min(NW, rpg / 4 + 2) <= rows / 4 + 2 groups
+  return 256 + ((size_t)rows / 4 + 2 * (size_t)groups_max + 8) * 2 * sizeof(double);
+}
+
 template <int KC>
-static int launch_head_dots_kc(const float* x, int64_t rows, const float* w, int N, float* dots, double* mom, int64_t rpg, hipStream_t s) {
+static int launch_head_dots_kc(const float* x, int64_t rows, const float* w, int N, float* dots, double* mom, int64_t rpg, void* scratch,
+                               hipStream_t s) {
   const size_t lds = (size_t)N * KC * 256 * 4;
   if (int r_ = ensure_dyn_lds((const void*)head_dots_kernel<KC>, 32 * KC * 256 * 4)) return r_;
-  const int64_t groups = (rows + 15) / 16;
-  const unsigned grid = (unsigned)(groups < 512 ? groups : 512);
-  hipLaunchKernelGGL((head_dots_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, N, dots, mom, rpg);
+  const unsigned grid = head_dots_grid(rows);
+  if (mom && (!scratch || ((uintptr_t)scratch & 7))) { set_error("head_fused: scratch"); return -1; }
+  if ((unsigned long)rows * KC * 256 * 4 > 0x7FFFFFF0ul) { set_error("head_fused: more than 2 GiB of encoder output (32-bit buffer offsets)"); return -1; }
+  unsigned* ticket = (unsigned*)scratch;
+  double* slots = scratch ? (double*)((char*)scratch + 256) : nullptr;
+  hipLaunchKernelGGL((head_dots_kernel<KC>), dim3(grid), dim3(256), lds, s, x, rows, w, N, dots, mom, rpg, slots, ticket,
+                     mom ? head_slots_per_group(rows, rpg) : 0);
   SVT_LAUNCH_CHECK();
   return 0;
 }
 int launch_head_fused(const float* x, int64_t rows, int K, const float* w, const float* wsum, const float* b, int N, float* dots,
-                      double* mom /*2 per group, zeroed; null = no output norm*/, int64_t rows_per_group, float eps, float* logits,
-                      FrameOut* frames, int n_oct, int n_cls, hipStream_t s, double n_stat, int (*between)(void*), void* between_arg) {
+                      double* mom /*2 per group (written); null = no output norm*/, int64_t rows_per_group, float eps, float* logits,
+                      FrameOut* frames, int n_oct, int n_cls, hipStream_t s, double n_stat, int (*between)(void*), void* between_arg,
+                      void* scratch /*head_scratch_bytes(rows, groups); its first 4 bytes ZERO*/) {
   if (!linear_head_eligible(K, N)) { set_error("head_fused: unsupported head geometry"); return -1; }
   if (frames && (N != 2 + n_oct + 1 + n_cls + 1 || N > 32)) { set_error("head_fused: n_out != 2 + (n_octave+1) + (n_class+1)"); return -1; }
-  int r = K == 512 ? launch_head_dots_kc<2>(x, rows, w, N, dots, mom, rows_per_group, s)
-        : K == 768 ? launch_head_dots_kc<3>(x, rows, w, N, dots, mom, rows_per_group, s)
-                   : launch_head_dots_kc<4>(x, rows, w, N, dots, mom, rows_per_group, s);
+  if (mom) {
+    const int64_t groups = (rows + rows_per_group - 1) / rows_per_group;
+    if (256 + (size_t)groups * head_slots_per_group(rows, rows_per_group) * 16 > head_scratch_bytes(rows, (int)groups)) { set_error("head_fused: scratch too small"); return -1; }
+  }
+  int r = K == 512 ? launch_head_dots_kc<2>(x, rows, w, N, dots, mom, rows_per_group, scratch, s)
+        : K == 768 ? launch_head_dots_kc<3>(x, rows, w, N, dots, mom, rows_per_group, scratch, s)
+                   : launch_head_dots_kc<4>(x, rows, w, N, dots, mom, rows_per_group, scratch, s);
   if (r) return r;
   if (between) { if (int rb = between(between_arg)) return rb; }   // the moments are complete here: cross-rank reduction hook
   hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, dots, rows, N, wsum, b, mom,

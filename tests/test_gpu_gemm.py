@@ -177,7 +177,7 @@ def test_split_operand_persistent_kernel(variant, name, prec, M, N, K, conv, act
     assert err < {2: 3e-5, 3: 4e-6}[prec] * max(1.0, (K / 768) ** 0.5), (name, variant, err)
 
 
-def run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=True, seed=0):
+def run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=True, seed=0, want_ref=True):
     """gemm_x3q_kernel through svt_debug_gemm_pairs: the fp32 A is converted to pair rows inside the hook, the result comes back as fp32."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(seed)
@@ -199,6 +199,8 @@ def run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=True, seed=0):
     _lib.check(lib.svt_debug_gemm_pairs(prec, A.data_ptr(), A.numel(), W.data_ptr(), C.data_ptr(), b.data_ptr() if bias else None, M, N, K,
                                         rpb, bstr, rstr, act, out_kind, 0, torch.cuda.current_stream().cuda_stream, 0, None), "svt_debug_gemm_pairs")
     torch.cuda.synchronize()
+    if not want_ref:
+        return C.cpu(), None
     ref = A_rows.double() @ W.cpu().double().t()
     if bias:
         ref = ref + b.cpu().double()
@@ -243,6 +245,27 @@ def test_pair_row_split_kernel(bm, out_kind, name, prec, M, N, K, conv, act, bia
     if out_kind:   # the stored value itself is cut: 2^-16 (bf16 pieces) / 2^-22 (fp16 pieces) relative
         tol += {2: 2.0 ** -15, 3: 2.0 ** -21}[prec] * ref.abs().max().item()
     assert err < tol, (name, bm, out_kind, err, tol)
+
+
+@pytest.mark.parametrize("bm", [256, 192, 128])
+@pytest.mark.parametrize("out_kind", [0, 1, 2])
+@pytest.mark.parametrize("name,prec,M,N,K,conv,act,bias", [c for c in X3Q_CASES if c[4] >= 96], ids=[c[0] for c in X3Q_CASES if c[4] >= 96])
+def test_pair_row_one_wave_kernel_equals_two_wave_kernel(bm, out_kind, name, prec, M, N, K, conv, act, bias):
+    """gemm_p1x_kernel (round 5: one wave per SIMD, three phases per slab; dispatched for K >= 96, so the test above holds IT to the fp64
+    reference) against gemm_x3q_kernel (svt_debug_set key 30 = 0): the same MFMAs in the same order per accumulator -- lo x hi, hi x hi,
+    hi x lo from the bias -- so the outputs are bit-identical, for every tile height, output form, M tail, conv rows and GELU."""
+    if out_kind == 2 and act:
+        pytest.skip("the plane output (QKV projection) has no activation")
+    lib = _lib.load()
+    lib.svt_debug_set(1, bm)
+    try:
+        one, _ = run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=bias, want_ref=False)
+        lib.svt_debug_set(30, 0)
+        two, _ = run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=bias, want_ref=False)
+    finally:
+        lib.svt_debug_set(30, 1)
+        lib.svt_debug_set(1, 0)
+    assert torch.isfinite(one).all() and torch.equal(one, two), (name, bm, out_kind, (one - two).abs().max().item())
 
 
 def test_gemm_rejects_unaligned():
