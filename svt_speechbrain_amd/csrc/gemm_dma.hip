@@ -1193,7 +1193,7 @@ int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
     const double flops = 2.0 * a.M * (double)a.N * a.K;
     const double bytes = ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N) * 4;
     prof_begin(s);
-    if (g_gemm_p1x && g.K >= 96) { if (int r_ = launch_gemm_p1x(kind, g, packed, best, s)) return r_; }   // one wave per SIMD (gemm_p1x.hip; svt_debug_set key 30)
+    if (g_gemm_p1x && g.K >= 96) { if (int r_ = launch_gemm_p1x(kind, g, packed, best, s)) return r_; }   // one wave per SIMD (gemm_p1x.hip; svt_debug_set key 30 = 1: A/B, same bits)
     else if (int r_ = launch_gemm_x3q(kind, g, packed, best, s)) return r_;
     prof_end(s, flops, bytes, 0);
     return 0;

@@ -356,7 +356,12 @@ int launch_p1x_o(const GemmArgs& a, const void* packed, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_p1x = 1;   // svt_debug_set key 30: 1 (default) = this kernel for every gemm_x3q-eligible launch with K >= 96, 0 = gemm_x3q_kernel
+// svt_debug_set key 30: 1 = this kernel for every gemm_x3q-eligible launch with K >= 96, 0 (default) = gemm_x3q_kernel.  Measured
+// (profiles/r05_gemm_p1x_ab.txt): bit-identical outputs and the SAME speed -- isolated launches within +-2 % (QKV -5 %, FFN-1 with GELU +3 %),
+// C2 fp16x3 2 567-2 570 against 2 570-2 578 clips/s, C3 1 015 both.  With three MFMAs per algorithmic multiply-add the split products are
+// bound by the matrix pipe at the clock the chip holds under that load, not by how the slab's loads are scheduled around it; the 16-bit
+// products, where the single-wave loop gained (gemm_p1w.hip), are not.  Kept as the A/B arm and as a second implementation the tests compare.
+int g_gemm_p1x = 0;
 
 // same arguments as launch_gemm_x3q (gemm_x3q.hip); the caller has checked gemm_x3q_eligible and K >= 96
 int launch_gemm_p1x(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s) {

@@ -251,19 +251,20 @@ def test_pair_row_split_kernel(bm, out_kind, name, prec, M, N, K, conv, act, bia
 @pytest.mark.parametrize("out_kind", [0, 1, 2])
 @pytest.mark.parametrize("name,prec,M,N,K,conv,act,bias", [c for c in X3Q_CASES if c[4] >= 96], ids=[c[0] for c in X3Q_CASES if c[4] >= 96])
 def test_pair_row_one_wave_kernel_equals_two_wave_kernel(bm, out_kind, name, prec, M, N, K, conv, act, bias):
-    """gemm_p1x_kernel (round 5: one wave per SIMD, three phases per slab; dispatched for K >= 96, so the test above holds IT to the fp64
-    reference) against gemm_x3q_kernel (svt_debug_set key 30 = 0): the same MFMAs in the same order per accumulator -- lo x hi, hi x hi,
-    hi x lo from the bias -- so the outputs are bit-identical, for every tile height, output form, M tail, conv rows and GELU."""
+    """gemm_p1x_kernel (round 5: one wave per SIMD, three phases per slab, K >= 96; svt_debug_set key 30 = 1) against gemm_x3q_kernel (the
+    dispatched kernel, which the test above holds to the fp64 reference): the same MFMAs in the same order per accumulator -- lo x hi,
+    hi x hi, hi x lo from the bias -- so the outputs are bit-identical, for every tile height, output form, M tail, conv rows and GELU."""
     if out_kind == 2 and act:
         pytest.skip("the plane output (QKV projection) has no activation")
     lib = _lib.load()
     lib.svt_debug_set(1, bm)
     try:
+        lib.svt_debug_set(30, 1)
         one, _ = run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=bias, want_ref=False)
         lib.svt_debug_set(30, 0)
         two, _ = run_gemm_pairs(prec, M, N, K, conv, act, out_kind, bias=bias, want_ref=False)
     finally:
-        lib.svt_debug_set(30, 1)
+        lib.svt_debug_set(30, 0)
         lib.svt_debug_set(1, 0)
     assert torch.isfinite(one).all() and torch.equal(one, two), (name, bm, out_kind, (one - two).abs().max().item())
 
