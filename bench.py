@@ -630,7 +630,7 @@ def main():
         if os.path.exists(PMC_TRAFFIC_FILE) and args.model == "wav2vec2-base" and B == 32 and args.seconds == 10.0 and args.precision == "bf16":
             try:
                 pm = json.load(open(PMC_TRAFFIC_FILE))
-                fam = [v for k, v in pm.items() if k.startswith(("gemm_pps_kernel", "gemm_pers_kernel", "gemm_pp8_kernel"))]
+                fam = [v for k, v in pm.items() if k.startswith(("gemm_p1w_kernel", "gemm_pps_kernel", "gemm_pers_kernel", "gemm_pp8_kernel"))]
                 tot_n = sum(v["launches"] for v in fam)
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fam) / tot_n / 1e9, 4)
             except Exception:
@@ -671,8 +671,9 @@ def main():
                          "kernel": ("svt::gemm_x3q_kernel <BM=128|192|256> (split-operand products on pair rows: activations AND weights pre-cut into "
                                     "16-bit (hi, lo) pieces by their producers, hi*hi + hi*lo + lo*hi = three MFMAs per 16x16x32 block on the persistent "
                                     "staggered schedule of gemm_pps_kernel); gemm_x3s_kernel for the batched positional conv") if split else
-                                   ("svt::gemm_pps_kernel / gemm_pp8_kernel <BM=128|192|256> (one LDS-DMA MFMA pipeline, staggered schedule: persistent "
-                                    "stream of tiles per CU; one tile per workgroup for the batched positional conv)"),
+                                   ("svt::gemm_p1w_kernel (one wave per SIMD; conv 1-6, projection, QKV, out-projection, FFN-2, large FFN-1) / gemm_pps_kernel "
+                                    "(two waves per SIMD taking turns; FFN-1 of the base model) / gemm_pp8_kernel <BM=128|192|256>: one LDS-DMA MFMA pipeline, "
+                                    "persistent stream of tiles per CU; one tile per workgroup for the batched positional conv"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"GB of HBM traffic per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",

@@ -13,7 +13,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(gemm_pps_kernel|gemm_pers_kernel|gemm_pp8_kernel|gemm_x3p_kernel|gemm_x3s_kernel|gemm_x3_kernel|outproj_ln_kernel|gemm_kernel|flash_attn_kernel|layernorm_f32_vec_kernel|"
+    m = re.search(r"(gemm_p1w_kernel|gemm_p1x_kernel|gemm_x3q_kernel|gemm_pps_kernel|gemm_pers_kernel|gemm_pp8_kernel|gemm_x3p_kernel|gemm_x3s_kernel|gemm_x3_kernel|outproj_ln_kernel|gemm_kernel|flash_attn_kernel|layernorm_f32_vec_kernel|"
                   r"conv0_group_apply_kernel|conv0_window_moments_kernel|conv0_group_coef_kernel|posconv_gather_kernel|"
                   r"linear_head_kernel|moments_kernel|global_norm_kernel|f32_to_bf16_kernel|decode_frames_kernel)", name)
     if not m:

@@ -24,6 +24,12 @@ $B --batch 1 --seconds 5 --steps 100 --warmup 10 > "$O/r05_bench_c1_b1_5s.json" 
 $B --batch 1 --seconds 5 --steps 100 --warmup 10 --streams 1 > "$O/r05_bench_c1_b1_5s_one_stream.json" 2>> "$O/bench.err"
 (python tools/av_bench.py; python tools/rca_bench.py; python tools/video_bench.py) 2>/dev/null > "$O/r05_c4_av_bench.txt"
 (python tools/soak.py --iters 1000; python tools/soak.py --precision fp16x3 --iters 300; python tools/soak.py --precision fp16 --iters 300; python tools/soak.py --model hubert-large-ll60k --batch 64 --iters 150; python tools/soak.py --batch 1 --seconds 5 --iters 1000; python tools/soak.py --video --iters 300) 2>&1 | grep forwards > "$O/r05_soak.txt"
+(echo "== 8 processes on the GPU, each forwards 8 inputs back to back, 40 sweeps: logits and every byte of the workspace against the first sweep"
+ python tools/determinism_stress.py --procs 8 --iters 40 --same-input 2>&1 | grep "sweeps over\|sweep [0-9]\|REPRO\|DISAGREE"
+ echo "== 8 processes x 24 encoder objects created one after the other: logits of every object on one input"
+ python tools/determinism_stress.py --procs 8 --encoders 24 --same-input 2>&1 | grep "encoder objects\|REPRO\|DISAGREE"
+ echo "== bench.py --gpus 8 --verify, eight ranks on this one GPU, 6 runs"
+ bash tools/run8_verify.sh 6 2>&1 | grep "verified\|differ\|diag") > "$O/r05_determinism_after_fixes.txt" 2>&1
 python tools/gemm_yardstick.py --iters 30 > "$O/r05_gemm_vendor_library_yardstick.txt" 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 P="rocprofv3 --kernel-trace --stats --output-format csv"
