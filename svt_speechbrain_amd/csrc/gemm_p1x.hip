@@ -4,7 +4,7 @@
 // A pair-row slab is the LDS image of a 64-deep 16-bit slab: 128 bytes per row, hi pieces of 32 consecutive elements in the first half, lo
 // pieces in the second.  Where the 16-bit kernel multiplies (k-step 0 x k-step 0) + (k-step 1 x k-step 1), this one multiplies
 // lo x hi + hi x hi + hi x lo -- in that order per accumulator, from the bias as the first MFMA's C operand: the order of gemm_x3q_kernel, so
-// the two kernels give the same bits (tests/test_gpu_gemm_x3.py compares them).  Per slab and wave: three PHASES of 8 MB MFMAs (MB = BM / 32
+// the two kernels give the same bits (tests/test_gpu_gemm.py compares them).  Per slab and wave: three PHASES of 8 MB MFMAs (MB = BM / 32
 // row blocks x 8 column blocks of the wave's BM/2 x 128 tile), all four fragment sets live (x hi, x lo, w hi, w lo: 64 + 64 registers at
 // BM = 256, beside 256 accumulator registers in the AGPR half of the file):
 //     phase 0   acc += x.lo w.hi     meanwhile: read x.hi of this slab;           request A of slab g + 2

@@ -71,6 +71,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // The epilogue's own operands -- bias and residual of the CP output columns this thread will store -- are fetched NOW, in front of the
+  // K loop: a one-utterance launch is a chain of memory round trips (arguments, operands, then bias / residual, then the store), and
+  // this takes one link out of it (round 5; the launches of a 5 s utterance last 5-14 us, most of it latency).
+  constexpr int CP = NB * NB, TPR = 16 / NB;
+  const int e_row = tid / TPR, e_cs = (tid % TPR) * CP;
+  const int e_m = m0 + e_row, e_n = n0 + e_cs;
+  const bool e_live = e_m < p.M && e_n < p.N;
+  const long e_idx = (z1 * p.c_z1 + z2 * p.c_z2) + (long)e_m * p.ldc + e_n;
+  float e_bias[CP], e_res[CP];
+#pragma unroll
+  for (int j = 0; j < CP; ++j) { e_bias[j] = 0.f; e_res[j] = 0.f; }
+  if (e_live) {
+    if (p.bias) {
+      const float* bp = p.bias + z2 * p.bias_z2 + e_n;
+#pragma unroll
+      for (int j = 0; j < CP; j += 4) { const float4 t = *(const float4*)(bp + j); e_bias[j] = t.x; e_bias[j + 1] = t.y; e_bias[j + 2] = t.z; e_bias[j + 3] = t.w; }
+    }
+    if (p.resid) {
+#pragma unroll
+      for (int j = 0; j < CP; j += 4) { const float4 t = *(const float4*)(p.resid + e_idx + j); e_res[j] = t.x; e_res[j + 1] = t.y; e_res[j + 2] = t.z; e_res[j + 3] = t.w; }
+    }
+  }
+
   auto load = [&](Frags<NB>& f, int i) {  // i-th slab of this wave's walk (a slab past the end is fetched again but never multiplied)
     int j = (i < mine ? i : (mine > 0 ? mine - 1 : 0)) + rot;
     if (j >= mine) j -= mine;
@@ -138,10 +161,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   __syncthreads();
 
   // thread t: CP = NB*NB consecutive columns of one row (16 / NB threads per row): row-contiguous stores
-  constexpr int CP = NB * NB, TPR = 16 / NB;
-  const int row = tid / TPR, cs = (tid % TPR) * CP;
-  const int m = m0 + row, n = n0 + cs;
-  if (m >= p.M || n >= p.N) return;
+  const int row = e_row, cs = e_cs;
+  if (!e_live) return;
   float v[CP];
 #pragma unroll
   for (int j = 0; j < CP; j += 4) {
@@ -153,13 +174,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     }
     v[j] = s[0]; v[j + 1] = s[1]; v[j + 2] = s[2]; v[j + 3] = s[3];
   }
-  const float* bias = p.bias ? p.bias + z2 * p.bias_z2 + n : nullptr;
-  const long idx = (z1 * p.c_z1 + z2 * p.c_z2) + (long)m * p.ldc + n;
+  const long idx = e_idx;
 #pragma unroll
   for (int j = 0; j < CP; ++j) {
-    float t = v[j] * p.alpha + (bias ? bias[j] : 0.f);
+    float t = v[j] * p.alpha + e_bias[j];
     t = act_apply(t, p.act);
-    if (p.resid) t += p.resid[idx + j];
+    t += e_res[j];
     v[j] = t;
   }
   if (p.out_f32) {
