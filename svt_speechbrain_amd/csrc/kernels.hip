@@ -27,19 +27,23 @@ __device__ __forceinline__ float wave_max(float v) {
 // rounding downstream moves every logit by ~1e-4 -- seen as soon as eight processes shared one GPU (tests/test_gpu_bench_two_ranks.py).
 // Instead every workgroup stores its partial sums and takes a ticket; the one that draws the last ticket adds the partials in workgroup
 // order and writes the result (no zeroed accumulator needed; the ticket must be 0 at launch and is put back to 0).
+// (No fence: an agent-scope release fence is an L2 write-back on this chip, and one per workgroup made the three statistics kernels
+// 30-50 us slower each.  The partials are WRITE-THROUGH stores -- st_partial -- whose acknowledgement the vmcnt wait below awaits, the
+// ticket is an agent-scope atomic behind it, and the reader uses loads that bypass the non-coherent caches -- ld_partial.)
+__device__ __forceinline__ void st_partial(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_groups) {
   __shared__ unsigned s_last;
-  __threadfence();   // this thread's partials are visible device-wide (across XCDs) before the ticket is taken
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partials have reached the level every XCD reads from
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == n_groups - 1 ? 1u : 0u;
     if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const bool last = s_last != 0;
-  if (last) __threadfence();
-  return last;
+  return s_last != 0;
 }
 // a partial written by another workgroup (possibly on another XCD): read past the non-coherent caches
 __device__ __forceinline__ double ld_partial(const double* p) {
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, int64_t n,
   if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[blockIdx.x * 2] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    part[blockIdx.x * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    st_partial(part + blockIdx.x * 2, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    st_partial(part + blockIdx.x * 2 + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
   }
   if (!last_workgroup(ticket + blockIdx.y, gridDim.x)) return;
   s = 0.0; ss = 0.0;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* 
   // per-workgroup partials, added in workgroup order by the clip's last workgroup (last_workgroup above): wm is written, not accumulated
   part += (size_t)b * gridDim.x * NWM;
   if (threadIdx.x < NWM)
-    part[blockIdx.x * NWM + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    st_partial(part + blockIdx.x * NWM + threadIdx.x, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   if (!last_workgroup(ticket + b, gridDim.x)) return;
   if (threadIdx.x < NWM) {
     double t = 0.0;
@@ -956,8 +960,8 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
       const int64_t ja = (cur_g * rows_per_group) >> 2;
       const int p = (int)(((W - ja) % NW + NW) % NW);
       double* sl = slots + ((size_t)cur_g * slots_per_group + p) * 2;
-      sl[0] = sa;
-      sl[1] = sq;
+      st_partial(sl, sa);
+      st_partial(sl + 1, sq);
     }
     la = 0.f; lq = 0.f;
   };
