@@ -21,10 +21,12 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- sums over the workgroups of a launch, reproducible bit for bit ----
-// fp64 atomicAdd gives a sum whose last bits depend on the order in which the workgroups arrive.  Harmless for a mean, but conv layer 0's
-// GroupNorm variance is a quadratic form of the window moments with heavy cancellation (low-pass audio against random filters: 1e3-1e5),
-// so a changed last bit of a moment flips the last bit of an fp32 coefficient about once per hundred forwards, and one flipped bf16
-// rounding downstream moves every logit by ~1e-4 -- seen as soon as eight processes shared one GPU (tests/test_gpu_bench_two_ranks.py).
+// fp64 atomicAdd gives a sum whose last bits depend on the order in which the workgroups arrive; conv layer 0's GroupNorm variance is a
+// quadratic form of the window moments with heavy cancellation (low-pass audio against random filters: 1e3-1e5), so a changed last bit
+// of a moment can flip the last bit of an fp32 coefficient, and one flipped bf16 rounding downstream moves every logit by ~1e-4.  (This
+// was the first suspect when the eight-rank dry run of bench.py --verify on one GPU began to fail; the forwards that differed there
+// turned out to come from a split load in head_dots_kernel, below -- but arrival order was the one input of the forward that is not a
+// function of its arguments, so it went too.)
 // Instead every workgroup stores its partial sums and takes a ticket; the one that draws the last ticket adds the partials in workgroup
 // order and writes the result (no zeroed accumulator needed; the ticket must be 0 at launch and is put back to 0).
 // (No fence: an agent-scope release fence is an L2 write-back on this chip, and one per workgroup made the three statistics kernels
