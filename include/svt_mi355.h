@@ -306,8 +306,10 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * 26 = stem + max-pool of the lip front-end as one persistent kernel (1, default) or as two kernels (0), 27 = stage 2's 1x1 stride-2
  * downsample inside conv1's product (1, default) or as its own product (0), 28 = two-slot schedule of gemm_pps_kernel (0, default: four
  * slots), 29 = gemm_p1w_kernel (one wave per SIMD) for the 16-bit products it measured faster on (1, default), everywhere (2) or never (0),
- * 30 = gemm_p1x_kernel (the same loop for the split-operand products on pair rows: 1) or gemm_x3q_kernel (0, default: same bits, same speed).
- * Returns 0 (key 24: the count), SVT_ERR_INVALID for an unknown key. */
+ * 30 = gemm_p1x_kernel (the same loop for the split-operand products on pair rows: 1) or gemm_x3q_kernel (0, default: same bits, same speed),
+ * 31 = query: returns the number of device buffers this process has FREED so far (value ignored; uploads and re-uploads must not free:
+ * tests/test_gpu_uploads.py).
+ * Returns 0 (keys 24, 31: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);
 
 /* ---- measurement hook: HIP-event timing of the dominant kernel on the stream it runs on ----

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "host.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -116,8 +117,10 @@ int dev_alloc(void** out, size_t n) {
   g_guard_recs[*out] = r;
   return 0;
 }
+static std::atomic<int> g_dev_frees{0};   // svt_debug_set key 31 (query): device frees of this process so far (tests: none on an upload path)
 void dev_free(void* p) {
   if (!p) return;
+  g_dev_frees.fetch_add(1, std::memory_order_relaxed);
   GuardRec r{};
   {
     std::lock_guard<std::mutex> lk(g_guard_mu);
@@ -521,6 +524,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 22) g_conv0_mfma = value;
   else if (key == 23) g_conv3x3_c64 = value;
   else if (key == 24) return g_conv3x3_c64_launches;
+  else if (key == 31) return g_dev_frees.load(std::memory_order_relaxed);
   else if (key == 25) g_conv3x3_c64_form = value;
   else if (key == 26) g_stem_pool_fused = value;
   else if (key == 27) g_conv_down_fused = value;
