@@ -510,8 +510,17 @@ __global__ __launch_bounds__(256) void conv0_window_moments_kernel(const float* 
     st_partial(part + blockIdx.x * NWM + threadIdx.x, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   if (!last_workgroup(ticket + b, gridDim.x)) return;
   if (threadIdx.x < NWM) {
+    // (eight loads in flight, added in workgroup order: one load per trip made the loop a chain of memory round trips)
     double t = 0.0;
-    for (unsigned k = 0; k < gridDim.x; ++k) t += ld_partial(part + k * NWM + threadIdx.x);
+    unsigned k = 0;
+    for (; k + 8 <= gridDim.x; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ld_partial(part + (k + j) * NWM + threadIdx.x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += v[j];
+    }
+    for (; k < gridDim.x; ++k) t += ld_partial(part + k * NWM + threadIdx.x);
     wm[b * NWM + threadIdx.x] = t;
   }
 }
@@ -1049,7 +1058,15 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
       const int n = (int)(nj < NW ? nj : NW);
       const double* sl = slots + (size_t)g * slots_per_group * 2;
       double ta = 0.0, tq = 0.0;
-      for (int i = lane; i < n; i += 64) { ta += ld_partial(sl + 2 * i); tq += ld_partial(sl + 2 * i + 1); }
+      int i = lane;
+      for (; i + 3 * 64 < n; i += 4 * 64) {   // eight loads in flight per lane, added in slot order
+        double va[4], vq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = ld_partial(sl + 2 * (i + 64 * j)); vq[j] = ld_partial(sl + 2 * (i + 64 * j) + 1); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ta += va[j]; tq += vq[j]; }
+      }
+      for (; i < n; i += 64) { ta += ld_partial(sl + 2 * i); tq += ld_partial(sl + 2 * i + 1); }
       ta = wave_sum(ta);
       tq = wave_sum(tq);
       if (lane == 0) { mom[2 * g] = ta; mom[2 * g + 1] = tq; }
