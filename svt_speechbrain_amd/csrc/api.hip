@@ -508,6 +508,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 28) g_pps_two_slots = value;
   else if (key == 29) g_gemm_p1w = value;
   else if (key == 30) g_gemm_p1x = value;
+  else if (key == 33) g_gemm_skinny_small_tiles = value;
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;

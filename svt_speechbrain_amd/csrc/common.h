@@ -266,6 +266,7 @@ extern int g_ln_two_rows;  // (hi, lo) LayerNorm: half a wave per row, 16-byte a
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
+extern int g_gemm_skinny_small_tiles;   // svt_debug_set key 33
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
 extern int g_stamp_ends;
 extern int g_pps_half_barriers;

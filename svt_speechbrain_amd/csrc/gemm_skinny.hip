@@ -222,9 +222,10 @@ bool gemm_skinny_eligible(const GemmArgs& a) {
   return big_tiles <= g_gemm_skinny_max_tiles;
 }
 
+int g_gemm_skinny_small_tiles = 96;   // svt_debug_set key 33: 32 x 32 tiles while the 64 x 64 tiling has at most this many workgroups
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s) {
   const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.nz;
-  return tiles64 <= 96 ? launch_skinny<2>(a, s) : launch_skinny<4>(a, s);
+  return tiles64 <= g_gemm_skinny_small_tiles ? launch_skinny<2>(a, s) : launch_skinny<4>(a, s);
 }
 
 }  // namespace svt
