@@ -987,7 +987,9 @@ __global__ __launch_bounds__(256) void head_dots_kernel(const float* __restrict_
       // then came out short by 12-35 elements' worth in ~0.15 % of the forwards (sum and dots intact; every logit moved by 2e-4 .. 1e-3
       // through the output norm): tools/determinism_stress.py, 10 of 6 400 forwards.  Three rebuilds, 6 400 forwards each, all clean: a
       // full wait in front of the statistics; scalar FMAs; and this one -- the same packed arithmetic and the same counted waits behind
-      // UNSPLIT loads.  So the counted wait is not safe behind that split pair on this chip; tests/test_build_isa.py keeps such pairs out.
+      // UNSPLIT loads.  WHICH instruction of the round-4 sequence misbehaves is not isolated: a microbenchmark of the pair, the counted wait
+      // and reads / overwrites of the destination registers right behind it (tools/microbench/split_load_probe.hip) saw no stale value in
+      // 2e10 lane-rows under the same eight-process load.  The kernel-level evidence stands; tests/test_build_isa.py keeps split pairs out.
       const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
       for (int c = 0; c < KC; ++c) {

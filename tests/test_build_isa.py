@@ -3,8 +3,10 @@
 Round 5 found a forward that was not reproducible while other processes used the GPU: hipcc had split a 16-byte load of
 `head_dots_kernel` into an OVERLAPPING pair (`global_load_dwordx3 ... offset:4` + `global_load_dwordx2`) and guarded the first use with
 its own counted `s_waitcnt vmcnt(N)`; under load the sum of squares of the output norm came out short in ~0.15 % of the forwards
-(svt_speechbrain_amd/csrc/kernels.hip, tools/determinism_stress.py).  The kernel now issues loads the compiler cannot take apart; this
-test keeps 12-byte vector loads out of every kernel except the one that really reads 7-tap rows (16 + 12 bytes, not overlapping)."""
+(svt_speechbrain_amd/csrc/kernels.hip, tools/determinism_stress.py; three rebuilds without that combination were clean, though a
+microbenchmark of the bare pair, tools/microbench/split_load_probe.hip, does not reproduce it).  The kernel now issues loads the compiler
+cannot take apart; this test keeps 12-byte vector loads out of every kernel except the one that really reads 7-tap rows (16 + 12 bytes,
+not overlapping)."""
 import os
 import re
 import shutil
