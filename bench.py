@@ -23,7 +23,7 @@ After the timed region (never part of `value`):
   * notes-out leg  -- step + device-to-host copy of the decoded frames + `frames2note` of every clip
                       (`notes_out_clips_per_s`: "greedy decode" all the way to note lists on the host);
   * parity leg     -- one forward of the same batch in the timed dtype and one in the exact-fp32 mode: max |dlogit|, frames whose
-                      argmax differs, clips with identical note lists, note-level precision / recall (`parity`, and `verified`);
+                      argmax differs, clips with identical note lists, note-level precision / recall (`parity`, `meets_north_star_parity`);
   * parity-grade leg -- the same workload in precision "fp16x3", the fast mode that meets the north star's tolerance
                       (`parity_grade`: clips/s, its own roofline fraction against 2.5 PF / 3, max |dlogit| vs the exact fp32 mode);
   * cpu_baseline   -- the oracle on the host cores, SURVEY.md §8(d) protocol (rank 0, N = 1 only).
@@ -49,17 +49,17 @@ import torch  # noqa: E402
 # MI355X dense peaks (MI355X_MICROARCH.md).  The split-operand modes issue three 16-bit MFMAs per algorithmic
 # multiply-add (Ah*Wh + Al*Wh + Ah*Wl), so their ceiling in ALGORITHMIC flops is a third of the bf16 / fp16 peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
-# What each numeric mode promises against the exact-fp32 mode (README "Numeric modes"; asserted by tests/test_gpu_parity.py on the
+# What the parity-grade modes promise against the exact-fp32 mode (README "Numeric modes"; asserted by tests/test_gpu_parity.py on the
 # goldens and checked here on the bench batch): largest |dlogit|, share of frames whose octave / pitch-class argmax may differ, and the
 # note-level COnPOff F1 of the mode's notes against the exact mode's.  Only fp32 and fp16x3 meet north_star's "1e-3 + identical notes".
 # Frames count against the share only beyond NEAR TIES (the reference's own margin between the two classes within 2e-3, twice the logit bar:
-# agreement.py); on 64 x 10 s of HuBERT-large one frame of 31 936 is such a tie in fp16x3 (max |dlogit| 9.5e-5, notes identical).
+# agreement.py).  The plain 16-bit modes (bf16, fp16) carry NO bound here: a bound next to a measured figure would be fitted to it
+# (ADVICE r05); what they cost is what `parity` measures, and the GPU suite holds them to the operand-rounding SIMULATION
+# (tests/golden/sim_bounds.json, tools/sim_split.py), not to a constant.
 PARITY_BOUNDS = {
     "fp32":   {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.0, "COnPOff_f1": 0.999},
     "fp16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.0, "COnPOff_f1": 0.999},
     "bf16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.003, "COnPOff_f1": 0.99},
-    "fp16":   {"max_abs_dlogit": 0.12, "frames_mismatch_frac": 0.02, "COnPOff_f1": 0.95},
-    "bf16":   {"max_abs_dlogit": 1.0, "frames_mismatch_frac": 0.15, "COnPOff_f1": 0.80},
 }
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
 
@@ -546,11 +546,12 @@ def main():
         torch.cuda.synchronize()
         del ref_enc
         parity = mode_agreement(own_logits, own_frames, ref_logits, ref_frames, 0.4, 0.5, 1 / 49.8)
-        bound = PARITY_BOUNDS[args.precision]
+        bound = PARITY_BOUNDS.get(args.precision)
         parity.update({"mode": args.precision, "reference_mode": "fp32 (exact fp32 MFMA), same library, same batch and weights",
                        "thresholds": {"onset": 0.4, "offset": 0.5, "frame_size_s": round(1 / 49.8, 6)},
                        "stated_bound": bound,
-                       "within_stated_bound": bool(parity["max_abs_dlogit"] <= bound["max_abs_dlogit"] and
+                       "within_stated_bound": None if bound is None else
+                                              bool(parity["max_abs_dlogit"] <= bound["max_abs_dlogit"] and
                                                    parity["frames_argmax_mismatch_beyond_near_ties"] <= bound["frames_mismatch_frac"] * parity["frames"] and
                                                    parity["COnPOff_f1"] >= bound["COnPOff_f1"]),
                        "seconds": round(time.perf_counter() - t_par, 2),
@@ -658,9 +659,11 @@ def main():
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates
             "rccl_ranks": res["ranks"],
-            # --verify: the gathered rows against a local recomputation of every shard.  Without it (N = 1): the parity leg's verdict --
-            # the timed dtype's logits / frames / notes against the exact mode, within the bound stated for that dtype (PARITY_BOUNDS)
-            "verified": verified if verified is not None else (parity["within_stated_bound"] if parity is not None else None),
+            # --verify only: the gathered rows against a local recomputation of every shard (null without the flag).  What the timed dtype
+            # computes against the exact mode is reported under its own keys: `parity` (measured figures + the mode's DOCUMENTED bound,
+            # `within_stated_bound`) and `meets_north_star_parity` = logits within 1e-3 AND identical argmax AND identical note lists
+            "verified": verified,
+            "meets_north_star_parity": parity["meets_1e-3_and_identical_notes"] if parity is not None else None,
             "parity": parity,
             "collective": None if world == 1 else {"op": "all_gather_into_tensor", "payload": args.gather,
                                                    "bytes_per_rank_per_step": gatherers[0].bytes_per_rank(),

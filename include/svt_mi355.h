@@ -308,7 +308,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * slots), 29 = gemm_p1w_kernel (one wave per SIMD) for the 16-bit products it measured faster on (1, default), everywhere (2) or never (0),
  * 30 = gemm_p1x_kernel (the same loop for the split-operand products on pair rows: 1) or gemm_x3q_kernel (0, default: same bits, same speed),
  * 31 = query: returns the number of device buffers this process has FREED so far (value ignored; uploads and re-uploads must not free:
- * tests/test_gpu_uploads.py), 33 = the small-problem GEMM uses 32 x 32 tiles while its 64 x 64 tiling has at most this many workgroups
+ * tests/test_gpu_uploads.py), 32 = the tickets of the three ordered cross-workgroup sums as acquire-release atomics (1) or relaxed ones behind
+ * write-through stores (0, default: kernels.hip, last_workgroup; same bits, tests/test_gpu_statistics.py), 33 = the small-problem GEMM uses 32 x 32 tiles while its 64 x 64 tiling has at most this many workgroups
  * (96, default; swept on the one-utterance forward: 150 / 200 / 1000 are 1.5-4.5 % slower).
  * Returns 0 (keys 24, 31: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);

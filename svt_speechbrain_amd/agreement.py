@@ -58,31 +58,36 @@ def note_agreement(est_notes, ref_notes) -> Dict[str, float]:
 
 
 def mode_agreement(logits: torch.Tensor, frames, ref_logits: torch.Tensor, ref_frames, onset_thres: float = 0.4,
-                   offset_thres: float = 0.5, frame_size: float = 1 / 49.8, lengths: Optional[np.ndarray] = None) -> Dict[str, object]:
+                   offset_thres: float = 0.5, frame_size: float = 1 / 49.8, lengths: Optional[np.ndarray] = None,
+                   n_octave: Optional[int] = None, n_class: int = 13) -> Dict[str, object]:
     """Everything above for one batch: ``logits`` (clips, T, 20) and ``frames`` (clips, T, 4 x int32, what the fused tail /
-    ``svt_decode_frames`` wrote) of the mode under test against the reference mode's."""
+    ``svt_decode_frames`` wrote) of the mode under test against the reference mode's.  ``n_octave`` / ``n_class``: the head's layout
+    (2 + n_octave + n_class logits per frame; ``n_octave`` defaults to what is left beside ``n_class``), as ``svt_frames_to_notes`` takes them."""
     d = (logits.detach().float() - ref_logits.detach().float()).abs()
     fr, rf = _frames_host(frames), _frames_host(ref_frames)
     if fr.shape != rf.shape:
         raise ValueError(f"mode_agreement: frame arrays of different shape {fr.shape} vs {rf.shape}")
     differ = (fr["octave"] != rf["octave"]) | (fr["pitch_class"] != rf["pitch_class"])
     # a differing frame is a NEAR TIE when, in the reference mode's own logits, the class the other mode picked is within 2e-3 of the
-    # winner: two forwards that both sit within the north star's 1e-3 of the truth cannot be expected to break such a tie the same way
-    n_oct = int(max(fr["octave"].max(initial=0), rf["octave"].max(initial=0))) + 1
+    # winner: two forwards that both sit within the north star's 1e-3 of the truth cannot be expected to break such a tie the same way.
+    # Logit layout (svt_decode_frames / svt_frames_to_notes): onset, offset, n_octave octave logits, n_class pitch-class logits.
+    width = int(ref_logits.shape[-1])
+    if n_octave is None:
+        n_octave = width - 2 - n_class
+    if n_octave < 1 or n_class < 1 or 2 + n_octave + n_class != width:
+        raise ValueError(f"mode_agreement: {width} logits per frame are not 2 + n_octave ({n_octave}) + n_class ({n_class})")
     near_tie = 0
     if differ.any() and d.numel():
         tol = 2e-3
-        rl = ref_logits.detach().float().cpu().reshape(-1, ref_logits.shape[-1])
-        n_oct_logits = rl.shape[-1] - 2 - 13 if rl.shape[-1] >= 16 else n_oct      # 2 onset / offset logits, then octaves, then 13 classes
         idx = np.flatnonzero(differ.reshape(-1))
-        for i in idx:
-            row = rl[i]
-            ok = True
-            for lo, hi, a, b in ((2, 2 + n_oct_logits, int(fr["octave"].reshape(-1)[i]), int(rf["octave"].reshape(-1)[i])),
-                                 (2 + n_oct_logits, rl.shape[-1], int(fr["pitch_class"].reshape(-1)[i]), int(rf["pitch_class"].reshape(-1)[i]))):
-                if a != b and float(row[lo + b] - row[lo + a]) > tol:
-                    ok = False
-            near_tie += int(ok)
+        rl = ref_logits.detach().float().cpu().reshape(-1, width).numpy()[idx]
+        ok = np.ones(idx.size, dtype=bool)
+        for lo, key in ((2, "octave"), (2 + n_octave, "pitch_class")):
+            a = fr[key].reshape(-1)[idx].astype(np.int64)      # what the mode under test picked
+            b = rf[key].reshape(-1)[idx].astype(np.int64)      # what the reference mode picked
+            gap = np.take_along_axis(rl, (lo + b)[:, None], 1)[:, 0] - np.take_along_axis(rl, (lo + a)[:, None], 1)[:, 0]
+            ok &= (a == b) | (gap <= tol)
+        near_tie = int(ok.sum())
     notes = frames2note_batch(fr, onset_thres, offset_thres, frame_size, lengths)
     ref_notes = frames2note_batch(rf, onset_thres, offset_thres, frame_size, lengths)
     out: Dict[str, object] = {

@@ -326,6 +326,7 @@ struct svt_encoder {
   svt_encoder_config cfg;
   int device = 0;
   bool finalized = false;
+  bool uploaded = false;   // device buffers exist: the next finalize is a RE-upload into live buffers
   ParamMap params;
   std::vector<ConvLayerW> conv;
   DevBuf fp_g, fp_b, proj_w, proj_b, pos_w, pos_b, enc_g, enc_b;
@@ -499,6 +500,11 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
 
 static int g_conv_down_fused = 1;   // svt_debug_set key 27: 0 = stage 2's stride-2 conv1 and its 1x1 downsample as two products (A/B, tests)
 int svt_debug_set(int key, int value) {
+#ifndef SVT_DIAG
+  // A/B arms that only `make DIAG=1` builds: the shipped library holds the kernels it dispatches
+  if ((key == 21 && value != 0 && value != 3) || (key == 28 && value != 0) || (key == 30 && value != 0)) {
+    set_error("svt_debug_set: this A/B arm is built by `make DIAG=1` only"); return SVT_ERR_INVALID; }
+#endif
   if (key == 0) g_gemm_dbg = value;
   else if (key == 1) g_gemm_force_bm = value;
   else if (key == 2) g_gemm_ring = value;
@@ -509,6 +515,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 29) g_gemm_p1w = value;
   else if (key == 30) g_gemm_p1x = value;
   else if (key == 33) g_gemm_skinny_small_tiles = value;
+  else if (key == 32) return set_ticket_fenced(value);
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
@@ -622,6 +629,11 @@ int svt_encoder_get_param(svt_encoder* e, const char* key, void* out_host, int64
 int svt_encoder_finalize(svt_encoder* e) {
   if (!e) { set_error("null encoder"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(e->device));
+  // A RE-upload overwrites live weight buffers in place (DevBuf::alloc keeps a buffer of unchanged size; the uploads and conversions run
+  // on the null stream, which does not order against the callers' non-blocking streams): wait for every forward still in flight on this
+  // device -- replica() lanes share these buffers -- before the first byte changes (tests/test_gpu_uploads.py)
+  if (e->uploaded) SVT_HIP(hipDeviceSynchronize());
+  e->uploaded = true;
   const svt_encoder_config& c = e->cfg;
   const int prec = storage_prec(c.precision);
   const ParamMap& P = e->params;
@@ -1489,6 +1501,7 @@ struct svt_rca {
   int D = 0, H = 0, F = 0, max_len = 0, prec = 0, gp = 0, device = 0;  // prec: storage type, gp: product engine
   float alpha = 0.5f;
   bool finalized = false;
+  bool uploaded = false;   // device buffers exist: the next finalize is a RE-upload into live buffers
   ParamMap params;
   DevBuf pe;
   RcaLayerW L[2];
@@ -1569,6 +1582,11 @@ int svt_rca_load_param(svt_rca* r, const char* key, const void* data_host, int d
 int svt_rca_finalize(svt_rca* r) {
   if (!r) { set_error("null rca"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(r->device));
+  // A RE-upload overwrites live weight buffers in place (DevBuf::alloc keeps a buffer of unchanged size; the uploads and conversions run
+  // on the null stream, which does not order against the callers' non-blocking streams): wait for every forward still in flight on this
+  // device -- replica() lanes share these buffers -- before the first byte changes (tests/test_gpu_uploads.py)
+  if (r->uploaded) SVT_HIP(hipDeviceSynchronize());
+  r->uploaded = true;
   const ParamMap& P = r->params;
   const Param* p = nullptr;
   const int D = r->D, F = r->F;
@@ -1681,6 +1699,7 @@ struct VConv {
 struct svt_video {
   int E = 0, prec = 0, gp = 0, device = 0;  // prec: storage type, gp: product engine
   bool finalized = false;
+  bool uploaded = false;   // device buffers exist: the next finalize is a RE-upload into live buffers
   ParamMap params;
   DevBuf stem_w, stem_bias, stem_slope;
   VConv conv1[4][2], conv2[4][2], down[4];
@@ -1870,6 +1889,11 @@ int svt_video_load_param(svt_video* v, const char* key, const void* data_host, i
 int svt_video_finalize(svt_video* v) {
   if (!v) { set_error("null video front-end"); return SVT_ERR_INVALID; }
   SVT_HIP(hipSetDevice(v->device));
+  // A RE-upload overwrites live weight buffers in place (DevBuf::alloc keeps a buffer of unchanged size; the uploads and conversions run
+  // on the null stream, which does not order against the callers' non-blocking streams): wait for every forward still in flight on this
+  // device -- replica() lanes share these buffers -- before the first byte changes (tests/test_gpu_uploads.py)
+  if (v->uploaded) SVT_HIP(hipDeviceSynchronize());
+  v->uploaded = true;
   const ParamMap& P = v->params;
   const Param* p = nullptr;
   // ---- stem: (64,1,5,7,7) + BatchNorm3d + PReLU(64) ----

@@ -1501,7 +1501,12 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
   const unsigned short *q = (const unsigned short*)Q, *k = (const unsigned short*)K, *v = (const unsigned short*)V;
   prof_begin(s);
 #define SVT_X3_LAUNCH(DH_, F16_, NW_) hipLaunchKernelGGL((flash_attn_x3_kernel<DH_, F16_, NW_>), grid, dim3(64 * NW_), 0, s, q, ldq, q_bstride, q_plane, k, v, ldk, k_bstride, k_plane, O, ldo, o_bstride, T, H, c, o_pairs)
-  if (dh == 64 && wide && g_attn_variant == 0) {
+#ifdef SVT_DIAG
+  const bool stag = g_attn_variant == 0;
+#else
+  const bool stag = true;   // the lockstep 8-wave form below is an A/B arm of `make DIAG=1` (svt_debug_set key 21)
+#endif
+  if (dh == 64 && wide && stag) {
     const int nqb = (T + 255) / 256;
     const int lds_bytes = 3 * 4 * 512 * 16;   // three stages of four 8 KiB tiles
     const dim3 g1((unsigned)(nqb * B * H));
@@ -1515,7 +1520,9 @@ int launch_flash_attention_x3(int kind, const void* Q, long ldq, long q_bstride,
                          ldo, o_bstride, T, H, c, o_pairs, nqb);
     }
   }
+#ifdef SVT_DIAG
   else if (dh == 64 && wide) { if (kind == 3) SVT_X3_LAUNCH(64, true, 8); else SVT_X3_LAUNCH(64, false, 8); }
+#endif
   else if (dh == 64) { if (kind == 3) SVT_X3_LAUNCH(64, true, 4); else SVT_X3_LAUNCH(64, false, 4); }
   else if (dh == 128) { if (kind == 3) SVT_X3_LAUNCH(128, true, 4); else SVT_X3_LAUNCH(128, false, 4); }
   else { set_error("flash_attention_x3: head_dim must be 64 or 128"); return -1; }
@@ -1543,7 +1550,12 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   // eight-wave workgroups (256 queries) halve the K / V traffic per query; used when a head has more than 128 queries
   // (measured 45.7 vs 46.9 us at 32 x 12 heads x 499 frames, 114.2 vs 118.7 us at 64 x 16; with few workgroups -- one 5 s
   // utterance: 12 -- the four-wave form spreads over more CUs and stays)
-  const bool wide = g_flash_wide && dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512 && !(g_attn_variant >= 5 && g_attn_variant <= 7);
+#ifdef SVT_DIAG
+  const int variant = g_attn_variant;
+#else
+  const int variant = 0;    // every other value selects an A/B arm that only `make DIAG=1` builds (svt_debug_set key 21)
+#endif
+  const bool wide = g_flash_wide && dh == 64 && T > 128 && (long)B * H * ((T + 255) / 256) >= 512 && !(variant >= 5 && variant <= 7);
   if (wide) grid.x = (T + 255) / 256;
   const double flops = 4.0 * B * H * (double)T * T * dh;
   if (gate && pb) {
@@ -1569,54 +1581,56 @@ int launch_flash_attention(const void* Q, long ldq, long q_bstride, const void* 
   else
 #endif
 #ifdef SVT_DIAG
-  if (dh == 64 && wide && g_attn_variant == 85) {
+  if (dh == 64 && wide && variant == 85) {
     // software-pipelined form (flash_attn_pipe_kernel, round 5)
     const int nqb = (T + 255) / 256;
     hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 8, 5, 2>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr);
-  } else if (dh == 64 && wide && g_attn_variant == 99) {   // stamps (tools/attn_pipe_stamps.py)
+  } else if (dh == 64 && wide && variant == 99) {   // stamps (tools/attn_pipe_stamps.py)
     const int nqb = (T + 127) / 128;
     hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 4, 3, 2>), dim3((unsigned)(nqb * B * H)), dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)O);
-  } else if (dh == 64 && wide && g_attn_variant >= 40 && g_attn_variant < 50) {   // experiments: 4x = 128-query workgroups, ring depth x
+  } else if (dh == 64 && wide && variant >= 40 && variant < 50) {   // experiments: 4x = 128-query workgroups, ring depth x
     const int nqb = (T + 127) / 128;
 #define SVT_PIPE4(NR_) hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 4, NR_, 2>), dim3((unsigned)(nqb * B * H)), dim3(256), 0, s, (const bf16_t*)Q, ldq, \
                        q_bstride, (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr)
-    if (g_attn_variant == 43) SVT_PIPE4(3); else if (g_attn_variant == 44) SVT_PIPE4(4); else SVT_PIPE4(5);
+    if (variant == 43) SVT_PIPE4(3); else if (variant == 44) SVT_PIPE4(4); else SVT_PIPE4(5);
 #undef SVT_PIPE4
-  } else if (dh == 64 && wide && g_attn_variant >= 80 && g_attn_variant < 90) {   // experiments: 8x = 256-query workgroups, ring depth x
+  } else if (dh == 64 && wide && variant >= 80 && variant < 90) {   // experiments: 8x = 256-query workgroups, ring depth x
     const int nqb = (T + 255) / 256;
 #define SVT_PIPE8(NR_) hipLaunchKernelGGL((flash_attn_pipe_kernel<64, 8, NR_, 2>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, \
                        q_bstride, (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb, (unsigned*)nullptr)
-    if (g_attn_variant == 83) SVT_PIPE8(3); else if (g_attn_variant == 84) SVT_PIPE8(4); else SVT_PIPE8(6);
+    if (variant == 83) SVT_PIPE8(3); else if (variant == 84) SVT_PIPE8(4); else SVT_PIPE8(6);
 #undef SVT_PIPE8
   } else
 #endif
-  if (dh == 64 && wide && (g_attn_variant == 3 || g_attn_variant == 0)) {
+  if (dh == 64 && wide && (variant == 3 || variant == 0)) {
     // staggered form (flash_attn_stag_kernel, round 4): three K / V stages, waves 4-7 half a tile behind waves 0-3
     const int nqb = (T + 255) / 256;
     hipLaunchKernelGGL((flash_attn_stag_kernel<64, false>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
   }
 #ifdef SVT_DIAG
-  else if (dh == 64 && wide && g_attn_variant == 2) {   // PIPE form (measured slower: 43.0-43.9 against 41.0-42.1 us at C2), make DIAG=1
+  else if (dh == 64 && wide && variant == 2) {   // PIPE form (measured slower: 43.0-43.9 against 41.0-42.1 us at C2), make DIAG=1
     const int nqb = (T + 255) / 256;
     hipLaunchKernelGGL((flash_attn_stag_kernel<64, true>), dim3((unsigned)(nqb * B * H)), dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride,
                        (const bf16_t*)K, ldk, k_bstride, (const bf16_t*)V, (bf16_t*)O, ldo, o_bstride, T, H, c, nqb);
   }
 #endif
-  else if (dh == 64 && wide)
+#ifdef SVT_DIAG
+  else if (dh == 64 && wide)   // the round-3 lockstep 8-wave kernel (A/B arm)
     hipLaunchKernelGGL((flash_attn_kernel<64, false, 8>), grid, dim3(512), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
-  else if (dh == 64 && g_attn_variant >= 5 && g_attn_variant <= 7) {
+  else if (dh == 64 && variant >= 5 && variant <= 7) {
     // experiment: four-wave workgroups with the residency capped by an LDS pad (5: three per CU = 768 slots, two exact rounds of the
     // 1 536 workgroups of C2; 6: two per CU; 7: four, the uncapped default of the narrow form)
-    const size_t pad = g_attn_variant == 5 ? 20480 : g_attn_variant == 6 ? 40960 : 0;
+    const size_t pad = variant == 5 ? 20480 : variant == 6 ? 40960 : 0;
     if (ensure_dyn_lds((const void*)flash_attn_kernel<64>, (int)pad)) return -1;
     dim3 g4((T + 127) / 128, H, B);
     hipLaunchKernelGGL((flash_attn_kernel<64>), g4, dim3(256), pad, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);
   }
+#endif
   else if (dh == 64)
     hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bstride, (const bf16_t*)K,
                        ldk, k_bstride, (const bf16_t*)V, 0, (bf16_t*)O, ldo, o_bstride, T, H, c, nullptr, nullptr);

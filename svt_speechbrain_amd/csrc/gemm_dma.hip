@@ -1139,6 +1139,7 @@ int split_weights_register(const void* w_f32, long n_rows, int K, int kind, hipS
     if (it != g_split_w.end() && it->second.N == (int)n_rows && it->second.K == K) packed = it->second.packed;
   }
   const bool reused = packed != nullptr;
+  if (reused) SVT_HIP(hipDeviceSynchronize());   // products of a forward still in flight on another stream may be reading `packed`
   if (!reused)
     if (int r = dev_alloc(&packed, (size_t)n_rows * K * 4)) return r;
   const long pieces = n_rows * (K / 8);

@@ -193,6 +193,10 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   constexpr int NREQ = (GW + GA + MB - 1) / MB;
   constexpr int LAST_W_BLOCK = (GW - 1) / NREQ;                 // row block in which the last W piece is issued
   constexpr int STORES_AFTER_W = (MB - LAST_W_BLOCK) * 4;       // that block's stores (issued at its end) and all later ones
+  // the counted waits' bookkeeping: the last k-step has room for every W and A piece of the slab it requests; vmcnt is a 6-bit counter;
+  // loads and stores of one wave retire IN ORDER on that counter (gfx9 returns VMEM in issue order), which w_as below relies on
+  static_assert(NREQ * MB >= GW + GA, "the last k-step issues every request of the next tile's head");
+  static_assert(GA + STORES_AFTER_W <= 63 && GA + GW <= 63, "vmcnt holds 6 bits");
   auto kstep_last = [&](int rs, bool ev, const char* srcA, int slotA, const char* srcW, int slotW) {
     const int logical = ti * nblk + lbase;
     const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
@@ -336,7 +340,9 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   }
   long long t_loop = 0;
   if (tr) t_loop = wall_clock64();
-  if (no_epi) p1_wait_vm<0>(); else p1_wait_vm<STORES_AFTER_W>();   // the surplus requests are older than these stores
+  // Everything this wave still has in flight -- the last tile's stores AND the stream's surplus LDS-DMA requests (they are INTERLEAVED with
+  // those stores in the last k-step's row blocks LAST_W_BLOCK + 1 .. MB - 1, not older than them: ADVICE r05) -- retires before the wave ends
+  p1_wait_vm<0>();
   if (tr && lane == 0) {   // record layout of gemm_pps_kernel (tools/gemm_trace.py); waves 0 / 2 stand for its two wave groups
     if ((wave & 1) == 0) {
       long long* o = p.trace + ((long)blockIdx.x * 2 + (wave >> 1)) * 8;
@@ -368,10 +374,14 @@ int launch_p1w_t(const GemmArgs& a, hipStream_t s) {
 int g_gemm_p1w = 1;   // svt_debug_set key 29: 1 (default) = this kernel where it measured faster than gemm_pps_kernel (gemm_dma.hip), 0 = never
 
 int launch_gemm_p1w(const GemmArgs& a, int bm, hipStream_t s) {
-  if (a.trace) {   // tools/gemm_trace.py --p1w: the two tile heights of the encoder's launches, without activation
+#ifdef SVT_DIAG
+  if (a.trace) {   // tools/gemm_trace.py --p1w (make DIAG=1): the two tile heights of the encoder's launches, without activation
     if (bm == 256) return launch_p1w_t<256, ACT_NONE, true>(a, s);
     return launch_p1w_t<192, ACT_NONE, true>(a, s);
   }
+#else
+  if (a.trace) { set_error("gemm_p1w: the stamped instantiations are built by `make DIAG=1` only"); return -1; }
+#endif
   if (a.act == ACT_GELU) {
     if (bm == 256) return launch_p1w_t<256, ACT_GELU>(a, s);
     if (bm == 192) return launch_p1w_t<192, ACT_GELU>(a, s);

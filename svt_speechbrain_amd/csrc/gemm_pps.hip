@@ -637,14 +637,6 @@ static int launch_pps_aux(const GemmArgs& a, int bm, hipStream_t s) {
 }
 
 int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int store_policy) {
-  // (nt stores, aux = 2, were measured in round 3 and never won: their instantiations are gone)
-  if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
-  return launch_pps_aux<0>(a, bm, s);
-}
-#else
-// The dispatched form: write-through (sc1) stores, four barriers per slab (measured against the eight-barrier form and the default
-// store policy in round 3: profiles/r03_gemm_pps_slots.txt; those and the slot-stamp instantiations are built by `make DIAG=1`).
-int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy*/) {
   // svt_debug_set key 28: the two-slot schedule (round 5).  0 (default) = never, 1 = wherever it applies, 2 = the one launch family it
   // measured faster on in isolation: the FFN-1 of the LARGE models (N = 4096, K = 1024, GELU, 256-row tiles: 284 -> 273 us; every C2 shape
   // is 1-6 % slower with it) -- which did not carry over to the step: C3 2 476 clips/s with it against 2 505 without
@@ -654,6 +646,15 @@ int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy
     if (a.act == ACT_GELU) return bm == 256 ? launch_pps_t<256, ACT_GELU, 16, 0, false, true>(a, s) : launch_pps_t<192, ACT_GELU, 16, 0, false, true>(a, s);
     return bm == 256 ? launch_pps_t<256, ACT_NONE, 16, 0, false, true>(a, s) : launch_pps_t<192, ACT_NONE, 16, 0, false, true>(a, s);
   }
+  // (nt stores, aux = 2, were measured in round 3 and never won: their instantiations are gone)
+  if (store_policy == 2) return launch_pps_aux<16>(a, bm, s);   // sc1 (write-through)
+  return launch_pps_aux<0>(a, bm, s);
+}
+#else
+// The dispatched form: write-through (sc1) stores, four barriers per slab (measured against the eight-barrier form and the default
+// store policy in round 3: profiles/r03_gemm_pps_slots.txt; those, the slot-stamp instantiations and round 5's two-slot schedule
+// (svt_debug_set key 28, measured slower: profiles/r05_gemm_two_slot_ab.txt) are built by `make DIAG=1`).
+int launch_gemm_pps(const GemmArgs& a, int bm, hipStream_t s, int /*store_policy*/) {
   if (a.act == ACT_GELU) {
     if (bm == 256) return launch_pps_t<256, ACT_GELU, 16, 0, true>(a, s);
     if (bm == 192) return launch_pps_t<192, ACT_GELU, 16, 0, true>(a, s);

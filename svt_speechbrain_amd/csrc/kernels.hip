@@ -35,12 +35,18 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void st_partial(double* p, double v) {
   __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A/B arm (svt_debug_set key 32 = 1): the ticket as an agent-scope ACQUIRE-RELEASE atomic -- the form the HIP / LLVM memory
+// model asks for (release: this workgroup's partials are visible before the ticket; acquire: the last workgroup sees everyone's).  The
+// default (0) is the relaxed form described above, which leans on what gfx950 does with write-through stores and cache-bypassing loads;
+// tests/test_gpu_statistics.py holds BOTH arms to host fp64 sums of the same inputs and to each other, bit for bit.
+__device__ int d_ticket_fenced = 0;
 __device__ __forceinline__ bool last_workgroup(unsigned* ticket, unsigned n_groups) {
   __shared__ unsigned s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partials have reached the level every XCD reads from
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = d_ticket_fenced ? __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                       : __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == n_groups - 1 ? 1u : 0u;
     if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2058,6 +2064,12 @@ __global__ void clock_stamp_kernel(long long* out) {
 int launch_clock_stamp(long long* out16, hipStream_t s) {
   hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, s, out16);  // 64 blocks: round-robin over the 8 XCDs
   SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int set_ticket_fenced(int on) {   // svt_debug_set key 32
+  const int v = on ? 1 : 0;
+  SVT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_ticket_fenced), &v, sizeof(int)));
   return 0;
 }
 

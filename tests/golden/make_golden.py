@@ -170,7 +170,15 @@ def make_encoder_case(hi, utils, name, cfg_name, B, L, seed, pad_to=None, full=T
 def make_fusion_cases(fusion_mod):
     sd = W.seeded_fusion_state_dict(1024, 3072, seed=3986)
     m = fusion_mod.FusionRCA().eval()
-    m.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    # the positional-encoding table the REFERENCE builds for itself (speechbrain PositionalEncoding's registered buffer), taken before
+    # any load: the fixture pins it (sha256 + a strided sample), and the reference runs on ITS OWN table, not on the one
+    # svt_speechbrain_amd.weights computes -- a strict load of our state dict would overwrite the buffer and pin nothing
+    pe_key = "fusion.positional_encoding.pe"
+    ref_pe = m.state_dict()[pe_key].detach().clone()
+    sd_ref = {k: (ref_pe if k == pe_key else v) for k, v in sd.items()}
+    m.load_state_dict(sd_ref, strict=True)
+    pe_pin = dict(pe_shape=tuple(ref_pe.shape), pe_sha256=hashlib.sha256(ref_pe.contiguous().numpy().tobytes()).hexdigest(),
+                  pe_strided=ref_pe[0, ::97, ::61].clone())
     cases = [("fusion_trunc", 2, 499, 500), ("fusion_pad", 1, 250, 240), ("fusion_eq", 1, 64, 64)]
     for name, B, T1, T2 in cases:
         g = torch.Generator().manual_seed(77 + T1)
@@ -180,7 +188,7 @@ def make_fusion_cases(fusion_mod):
             out = m(a, v)
         fx = dict(name=name, B=B, T1=T1, T2=T2, in_seed=77 + T1, weight_seed=3986, sd_sha256=sd_digest(sd),
                   out_strided=out[:, ::7, ::5].clone(), out_absmean=float(out.abs().mean()),
-                  out_first=out[:, :4].clone())
+                  out_first=out[:, :4].clone(), **pe_pin)
         torch.save(fx, os.path.join(HERE, name + ".pt"))
         print(name, tuple(out.shape))
 

@@ -41,7 +41,7 @@ def main():
     for name in CASES:
         fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
         out[name] = {}
-        for mode in ("bf16x1", "f16x1"):
+        for mode in ("bf16x1", "f16x1", "bf16x1s", "f16x1s"):   # operand rounding; "s": + what the kernels STORE in 16 bits (tools/sim_split.py)
             mx, mean, mism, frames, n_ref, f_full, f_nooff, f_on = sim_split.simulate(fx, mode)
             # [max |dlogit|, mean |dlogit|, frames with another argmax, frames, reference notes, F1 COnPOff, COnP, COn of the simulated notes]
             out[name][mode] = [round(mx, 6), round(mean, 7), mism, frames, n_ref, f_full, f_nooff, f_on]

@@ -46,3 +46,56 @@ def test_no_split_vector_loads(lib):
                     bad.append((kernel, line.split("//")[0].strip()))
         assert n_kernels > 100, n_kernels
         assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("lib", ["libsvt_mi355.so", "libsvt_mi355_f16.so"])
+def test_vmem_instructions_beside_hand_counted_waits(lib):
+    """every kernel with hand-written `s_waitcnt vmcnt(N)` is held to the committed table of its VMEM
+    instructions and counted waits (tools/isa_vmem_table.py: written when the GPU suite, the soak and the determinism stress were green on
+    this code) -- a spill, a split / widened / duplicated load or a wait the compiler added or dropped changes the table.  Beyond the
+    table: no scratch traffic at all in these kernels, and the LDS-DMA GEMM stream issues nothing but 16-byte requests, 16-byte
+    bias loads and 8- / 16-byte row stores."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_vmem_table as T
+    src = os.path.join(ROOT, "svt_speechbrain_amd", lib)
+    if not os.path.exists(src) or not os.path.exists(OBJDUMP):
+        pytest.skip("library or llvm-objdump not present")
+    got = T.table_of(src)
+    want = json.load(open(T.TABLE))[lib]
+    assert len(got) >= 40, len(got)
+    for name, rec in got.items():
+        assert not any(m.startswith("scratch_") for m in rec["vmem"]), (name, rec["vmem"])
+        if any(f in name for f in T.STREAM_FAMILIES):
+            extra = set(rec["vmem"]) - T.STREAM_ALLOWED
+            assert not extra, (name, extra)
+    assert sorted(got) == sorted(want), (sorted(set(got) ^ set(want))[:6], "kernel set changed: re-validate on the GPU, then python tools/isa_vmem_table.py")
+    diff = [(k, got[k], want[k]) for k in got if got[k] != want[k]]
+    assert not diff, (diff[:3], "VMEM / wait table changed: re-validate on the GPU, then python tools/isa_vmem_table.py")
+
+
+@pytest.mark.parametrize("lib", ["libsvt_mi355.so", "libsvt_mi355_f16.so"])
+def test_shipped_library_holds_no_ab_arms(lib):
+    """experiment kernels that nothing dispatches (`gemm_p1x_kernel`, the two-slot schedule of gemm_pps_kernel, the
+    lockstep 8-wave attention, stamped diagnostic instantiations) are built by `make DIAG=1` only."""
+    src = os.path.join(ROOT, "svt_speechbrain_amd", lib)
+    if not os.path.exists(src):
+        pytest.skip("library not present")
+    syms = subprocess.run(["nm", "-C", "--defined-only", src], capture_output=True, text=True).stdout
+    if "gemm_pps_kernel" not in syms:   # kernel names live in the device code objects, not in the host symbol table
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_vmem_table as T
+        syms = "\n".join(subprocess.run(["c++filt"], input="\n".join(
+            m for dis in T.disassemble(src) for m in re.findall(r"^[0-9a-f]+ <(\S+)>:", dis, re.M)), capture_output=True, text=True).stdout.splitlines())
+    assert "gemm_pps_kernel" in syms and "flash_attn_stag_kernel" in syms
+    for residue in ("gemm_p1x_kernel", "flash_attn_pipe_kernel", "flash_attn_kernel<64, false, 8", "flash_attn_x3_kernel<64, true, 8",
+                    "flash_attn_x3_kernel<64, false, 8"):
+        assert residue not in syms, residue
+    # gemm_pps_kernel<BM, ACT, STAUX, STAMP, HALF, TWO>: no two-slot (TWO = true) and no stamped (STAMP != 0) instantiation
+    for m in re.findall(r"gemm_pps_kernel<([^>]*)>", syms):
+        a = [x.strip() for x in m.split(",")]
+        assert a[3] == "0" and a[-1] == "false", m
+    for m in re.findall(r"gemm_p1w_kernel<([^>]*)>", syms):
+        assert m.split(",")[-1].strip() == "false", m   # TR (stamps) only under DIAG

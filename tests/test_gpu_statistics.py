@@ -1,0 +1,87 @@
+"""The three cross-workgroup statistics of a forward (waveform moments, conv-0 window moments, output-norm moments) are summed in a fixed
+order by the launch's LAST workgroup (csrc/kernels.hip, last_workgroup): per-workgroup partials as write-through stores, a ticket atomic,
+cache-bypassing loads -- relaxed atomics, no fence (a fence is an L2 write-back on gfx950: +30-50 us per kernel).  ADVICE r05 asked for
+more than run-to-run bit equality: the sums are compared here with HOST fp64 sums of the same inputs, in both arms of the ticket
+(svt_debug_set key 32: 0 relaxed, 1 acquire-release), over many forwards with other work on the GPU between them -- a stale partial
+would be off by a whole workgroup's share (1e-3 .. 1e-1 relative), the summation order by ~1e-15."""
+import ctypes as C
+
+import pytest
+import torch
+
+import svt_speechbrain_amd as S
+from svt_speechbrain_amd import _lib
+from svt_speechbrain_amd.config import PRESETS
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def host_sums(wav: torch.Tensor, k: int, stride: int):
+    """fp64 sums the kernels take: (sum, sum of squares) of the batch, and per clip the 10 tap sums + 55 tap products of the conv-0
+    windows (products rounded to fp32 first, as the kernel forms them)."""
+    x = wav.double()
+    mom = torch.stack([x.sum(), (x * x).sum()])
+    win = wav.unfold(-1, k, stride)                     # (B, T1, k) fp32
+    cols = [win[..., j].double().sum(1) for j in range(k)]
+    for j in range(k):
+        for j2 in range(j, k):
+            cols.append((win[..., j] * win[..., j2]).double().sum(1))
+    return mom, torch.stack(cols, 1)                    # (2,), (B, 65)
+
+
+@pytest.mark.parametrize("fenced", [0, 1])
+def test_ordered_sums_equal_host_fp64_sums(fenced):
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="bf16", normalize_wav=True, seed=3).to(DEV)
+    lib = enc._lib()
+    B, L = 6, 48000
+    g = torch.Generator().manual_seed(77)
+    k, st = cfg.conv_kernel[0], cfg.conv_stride[0]
+    noise = torch.randn(4096, 4096, device=DEV)
+    assert lib.svt_debug_set(32, fenced) == 0
+    try:
+        seen = None
+        for it in range(40):
+            wav = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+            want_mom, want_win = host_sums(wav, k, st)
+            y = enc(wav.to(DEV))
+            slot = enc._sync_device(DEV)
+            ws = slot.ws.clone()                          # stream-ordered copy of the workspace behind the forward
+            noise = noise @ noise.t() * 1e-4              # other kernels between the forwards (caches in another state each time)
+            offs = (C.c_int64 * 25)()
+            assert lib.svt_debug_encoder_layout(slot.handle, B, L, offs, 25) == 25, _lib.last_error(lib)
+            torch.cuda.synchronize()
+            mom = ws[offs[0]:offs[0] + (4 * B + 65 * B) * 8].view(torch.float64).cpu()
+            got_mom, got_win = mom[:2], mom[4 * B:].view(B, 65)
+            assert torch.allclose(got_mom, want_mom, rtol=1e-12, atol=1e-12), (it, got_mom, want_mom)
+            assert torch.allclose(got_win, want_win, rtol=1e-11, atol=1e-11), (it, (got_win - want_win).abs().max())
+            # the output norm's moments belong to the un-normalised encoder output, which this call does not return: what it returns has
+            # unit statistics over the whole batch iff those moments were complete
+            yd = y.double()
+            assert abs(yd.mean().item()) < 1e-5 and abs(yd.var(unbiased=False).item() - 1.0) < 1e-4
+            # same input again: bit-identical statistics
+            if it == 0:
+                seen = (wav, mom.clone())
+        enc(seen[0].to(DEV))
+        slot = enc._sync_device(DEV)
+        torch.cuda.synchronize()
+        again = slot.ws[offs[0]:offs[0] + (4 * B + 65 * B) * 8].view(torch.float64).cpu()
+        assert torch.equal(again, seen[1])
+    finally:
+        lib.svt_debug_set(32, 0)
+
+
+def test_both_ticket_forms_give_the_same_bits():
+    cfg = PRESETS["tiny-group"]
+    enc = S.HuggingFaceWav2Vec2("tiny-group", None, config=cfg, precision="fp32", normalize_wav=True, seed=3).to(DEV)
+    lib = enc._lib()
+    wav = (0.1 * torch.randn(5, 40000, generator=torch.Generator().manual_seed(1))).clamp_(-1, 1).to(DEV)
+    try:
+        lib.svt_debug_set(32, 0)
+        a = enc(wav).clone()
+        lib.svt_debug_set(32, 1)
+        b = enc(wav).clone()
+    finally:
+        lib.svt_debug_set(32, 0)
+    assert torch.equal(a, b)

@@ -50,3 +50,30 @@ def test_creating_and_reloading_an_encoder_frees_nothing(precision):
     y3 = enc(wav)
     assert frees(lib) == base
     assert not torch.equal(y0, y3) and torch.isfinite(y3).all()
+
+
+def test_a_reupload_waits_for_forwards_still_in_flight():
+    """a re-upload overwrites the live weight buffers in place (same-size buffers are kept), on the null stream, while torch's
+    side streams are non-blocking -- so svt_*_finalize must wait for the device before the first byte changes.  A queue of forwards on a
+    side stream (tens of milliseconds of work), then new parameter VALUES and a forward on the main stream right away: every queued
+    forward must still return what the OLD parameters give, bit for bit, and the new forward what a fresh object gives."""
+    cfg = PRESETS["tiny-layer"]
+    enc = S.HuggingFaceWav2Vec2("tiny-layer", None, config=cfg, precision="bf16", normalize_wav=True, seed=21).to(DEV)
+    wav = (0.1 * torch.randn(24, 80000, generator=torch.Generator().manual_seed(5))).to(DEV)
+    small = wav[:2, :8000].contiguous()
+    want_old = enc(wav).clone()
+    sd_new = {k: (v + 0.02 * torch.randn_like(v) if v.is_floating_point() else v) for k, v in enc.state_dict().items()}
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            outs.append(enc(wav).clone())
+    enc.load_state_dict(sd_new)            # marks the parameters stale; the upload happens inside the next forward
+    got_new = enc(small).clone()           # main stream: re-upload (must drain `side` first), then a short forward
+    torch.cuda.synchronize()
+    for i, y in enumerate(outs):
+        assert torch.equal(y, want_old), f"forward {i} queued before the re-upload read half-updated weights"
+    fresh = S.HuggingFaceWav2Vec2("tiny-layer", None, config=cfg, precision="bf16", normalize_wav=True, seed=21).to(DEV)
+    fresh.load_state_dict(sd_new)
+    assert torch.equal(got_new, fresh(small))

@@ -295,6 +295,22 @@ def test_mode_agreement_levels_and_near_ties():
     r = mode_agreement(own, frames(own), ref, frames(ref))
     assert r["frames_argmax_mismatch"] == 2 and r["frames_argmax_mismatch_beyond_near_ties"] == 1
     assert not r["meets_1e-3_and_identical_argmax_up_to_near_ties"]
+    # another head layout (3 octaves + 7 classes = 12 logits): the slices follow n_octave / n_class, not a hard-coded 13
+    ref12 = torch.randn(1, 40, 12)
+    ref12[0, 4, 5], ref12[0, 4, 6] = 6.0, 6.0 - 1e-5                          # classes 0 / 1 of the pitch-class slice (2 + 3 + ...)
+
+    def frames12(lg):
+        fr = np.zeros(lg.shape[:2], dtype=FRAME_DTYPE)
+        fr["p_on"], fr["p_off"] = torch.sigmoid(lg[..., 0]).numpy(), torch.sigmoid(lg[..., 1]).numpy()
+        fr["octave"], fr["pitch_class"] = lg[..., 2:5].argmax(-1).numpy(), lg[..., 5:].argmax(-1).numpy()
+        return fr
+
+    own12 = ref12.clone()
+    own12[0, 4, 6] += 3e-5
+    r = mode_agreement(own12, frames12(own12), ref12, frames12(ref12), n_octave=3, n_class=7)
+    assert r["frames_argmax_mismatch"] == 1 and r["frames_argmax_mismatch_beyond_near_ties"] == 0
+    with pytest.raises(ValueError):
+        mode_agreement(own12, frames12(own12), ref12, frames12(ref12))        # 12 logits are not 2 + n_octave + 13
     # micro-average: 1 of 2 notes matched in one clip, 0 of 0 in the other -> precision 1/2, not the mean of (1/2, 1)
     na = note_agreement([[[0.0, 1.0, 60], [2.0, 3.0, 70]], []], [[[0.0, 1.0, 60], [2.5, 3.0, 64]], []])
     assert na["COnPOff_precision"] == 0.5 and na["COnPOff_recall"] == 0.5 and na["clips_with_identical_notes"] == 1

@@ -99,6 +99,22 @@ def test_oracle_fusion(golden, name):
     assert (out[:, :4] - fx["out_first"]).abs().max() < 5e-5
 
 
+def test_positional_encoding_table_is_the_references_own_buffer(golden):
+    """`weights.positional_encoding_table` (what FusionRCA here and the oracle add to the audio features) against the buffer the
+    REFERENCE's speechbrain PositionalEncoding registered for itself -- captured by make_golden.py before any state-dict load and
+    stored as sha256 + strided sample in every fusion fixture (the goldens' outputs were produced on that buffer): bit for bit."""
+    import hashlib
+    for name in ("fusion_eq", "fusion_pad", "fusion_trunc"):
+        fx = golden(name)
+        pe = W.positional_encoding_table(fx["pe_shape"][2], fx["pe_shape"][1])
+        assert tuple(pe.shape) == tuple(fx["pe_shape"]) and pe.dtype == torch.float32
+        assert torch.equal(pe[0, ::97, ::61], fx["pe_strided"])
+        assert hashlib.sha256(pe.contiguous().numpy().tobytes()).hexdigest() == fx["pe_sha256"]
+    # and it is what the seeded state dict, the module and the oracle use
+    sd = W.seeded_fusion_state_dict(1024, 3072, seed=1)
+    assert hashlib.sha256(sd["fusion.positional_encoding.pe"].numpy().tobytes()).hexdigest() == fx["pe_sha256"]
+
+
 def test_oracle_ctc(golden):
     cases = golden("ctc")
     for k, c in cases.items():

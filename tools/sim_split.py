@@ -30,17 +30,40 @@ def pieces(x, dt, n):
 
 
 def make_ops(mode):
+    """Replacements for (F.linear, F.conv1d, torch.matmul, F.gelu).  A trailing "s" (``bf16x1s`` / ``f16x1s``: the STORED-activation
+    simulation, round 6) also rounds what the 16-bit kernels STORE in 16 bits beside the operands: the result of every F.linear (the
+    GEMM epilogue writes 16-bit rows; an out-projection / FFN-2 / projection result then meets the fp32 residual arithmetic already
+    rounded) and of every GELU (conv activations, positional embedding) -- with a linear -> GELU pair rounded ONCE, behind the GELU,
+    as the fused epilogue does.  Convolution and matmul results are not rounded by themselves: their consumers are products (operand
+    rounding, already simulated), a GELU, or -- layer-norm extractors -- an fp32 buffer."""
+    stored = mode.endswith("s")
+    if stored:
+        mode = mode[:-1]
     dt = torch.bfloat16 if mode.startswith("bf16") else torch.float16
     nprod = int(mode.split("x")[1])
     # product list: (index of A piece, index of W piece), smallest terms dropped
     plan = {1: [(0, 0)], 3: [(0, 0), (1, 0), (0, 1)], 6: [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]}[nprod]
     npieces = max(max(a, b) for a, b in plan) + 1
-    lin, conv, mm = F.linear, F.conv1d, torch.matmul
+    lin, conv, mm, act = F.linear, F.conv1d, torch.matmul, F.gelu
+    raw = {}   # id(rounded F.linear result) -> (rounded result, exact result): what a GELU right behind the product starts from
 
     def linear(x, w, b=None):
         xs, ws = pieces(x, dt, npieces), pieces(w, dt, npieces)
         y = sum(lin(xs[i], ws[j]) for i, j in reversed(plan))
-        return y if b is None else y + b
+        y = y if b is None else y + b
+        if not stored:
+            return y
+        r = y.to(dt).float()
+        raw.clear()
+        raw[id(r)] = (r, y)
+        return r
+
+    def gelu(x, *a, **kw):
+        if not stored:
+            return act(x, *a, **kw)
+        hit = raw.get(id(x))
+        src = hit[1] if hit is not None and hit[0] is x else x
+        return act(src, *a, **kw).to(dt).float()
 
     def conv1d(x, w, b=None, **kw):
         if x.shape[1] == 1:  # conv0 is not an MFMA product in the kernels (fp32 VALU)
@@ -53,7 +76,7 @@ def make_ops(mode):
         xs, ws = pieces(a, dt, npieces), pieces(b, dt, npieces)
         return sum(mm(xs[i], ws[j]) for i, j in reversed(plan))
 
-    return linear, conv1d, matmul
+    return linear, conv1d, matmul, gelu
 
 
 def simulate(fx, mode):
@@ -66,13 +89,13 @@ def simulate(fx, mode):
     hd = W.seeded_head_state_dict(cfg.hidden_size, 20, seed=fx["head_seed"])
     g = torch.Generator().manual_seed(fx["wav_seed"])
     wav = (0.1 * torch.randn(fx["B"], fx["L"], generator=g)).clamp_(-1, 1)
-    keep = (F.linear, F.conv1d, torch.matmul)
-    F.linear, F.conv1d, torch.matmul = make_ops(mode)
+    keep = (F.linear, F.conv1d, torch.matmul, F.gelu)
+    F.linear, F.conv1d, torch.matmul, F.gelu = make_ops(mode)
     try:
         with torch.no_grad():
             feats = O.encoder_forward(sd, cfg, wav)
     finally:
-        F.linear, F.conv1d, torch.matmul = keep
+        F.linear, F.conv1d, torch.matmul, F.gelu = keep
     with torch.no_grad():
         logits = O.head_forward(feats, hd["w.weight"], hd["w.bias"])
     err = (logits - fx["logits"]).abs()
