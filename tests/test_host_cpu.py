@@ -781,11 +781,11 @@ def test_committed_simulation_bounds_are_what_the_simulation_gives():
     assert table["_sources_sha256"] == make_sim_bounds.source_digest(), \
         "oracle/svt_oracle.py or tools/sim_split.py changed: re-run python tests/golden/make_sim_bounds.py and commit sim_bounds.json"
     for name in ("tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2", "hubert_large_b2"):
-        assert set(table[name]) == {"bf16x1", "f16x1"} and all(len(v) == 8 for v in table[name].values())
+        assert set(table[name]) == {"bf16x1", "f16x1", "bf16x1s", "f16x1s"} and all(len(v) == 8 for v in table[name].values())
     torch.set_num_threads(8)
     for name in ("tiny_group", "tiny_layer", "base_c1"):
         fx = torch.load(os.path.join(ROOT, "tests", "golden", f"{name}.pt"), weights_only=False)
-        for mode in ("bf16x1", "f16x1"):
+        for mode in ("bf16x1", "f16x1", "bf16x1s", "f16x1s"):
             mx, mean, mism, frames, n_ref, f_full, f_nooff, f_on = sim_split.simulate(fx, mode)
             t = table[name][mode]
             assert n_ref == t[4] and abs(f_full - t[5]) <= 2.0 / max(1, n_ref) and abs(f_on - t[7]) <= 2.0 / max(1, n_ref), (name, mode)
