@@ -256,6 +256,21 @@ int svt_video_keep_workspace(svt_video* v, int keep);
 /* video (B,1,T,H,W) f32 on the device -> out (B,T,embed_dim) f32 */
 int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
+/* the same with a row pitch: out row (b, t) starts at out_dev + (b * t_total + t) * out_ld (out_ld >= embed_dim); zero_left > 0 also zeroes
+ * the `zero_left` columns to the LEFT of every row (out_dev - zero_left must be inside the caller's buffer, out_ld >= embed_dim +
+ * zero_left): with out_dev = feats + E, out_ld = 2 E, zero_left = E this writes AV-HuBERT's concat fusion input
+ * cat([zeros (absent audio), video], -1) in place (N20EMv2/video_only/hubert.py:700-712) */
+int svt_video_forward_ex(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev, int64_t out_ld,
+                         int32_t zero_left, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* ---- the recipe's input side, fused (round 6): replaces transform_eval of N20EMv2/video_only/train_video_ssl.py:445-457 + the
+ * .astype(np.float32) of :530-533 in front of the lip front-end.  roi_dev: (B, T, h_in, w_in) uint8 gray frames as np.load returns them,
+ * on the device.  Every pixel u becomes float32(((double(u) - sub0) / div0 - mean) / std) -- numpy's float64 arithmetic rounded once,
+ * bit-identical -- of the centre crop_h x crop_w window (offsets int(round(h_in - crop_h) / 2.), utils.py:79-83).  The recipes use
+ * {0.0, 255.0, 0.421, 0.165, 88, 88}.  Workspace: svt_video_workspace_bytes(v, batch, t, crop_h, crop_w).  out_ld / zero_left as above. */
+typedef struct svt_video_transform { double sub0, div0, mean, std; int32_t crop_h, crop_w; } svt_video_transform;
+int svt_video_forward_u8(svt_video* v, const uint8_t* roi_dev, int32_t batch, int32_t t, int32_t h_in, int32_t w_in,
+                         const svt_video_transform* tf, float* out_dev, int64_t out_ld, int32_t zero_left, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
 
 /* ---- Fbank add-ons: replace speechbrain.processing.features.Deltas (features.py:788-850; replicate padding, kernel
  * -n..n, denominator n(n+1)(2n+1)/3) and ContextWindow (:853-940; out[..., c*ctx + j], zero padding).  x rows have pitch ldx
@@ -309,7 +324,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * 30 = gemm_p1x_kernel (the same loop for the split-operand products on pair rows: 1) or gemm_x3q_kernel (0, default: same bits, same speed),
  * 31 = query: returns the number of device buffers this process has FREED so far (value ignored; uploads and re-uploads must not free:
  * tests/test_gpu_uploads.py), 32 = the tickets of the three ordered cross-workgroup sums as acquire-release atomics (1) or relaxed ones behind
- * write-through stores (0, default: kernels.hip, last_workgroup; same bits, tests/test_gpu_statistics.py), 33 = the small-problem GEMM uses 32 x 32 tiles while its 64 x 64 tiling has at most this many workgroups
+ * write-through stores (0, default: kernels.hip, last_workgroup; same bits, tests/test_gpu_statistics.py), 34 = the persistent 16-bit GEMM
+ * kernels' tile walk: -1 (default) chosen per launch, 0 = n fastest, n > 0 = panels of n tile rows (common.h, tile_walk; same bits), 33 = the small-problem GEMM uses 32 x 32 tiles while its 64 x 64 tiling has at most this many workgroups
  * (96, default; swept on the one-utterance forward: 150 / 200 / 1000 are 1.5-4.5 % slower).
  * Returns 0 (keys 24, 31: the count), SVT_ERR_INVALID for an unknown key. */
 int svt_debug_set(int key, int value);

@@ -443,6 +443,20 @@ def _bn_eval(x, sd, p):
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
 
 
+def video_transform_eval(roi, crop: int = 88, image_mean: float = 0.421, image_std: float = 0.165):
+    """The video recipes' evaluation transform on one song's ``(T, H, W)`` uint8 lip ROI -> ``(T, crop, crop)`` float32:
+    ``Normalize(0.0, 255.0)`` -> ``CenterCrop((88, 88))`` -> ``Normalize(0.421, 0.165)`` (N20EMv2/video_only/train_video_ssl.py:445-457;
+    utils.py:53-61 -- ``(frames - mean) / std`` on the numpy array, i.e. float64 -- and :79-83 -- offsets ``int(round(w - tw) / 2.)``),
+    then ``.astype(np.float32)`` (train_video_ssl.py:530-533).  Plain numpy, same operation order."""
+    import numpy as np
+    f = (np.asarray(roi) - 0.0) / 255.0
+    _, h, w = f.shape
+    dw = int(round((w - crop)) / 2.)
+    dh = int(round((h - crop)) / 2.)
+    f = f[:, dh:dh + crop, dw:dw + crop]
+    return ((f - image_mean) / image_std).astype(np.float32)
+
+
 def video_frontend_forward(sd: Dict[str, torch.Tensor], video: torch.Tensor, prefix: str = "") -> torch.Tensor:
     """video (B,1,T,H,W) -> (B,T,embed).  resnet.py:150-158 (ResEncoder.forward), :36-72 (BasicBlock), :125-132
     (trunk), :183-187 (SubModel: proj on the transposed features; returned here already as (B,T,E))."""

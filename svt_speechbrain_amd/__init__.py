@@ -13,9 +13,11 @@ from .checkpoints import Checkpointer  # noqa: F401
 from .losses import bce_loss, nll_loss, Softmax  # noqa: F401
 from . import video  # noqa: F401
 from . import dataio, scoring  # noqa: F401
-from .video import FairseqAVHubertPretrain  # noqa: F401
-from .song import SongTranscriber, utterance_bounds, save_song_features, feature_path  # noqa: F401
+from .video import FairseqAVHubertPretrain, EvalTransform  # noqa: F401
+from .song import (SongTranscriber, utterance_bounds, save_song_features, feature_path, song_video_features,  # noqa: F401
+                   save_song_video_features, video_feature_path)
 
 __all__ = ["EncoderConfig", "PRESETS", "config_from_source", "HuggingFaceWav2Vec2", "Linear", "FusionRCA", "Fbank",
            "decode_frames", "frame2note", "frames2note", "frames2note_batch", "frames_to_info", "ctc_greedy_decode", "filter_ctc_output", "AMTForward",
-           "SongTranscriber", "utterance_bounds", "save_song_features", "feature_path"]
+           "SongTranscriber", "utterance_bounds", "save_song_features", "feature_path", "song_video_features",
+           "save_song_video_features", "video_feature_path", "EvalTransform", "FairseqAVHubertPretrain"]

@@ -48,6 +48,11 @@ class EncoderConfigC(C.Structure):
     ]
 
 
+class VideoTransformC(C.Structure):
+    """svt_video_transform: ((u - sub0) / div0 - mean) / std in float64 on the centre crop_h x crop_w window of a uint8 lip ROI."""
+    _fields_ = [("sub0", C.c_double), ("div0", C.c_double), ("mean", C.c_double), ("std", C.c_double), ("crop_h", C.c_int32), ("crop_w", C.c_int32)]
+
+
 class FrameC(C.Structure):
     _fields_ = [("p_on", C.c_float), ("p_off", C.c_float), ("octave", C.c_int32), ("pitch_class", C.c_int32)]
 
@@ -99,6 +104,10 @@ SYMBOLS = {
     "svt_video_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "svt_video_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "svt_video_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "svt_video_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(VideoTransformC),
+                                       C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "svt_deltas": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "svt_context_window": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]),
     "svt_bce_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,

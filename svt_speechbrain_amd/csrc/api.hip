@@ -516,6 +516,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 30) g_gemm_p1x = value;
   else if (key == 33) g_gemm_skinny_small_tiles = value;
   else if (key == 32) return set_ticket_fenced(value);
+  else if (key == 34) g_gemm_walk = value;
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
@@ -2000,11 +2001,17 @@ int svt_video_keep_workspace(svt_video* v, int keep) {
   return SVT_OK;
 }
 
-int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
-                      void* workspace_dev, size_t workspace_bytes, void* stream) {
-  if (!v || !video_dev || !out_dev || !workspace_dev) { set_error("svt_video_forward: null argument"); return SVT_ERR_INVALID; }
+// One body for the three entry points: `video_dev` fp32 (B,1,T,h,w) already normalised, or `roi_dev` uint8 (B,T,h_in,w_in) with the
+// recipe's transform `tf` and crop offsets (dy, dx) fused into the padding pass; out rows with pitch out_ld, `zero_left` columns to the
+// left of every row zeroed (one 2-D memset node: no torch kernel, capturable)
+static int video_forward_impl(svt_video* v, const float* video_dev, const unsigned char* roi_dev, int h_in, int w_in, int dy, int dx,
+                              const VideoTransform* tf, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev, int64_t out_ld,
+                              int32_t zero_left, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!v || (!video_dev && !roi_dev) || !out_dev || !workspace_dev) { set_error("svt_video_forward: null argument"); return SVT_ERR_INVALID; }
   if (!v->finalized) { set_error("svt_video_forward: call svt_video_finalize first"); return SVT_ERR_STATE; }
   if (batch < 1 || t < 1 || h < 8 || w < 8) { set_error("svt_video_forward: bad geometry"); return SVT_ERR_INVALID; }
+  if (out_ld < v->E || zero_left < 0 || (zero_left > 0 && out_ld < (int64_t)v->E + zero_left)) {
+    set_error("svt_video_forward: out_ld must hold embed_dim (+ zero_left) columns"); return SVT_ERR_INVALID; }
   const VGeom g = video_geom(h, w);
   VWs ws;
   if (video_carve(v, batch, t, g, workspace_dev, &ws) > workspace_bytes) { set_error("svt_video_forward: workspace too small"); return SVT_ERR_WORKSPACE; }
@@ -2014,7 +2021,11 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   const int prec = v->prec;
   const size_t es = esize(prec);
   const long F = (long)batch * t;
-  if (launch_video_pad(prec, video_dev, batch, t, h, w, g.Hp0, g.Wp0, ws.vp, s)) return SVT_ERR_HIP;
+  if (roi_dev) {
+    if (launch_video_pad_u8(prec, roi_dev, batch, t, h_in, w_in, dy, dx, h, w, g.Hp0, g.Wp0, *tf, ws.vp, s)) return SVT_ERR_HIP;
+  } else if (launch_video_pad(prec, video_dev, batch, t, h, w, g.Hp0, g.Wp0, ws.vp, s)) return SVT_ERR_HIP;
+  if (zero_left > 0)
+    SVT_HIP(hipMemset2DAsync(out_dev - zero_left, (size_t)out_ld * 4, 0, (size_t)zero_left * 4, (size_t)F, s));
   const bool fused_stem = v->gp == 1 && conv3d_front_pool_ok(prec, g.Hp0, g.Wp0, g.W0);
   if (!fused_stem && launch_conv3d_front(prec, ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0,
                                          g.H0, g.W0, ws.o0, s)) return SVT_ERR_HIP;
@@ -2144,9 +2155,31 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
   if (launch_avgpool_interior(prec, x, F, g.Hs[3], g.Ws[3], 512, ws.pooled, s)) return SVT_ERR_HIP;
   GemmArgs pj;
   pj.A = ws.pooled; pj.W = v->proj_w.p; pj.C = out_dev; pj.bias = v->proj_b.as<float>();
-  pj.M = (int)F; pj.N = v->E; pj.K = 512; pj.a_rpb = (int)F; pj.a_rstride = 512; pj.ldw = 512; pj.ldc = v->E; pj.out_f32 = 1;
+  pj.M = (int)F; pj.N = v->E; pj.K = 512; pj.a_rpb = (int)F; pj.a_rstride = 512; pj.ldw = 512; pj.ldc = out_ld; pj.out_f32 = 1;
   if (launch_gemm(v->gp, pj, s)) return SVT_ERR_HIP;
   return SVT_OK;
+}
+
+int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return video_forward_impl(v, video_dev, nullptr, 0, 0, 0, 0, nullptr, batch, t, h, w, out_dev, v ? v->E : 0, 0, workspace_dev, workspace_bytes, stream);
+}
+int svt_video_forward_ex(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev, int64_t out_ld,
+                         int32_t zero_left, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return video_forward_impl(v, video_dev, nullptr, 0, 0, 0, 0, nullptr, batch, t, h, w, out_dev, out_ld, zero_left, workspace_dev, workspace_bytes, stream);
+}
+int svt_video_forward_u8(svt_video* v, const uint8_t* roi_dev, int32_t batch, int32_t t, int32_t h_in, int32_t w_in,
+                         const svt_video_transform* tf, float* out_dev, int64_t out_ld, int32_t zero_left, void* workspace_dev,
+                         size_t workspace_bytes, void* stream) {
+  if (!tf || !roi_dev) { set_error("svt_video_forward_u8: null argument"); return SVT_ERR_INVALID; }
+  if (tf->crop_h < 8 || tf->crop_w < 8 || tf->crop_h > h_in || tf->crop_w > w_in) {
+    set_error("svt_video_forward_u8: the crop must lie inside the ROI (CenterCrop of a smaller frame is not defined by the reference)"); return SVT_ERR_INVALID; }
+  if (tf->div0 == 0.0 || tf->std == 0.0) { set_error("svt_video_forward_u8: zero divisor in the transform"); return SVT_ERR_INVALID; }
+  // CenterCrop (N20EMv2/video_only/utils.py:79-83): delta = int(round(w - tw) / 2.) -- truncation of a non-negative half
+  const int dx = (w_in - tf->crop_w) / 2, dy = (h_in - tf->crop_h) / 2;
+  const VideoTransform vt{tf->sub0, tf->div0, tf->mean, tf->std};
+  return video_forward_impl(v, nullptr, roi_dev, h_in, w_in, dy, dx, &vt, batch, t, tf->crop_h, tf->crop_w, out_dev, out_ld, zero_left, workspace_dev,
+                            workspace_bytes, stream);
 }
 
 // ---- Fbank add-ons ----

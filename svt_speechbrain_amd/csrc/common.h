@@ -206,6 +206,7 @@ struct GemmArgs {
   int act = ACT_NONE;
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
+  int walk_pm = 0;  // persistent kernels' tile walk (tile_walk below): 0 = n fastest, > 0 = panels of this many tile rows (set by gemm_walk_pm)
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
   int raster_gm = 8;  // set by the register-staged launcher: M-tiles per band of the block -> tile map (gemm.hip)
   // ---- generalised addressing / epilogue (gen = 1): 2-D convolution as implicit GEMM over a zero-padded
@@ -261,6 +262,24 @@ bool gemm_x3q_eligible(const GemmArgs& a);
 int launch_gemm_x3q(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);
 int launch_gemm_p1x(int kind, const GemmArgs& a, const void* packed, int bm, hipStream_t s);   // gemm_p1x.hip: the same product, one wave per SIMD (K >= 96)
 extern int g_gemm_p1x;   // svt_debug_set key 30
+extern int g_gemm_walk;  // svt_debug_set key 34: -1 (default) = choose per launch (gemm_walk_pm), 0 = always n fastest, > 0 = this panel height
+// Tile walk of the persistent GEMM kernels (gemm_p1w / gemm_pps): logical tile index -> (tile_m, tile_n).  Blocks b and b + 8 share an XCD
+// and an XCD works on 32 consecutive logical tiles per round, so the walk decides what an XCD's L2 has to hold:
+//   pm == 0: n fastest -- 32 tiles = a few whole rows of tiles: every A row block is fetched by ONE XCD, all of W by every XCD in every
+//            round.  Right while W (N x K) stays resident in the XCD's 4 MiB L2 (every shape of the base model but FFN-1).
+//   pm  > 0: panels of pm tile rows walked column by column (m fastest inside a column) -- 32 tiles = pm rows x 32 / pm columns: an
+//            XCD round fetches pm A blocks + 32 / pm W blocks instead of ~32 / tiles_n A blocks + ALL tiles_n W blocks.  For the large
+//            models' FFN-1 (N = 4096, K = 1024: W = 8 MiB, twice the L2) that is 6 MiB instead of 9 MiB per XCD and round, for a square
+//            8192 problem 48 instead of 132 (what the vendor library's kernel name calls WGM / SKXCCM: profiles/r06_gemm_tile_walk.txt).
+__device__ __forceinline__ void tile_walk(int logical, int tiles_m, int tiles_n, int pm, int& tile_m, int& tile_n) {
+  if (pm <= 0) { tile_n = logical % tiles_n; tile_m = logical / tiles_n; return; }
+  const int per_panel = pm * tiles_n;
+  const int pnl = logical / per_panel, rem = logical - pnl * per_panel;
+  const int rows = min(pm, tiles_m - pnl * pm);      // the last panel may be shorter
+  tile_n = rem / rows;
+  tile_m = pnl * pm + (rem - tile_n * rows);
+}
+int gemm_walk_pm(const GemmArgs& a, int bm);   // gemm_dma.hip: the panel height for this launch (0 = n fastest)
 extern int g_x3_pairs;  // 1 (default): the split modes keep product operands as pair rows; 0: fp32 activations cut inside the product kernels (svt_debug_set key 19)
 extern int g_ln_two_rows;  // (hi, lo) LayerNorm: half a wave per row, 16-byte accesses (1, default) or a wave per row (0)
 extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged split kernel only (svt_debug_set key 11)
@@ -395,6 +414,10 @@ int launch_relpos_gate(int prec, const void* u, int64_t rows, int T, int H, int 
 int launch_scores_add_relbias(float* S, int64_t BH, int H, int T, int Tp, const float* gate, const float* pb, hipStream_t s);
 // lip front-end (video.hip)
 int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int Hp, int Wp, void* out, hipStream_t s);
+// the recipe's uint8 -> float32 pixel map, ((u - sub0) / div0 - mean) / std in float64 (video.hip, svt_video_forward_u8)
+struct VideoTransform { double sub0, div0, mean, std; };
+int launch_video_pad_u8(int prec, const unsigned char* v, int B, int T, int Hin, int Win, int dy, int dx, int H, int W, int Hp, int Wp,
+                        const VideoTransform& tf, void* out, hipStream_t s);
 int launch_conv3d_front(int prec, const void* vp, const void* w, const float* bias, const float* slope, long F, int T, int Hp,
                         int Wp, int H0, int W0, void* out, hipStream_t s);
 int launch_maxpool_3x3s2(int prec, const void* in, long F, int H0, int W0, int C, int H1, int W1, void* out, hipStream_t s);

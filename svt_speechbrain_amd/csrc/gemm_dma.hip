@@ -1161,6 +1161,16 @@ void split_weights_forget(const void* w_f32) {
 }
 // launches the LDS-DMA split kernel when `a` is a plain (un-batched) product against a registered weight matrix; returns
 // 1 when the caller has to use the register-staged split kernel instead, 0 on success, < 0 on error
+// svt_debug_set key 34 (tile_walk, common.h).  The automatic choice: panels when W does not fit an XCD's L2 beside the A stream and the
+// problem has enough columns of tiles to form them.
+int g_gemm_walk = -1;
+int gemm_walk_pm(const GemmArgs& a, int bm) {
+  if (g_gemm_walk >= 0) return g_gemm_walk;
+  const int tiles_n = a.N / 256, tiles_m = (a.M + bm - 1) / bm;
+  const double w_bytes = (double)a.N * a.K * 2.0;
+  if (tiles_n < 8 || tiles_m < 16 || w_bytes <= 3.0 * 1024 * 1024) return 0;
+  return 8;
+}
 int g_x3_pairs = 1;
 int launch_gemm_x3(int kind, const GemmArgs& a, hipStream_t s) {
   if (a.a_pairs) {

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   const int lbase = (b & 7) * per + (b >> 3);
   if (lbase >= ntiles) return;
   const int my_tiles = (ntiles - lbase + nblk - 1) / nblk;
+  const int tiles_m = ntiles / tiles_n;
+  auto tile_col = [&](int logical) -> int { int tm, tn; tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tm, tn); return tn; };
 
   const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W;
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   const long w_col = (long)p.ldw * 2;   // bytes per output column of W
   const bool plain_a = p.a_rpb >= p.M;
   auto setup = [&](int logical, unsigned (&ao)[GA], unsigned& wo) {
-    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    int tile_n, tile_m;
+    tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
   for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (has_bias) {
-    const float* bp = p.bias + ((lbase % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+    const float* bp = p.bias + (tile_col(lbase) * BN + wn * 128 + (lane & 15) * 8);
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                  : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
   }
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   static_assert(GA + STORES_AFTER_W <= 63 && GA + GW <= 63, "vmcnt holds 6 bits");
   auto kstep_last = [&](int rs, bool ev, const char* srcA, int slotA, const char* srcW, int slotW) {
     const int logical = ti * nblk + lbase;
-    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    int tile_n, tile_m;
+    tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const long rows_left = (long)p.M - m0;
     const unsigned long nbytes = (unsigned long)rows_left * p.ldc * 2;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
       if (has_bias) {
         // the NEXT tile's bias: fetched in front of this k-step's requests, so that the counted wait of the barrier -- which leaves only
         // those requests in flight -- covers it
-        const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+        const float* bp = p.bias + (tile_col(ti + 1 < my_tiles ? (ti + 1) * nblk + lbase : lbase) * BN + wn * 128 + (lane & 15) * 8);
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                      : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
       }
@@ -359,11 +363,13 @@ int launch_p1w_t(const GemmArgs& a, hipStream_t s) {
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
+  GemmArgs aw = a;
+  aw.walk_pm = gemm_walk_pm(a, BM);
   if (int r_ = ensure_dyn_lds((const void*)gemm_p1w_kernel<BM, ACT, TR>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_p1w_kernel<BM, ACT, TR>), dim3(nblk), dim3(256), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_p1w_kernel<BM, ACT, TR>), dim3(nblk), dim3(256), lds_bytes, s, aw, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   const int lbase = (b & 7) * per + (b >> 3);
   if (lbase >= ntiles) return;
   const int my_tiles = (ntiles - lbase + nblk - 1) / nblk;
+  const int tiles_m = ntiles / tiles_n;
+  auto tile_col = [&](int logical) -> int { int tm, tn; tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tm, tn); return tn; };
 
   const char* gA = (const char*)p.A;
   const char* gW = (const char*)p.W;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
   unsigned aofE[GA], wofE[GW], aofO[GA], wofO[GW];
   const bool plain_a = p.a_rpb >= p.M;
   auto setup = [&](int logical, unsigned (&ao)[GA], unsigned (&wo)[GW]) {
-    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    int tile_n, tile_m;
+    tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
   for (int j = 0; j < 2; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (has_bias) {
-    const float* bp = p.bias + ((lbase % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+    const float* bp = p.bias + (tile_col(lbase) * BN + wn * 128 + (lane & 15) * 8);
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                  : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
   }
@@ -197,7 +200,8 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
     long long t_e0 = 0;
     if (tr) t_e0 = wall_clock64();
     const int logical = ti * nblk + lbase;
-    const int tile_n = logical % tiles_n, tile_m = logical / tiles_n;
+    int tile_n, tile_m;
+    tile_walk(logical, tiles_m, tiles_n, p.walk_pm, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     // descriptor over the rows [m0, M) of C: a row >= M lands beyond num_records and is dropped by the memory pipeline
     const long rows_left = (long)p.M - m0;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
             dma(w_even ? wofE[i2] : wofO[i2], wb, lds_unit(wslot, i2));                                             \
       }                                                                                                             \
       if (half_ == 1 && last_k && has_bias) {                                                                       \
-        const float* bp = p.bias + ((((ti + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);       \
+        const float* bp = p.bias + (tile_col(ti + 1 < my_tiles ? (ti + 1) * nblk + lbase : lbase) * BN + wn * 128 + (lane & 15) * 8);       \
         /* read-write operands: the loaded value stays in the registers bq already lives in, so the join behind this conditional   \
            block needs no copy of a register whose data has not landed yet (the compiler cannot see the counted wait that covers  \
            these loads); the epilogue re-defines bq behind that wait before its first use */                                  \
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p, int tiles_n, 
       const char* ab = gA + (long)(a_cur ? kt_ + 2 : kt_ + 2 - nk) * (BK * 2);
       const int aslot = a0_ + 2 >= 3 ? a0_ - 1 : a0_ + 2;
       if (kt_ + 1 == nk && has_bias) {   // the next tile's bias: older than this interval's requests, covered by the wait in front of M_g
-        const float* bp = p.bias + ((((ti_ + 1) * nblk + lbase) % tiles_n) * BN + wn * 128 + (lane & 15) * 8);
+        const float* bp = p.bias + (tile_col(ti_ + 1 < my_tiles ? (ti_ + 1) * nblk + lbase : lbase) * BN + wn * 128 + (lane & 15) * 8);
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                      : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
       }
@@ -571,11 +575,13 @@ int launch_pps_t(const GemmArgs& a, hipStream_t s) {
   const int ntiles = tiles_m * tiles_n;
   const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
   const size_t lds_bytes = 5 * 32768;
+  GemmArgs aw = a;
+  aw.walk_pm = gemm_walk_pm(a, BM);
   if (int r_ = ensure_dyn_lds((const void*)gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB, TWO>, (int)lds_bytes)) return r_;
   const double flops = 2.0 * a.M * (double)a.N * a.K;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 + (double)a.M * a.N * 2;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB, TWO>), dim3(nblk), dim3(512), lds_bytes, s, a, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_pps_kernel<BM, ACT, STAUX, STAMP, HB, TWO>), dim3(nblk), dim3(512), lds_bytes, s, aw, tiles_n, ntiles);
   prof_end(s, flops, bytes, 0);
   SVT_LAUNCH_CHECK();
   return 0;

@@ -69,6 +69,66 @@ __global__ void video_pad8_kernel(const float* v, int B, int Tt, int H, int W, i
   }
 }
 
+// ---- the recipe's input side (round 6): uint8 lip ROI -> cropped, normalised, padded operand in ONE pass ----
+// Replaces transform_eval of N20EMv2/video_only/train_video_ssl.py:445-457 -- Normalize(0, 255) -> CenterCrop((88, 88)) ->
+// Normalize(0.421, 0.165) on the np.load'ed uint8 frames, then .astype(np.float32) (:530-533) -- in front of video_pad*_kernel.  numpy
+// evaluates ((u - sub0) / div0 - mean) / std in float64 and rounds ONCE to float32; a uint8 pixel has 256 values, so every workgroup
+// builds the 256-entry table in LDS with the same four IEEE float64 operations (bit-identical to numpy; tests/golden/video_u8.pt) and
+// the pass reads one byte per pixel instead of four.
+__device__ __forceinline__ void build_u8_table(float* lut, VideoTransform tf) {
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) lut[i] = (float)((((double)i - tf.sub0) / tf.div0 - tf.mean) / tf.std);
+  __syncthreads();
+}
+// roi (B,T,Hin,Win) uint8; output pixel (y, x) of the H x W crop = roi pixel (y + dy, x + dx)
+template <typename T>
+__global__ __launch_bounds__(256) void video_pad_u8_kernel(const unsigned char* v, int B, int Tt, int Hin, int Win, int dy, int dx, int H, int W,
+                                                          int Hp, int Wp, VideoTransform tf, T* out) {
+  __shared__ float lut[256];
+  build_u8_table(lut, tf);
+  const long n = (long)B * (Tt + 4) * Hp * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp);
+    long r = i / Wp;
+    const int yp = (int)(r % Hp);
+    r /= Hp;
+    const int tp = (int)(r % (Tt + 4));
+    const int b = (int)(r / (Tt + 4));
+    const int x = xp - 4, y = yp - 3, t = tp - 2;
+    float val = 0.f;
+    if (x >= 0 && x < W && y >= 0 && y < H && t >= 0 && t < Tt) val = lut[v[(((long)b * Tt + t) * Hin + y + dy) * Win + x + dx]];
+    out[i] = from_f32<T>(val);
+  }
+}
+// 16-bit modes, Wp % 8 == 0: 8 output pixels (one 16-byte store) per thread
+__global__ __launch_bounds__(256) void video_pad8_u8_kernel(const unsigned char* v, int B, int Tt, int Hin, int Win, int dy, int dx, int H, int W,
+                                                           int Hp, int Wp, VideoTransform tf, bf16_t* out) {
+  __shared__ float lut[256];
+  build_u8_table(lut, tf);
+  const int Wg = Wp >> 3;
+  const long n = (long)B * (Tt + 4) * Hp * Wg;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % Wg);
+    long r = i / Wg;
+    const int yp = (int)(r % Hp);
+    r /= Hp;
+    const int tp = (int)(r % (Tt + 4));
+    const int b = (int)(r / (Tt + 4));
+    const int x0 = g * 8 - 4, y = yp - 3, t = tp - 2;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    if (y >= 0 && y < H && t >= 0 && t < Tt) {
+      const unsigned char* row = v + (((long)b * Tt + t) * Hin + y + dy) * Win + dx;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int x = x0 + j;
+        if (x >= 0 && x < W) o[j] = (bf16_t)lut[row[x]];
+      }
+    }
+    *(bf16x8*)(out + i * 8) = o;
+  }
+}
+
 // exact-fp32 stem (parity mode): one thread per (pixel, channel); w is [35*8][64] (k-major), BN scale folded
 __global__ __launch_bounds__(256) void conv3d_front_f32_kernel(const float* vp, const float* w, const float* bias,
                                                                const float* slope, int Tt, int Hp, int Wp, int H0, int W0,
@@ -424,6 +484,17 @@ int launch_video_pad(int prec, const float* v, int B, int T, int H, int W, int H
     hipLaunchKernelGGL(video_pad8_kernel, dim3(grid_of(n / 8)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (bf16_t*)out);
   else if (prec) hipLaunchKernelGGL(video_pad_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (bf16_t*)out);
   else hipLaunchKernelGGL(video_pad_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, H, W, Hp, Wp, (float*)out);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_video_pad_u8(int prec, const unsigned char* v, int B, int T, int Hin, int Win, int dy, int dx, int H, int W, int Hp, int Wp,
+                        const VideoTransform& tf, void* out, hipStream_t s) {
+  const long n = (long)B * (T + 4) * Hp * Wp;
+  if (prec && Wp % 8 == 0)
+    hipLaunchKernelGGL(video_pad8_u8_kernel, dim3(grid_of(n / 8)), dim3(256), 0, s, v, B, T, Hin, Win, dy, dx, H, W, Hp, Wp, tf, (bf16_t*)out);
+  else if (prec) hipLaunchKernelGGL(video_pad_u8_kernel<bf16_t>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, Hin, Win, dy, dx, H, W, Hp, Wp, tf, (bf16_t*)out);
+  else hipLaunchKernelGGL(video_pad_u8_kernel<float>, dim3(grid_of(n)), dim3(256), 0, s, v, B, T, Hin, Win, dy, dx, H, W, Hp, Wp, tf, (float*)out);
   SVT_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,11 @@
   concatenated over the song, ``frame2note`` once at the last utterance (``:85-107``);
 * the stage-1 feature writer of ``N20EMv2/audio_only/extract_ssl_feats.py:102-116``: per-utterance ``feats[0]``
   concatenated along time and ``torch.save``d as ``<folder>/noise_data/clean_feats.pt`` (or
-  ``noise_data/<type>/SNR_<db>dB_feats.pt``) — the input of the audio-visual recipe.
+  ``noise_data/<type>/SNR_<db>dB_feats.pt``) — the input of the audio-visual recipe;
+* its video twin, ``N20EMv2/video_only/extract_ssl_feats.py:28-36,99-111``: the song's lip ROI (``np.load``: ``(T, H, W)`` uint8),
+  ``transform_eval``, utterances of ``dur_threshold`` seconds at the video's ``sample_rate`` (50 frames/s; bounds as for the audio,
+  ``train_video_ssl.py:537-546``), batch-1 AV-HuBERT forwards, ``feats[0]`` concatenated and saved as
+  ``<folder>/noise_data/video_feats.pt`` (``song_video_features`` / ``save_song_video_features``).
 """
 from __future__ import annotations
 
@@ -125,3 +129,30 @@ def save_song_features(feats: torch.Tensor, song_folder: str, add_noise: bool = 
     os.makedirs(os.path.dirname(path), exist_ok=True)
     torch.save(feats.detach().cpu(), path)
     return path
+
+
+def video_feature_path(song_folder: str) -> str:
+    """``os.path.join(dirname(video_path), "noise_data", "video_feats.pt")`` (N20EMv2/video_only/extract_ssl_feats.py:104-110)."""
+    return os.path.join(song_folder, "noise_data", "video_feats.pt")
+
+
+def save_song_video_features(feats: torch.Tensor, song_folder: str) -> str:
+    path = video_feature_path(song_folder)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(feats.detach().cpu(), path)
+    return path
+
+
+@torch.no_grad()
+def song_video_features(encoder, roi: torch.Tensor, frame_rate: int = 50, dur_threshold: float = 5.0, transform=None) -> torch.Tensor:
+    """Per-song video features as the reference's extraction pass computes them (extract_ssl_feats.py:28-36, 99-107): ``roi`` is the
+    song's ``(T, H, W)`` **uint8** lip ROI on the GPU (what ``np.load(video)`` returns); utterance ``i`` of ``round(T / (rate * dur))``
+    covers frames ``round((i-1) * rate * dur) : round(i * rate * dur)`` (the last one runs to the end); each goes through ``encoder``
+    (``FairseqAVHubertPretrain``) as a batch of ONE -- the wrapper's whole-tensor output norm is per utterance, as in the reference's
+    batch-1 evaluation -- with ``transform_eval`` applied inside the front-end's padding kernel; returns the ``(T, D)`` concatenation."""
+    if roi.dim() != 3 or roi.dtype != torch.uint8:
+        raise ValueError(f"expected the (T, H, W) uint8 lip ROI of one song, got {tuple(roi.shape)} {roi.dtype}")
+    out = []
+    for lo, hi in utterance_bounds(roi.shape[0], frame_rate, dur_threshold):
+        out.append(encoder({"video": roi[lo:hi].unsqueeze(0), "audio": None, "transform": transform})[0])
+    return torch.cat(out, dim=0)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from typing import Optional
 
 import torch
 from torch import nn
@@ -20,6 +21,31 @@ from . import _lib
 from ._device import DeviceObjects, ReplicaAware
 from .huggingface_interface import ParamTree, PRECISIONS, LIB_VARIANT
 from .weights import seeded_video_frontend_state_dict
+
+
+class EvalTransform:
+    """``transform_eval`` of the video recipes (``N20EMv2/video_only/train_video_ssl.py:445-457``): ``Normalize(0.0, 255.0)`` ->
+    ``CenterCrop((88, 88))`` -> ``Normalize(0.421, 0.165)`` on the ``np.load``-ed uint8 frames, then ``.astype(np.float32)`` (:530-533).
+    Passed to the lip front-end together with the RAW uint8 ROI, it runs inside the padding kernel (``svt_video_forward_u8``): one byte
+    per pixel crosses HBM instead of four, and no host pass touches the frames.  ``__call__`` is the host restatement (numpy, float64
+    like the reference) for callers that still want the float tensor."""
+
+    def __init__(self, crop=(88, 88), image_mean: float = 0.421, image_std: float = 0.165, scale_sub: float = 0.0, scale_div: float = 255.0):
+        self.crop_h, self.crop_w = int(crop[0]), int(crop[1])
+        self.sub0, self.div0, self.mean, self.std = float(scale_sub), float(scale_div), float(image_mean), float(image_std)
+
+    def offsets(self, h: int, w: int):
+        if h < self.crop_h or w < self.crop_w:
+            raise ValueError(f"CenterCrop({self.crop_h}, {self.crop_w}) of a {h} x {w} frame")
+        return int(round(h - self.crop_h) / 2.0), int(round(w - self.crop_w) / 2.0)     # utils.py:79-83
+
+    def __call__(self, frames):
+        import numpy as np
+        f = np.asarray(frames)
+        dy, dx = self.offsets(f.shape[-2], f.shape[-1])
+        f = (f - self.sub0) / self.div0
+        f = f[..., dy:dy + self.crop_h, dx:dx + self.crop_w]
+        return ((f - self.mean) / self.std).astype(np.float32)
 
 
 class SubModel(ReplicaAware, nn.Module):
@@ -88,23 +114,53 @@ class SubModel(ReplicaAware, nn.Module):
         slot.sig = sig
         return slot
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, transform: "Optional[EvalTransform]" = None) -> torch.Tensor:
+        return self.forward_into(x, None, transform).transpose(1, 2)  # (B, embed_dim, T), the reference's layout
+
+    def forward_into(self, x: torch.Tensor, fused: Optional[torch.Tensor] = None, transform: "Optional[EvalTransform]" = None) -> torch.Tensor:
+        """The front-end on ``x`` -- a ``(B, 1, T, H, W)`` float tensor already normalised (what the reference's ``SubModel`` takes), or the
+        raw ``(B, T, H, W)`` / ``(B, 1, T, H, W)`` / ``(B, T, H, W, 1)`` **uint8** lip ROI, in which case ``transform`` (default: the recipes'
+        ``transform_eval``) is applied inside the padding kernel.  Returns ``(B, T, embed_dim)``; with ``fused`` -- an uninitialised
+        ``(B, T, 2 * embed_dim)`` fp32 buffer -- the result is written into its right half and the left half is zeroed by the same C-ABI
+        call (AV-HuBERT's ``cat([zeros, video], -1)``, ``hubert.py:700-712``), and ``fused`` is returned."""
         if not x.is_cuda:
             raise _lib.SvtError("the lip front-end needs its input on the GPU; there is no CPU fallback")
-        if x.dim() != 5 or x.shape[1] != 1:
-            raise ValueError(f"expected a (B, 1, T, H, W) lip ROI tensor, got {tuple(x.shape)}")
-        B, _, T, H, W = x.shape
+        u8 = x.dtype == torch.uint8
+        if u8 and x.dim() == 5 and x.shape[-1] == 1 and x.shape[1] != 1:
+            x = x[..., 0]                         # (B, T, H, W, 1): the recipe's batch.sig before its permute
+        if u8 and x.dim() == 5 and x.shape[1] == 1:
+            x = x[:, 0]
+        if (u8 and x.dim() != 4) or (not u8 and (x.dim() != 5 or x.shape[1] != 1)):
+            raise ValueError(f"expected a (B, 1, T, H, W) float lip ROI or a (B, T, H, W) uint8 one, got {tuple(x.shape)} {x.dtype}")
+        if transform is not None and not u8:
+            raise ValueError("transform applies to the raw uint8 ROI; a float tensor is taken as already normalised")
+        B, T = (x.shape[0], x.shape[1]) if u8 else (x.shape[0], x.shape[2])
+        Hin, Win = x.shape[-2], x.shape[-1]
+        tf = (transform or EvalTransform()) if u8 else None
+        H, W = (tf.crop_h, tf.crop_w) if u8 else (Hin, Win)
         lib = _lib.load(LIB_VARIANT.get(self.precision))
         slot = self._sync(x.device)
-        v = x.detach().to(torch.float32).contiguous()
+        v = x.detach().contiguous() if u8 else x.detach().to(torch.float32).contiguous()
         need = lib.svt_video_workspace_bytes(slot.handle, B, T, H, W)
         if need < 0:
             raise ValueError(f"unsupported geometry {tuple(x.shape)}")
         ws = slot.workspace(need, v.device)
-        out = torch.empty((B, T, self.embed_dim), dtype=torch.float32, device=v.device)
-        _lib.check(lib.svt_video_forward(slot.handle, _lib.ptr(v), B, T, H, W, _lib.ptr(out), _lib.ptr(ws),
-                                         ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward", lib)
-        return out.transpose(1, 2)  # (B, embed_dim, T), the reference's layout
+        E = self.embed_dim
+        if fused is not None:
+            if fused.shape != (B, T, 2 * E) or fused.dtype != torch.float32 or not fused.is_contiguous() or fused.device != v.device:
+                raise ValueError(f"fused must be a contiguous fp32 (B, T, 2 * embed_dim) tensor on {v.device}")
+            out, out_ptr, ld, zl = fused, fused.data_ptr() + 4 * E, 2 * E, E
+        else:
+            out = torch.empty((B, T, E), dtype=torch.float32, device=v.device)
+            out_ptr, ld, zl = out.data_ptr(), E, 0
+        if u8:
+            tc = _lib.VideoTransformC(tf.sub0, tf.div0, tf.mean, tf.std, tf.crop_h, tf.crop_w)
+            _lib.check(lib.svt_video_forward_u8(slot.handle, _lib.ptr(v), B, T, Hin, Win, C.byref(tc), C.c_void_p(out_ptr), ld, zl,
+                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward_u8", lib)
+        else:
+            _lib.check(lib.svt_video_forward_ex(slot.handle, _lib.ptr(v), B, T, H, W, C.c_void_p(out_ptr), ld, zl, _lib.ptr(ws),
+                                                ws.numel(), _lib.stream_ptr(v.device)), "svt_video_forward_ex", lib)
+        return out
 
 
 VideoFrontend = SubModel
@@ -237,11 +293,15 @@ class FairseqAVHubertPretrain(ReplicaAware, nn.Module):
             raise ValueError('expected {"video": (B,1,T,H,W) tensor, "audio": None}')
         if wav.get("audio") is not None:
             raise NotImplementedError("the recipes feed AV-HuBERT the video modality only (audio=None)")
-        video = wav["video"]
-        fv = self.model.feature_extractor_video(video)            # (B, E, T) view of a (B, T, E) buffer
-        B, E, T = fv.shape
-        feats = torch.zeros((B, T, 2 * E), dtype=torch.float32, device=fv.device)
-        feats[:, :, E:] = fv.transpose(1, 2)                       # audio half = zeros (hubert.py:700-702)
+        video = wav["video"]            # (B, 1, T, H, W) float, normalised -- or the raw uint8 ROI (transform_eval runs in the kernel)
+        fe = self.model.feature_extractor_video
+        E = fe.embed_dim
+        u8 = video.dtype == torch.uint8
+        B = video.shape[0]
+        T = video.shape[1] if (u8 and not (video.dim() == 5 and video.shape[1] == 1)) else video.shape[2]
+        # cat([zeros (absent audio), video], -1) (hubert.py:700-712) written in place by the front-end's own call: its projection stores
+        # rows with pitch 2E into the right half, one 2-D memset node zeroes the left half -- no torch fill / strided copy
+        feats = fe.forward_into(video, torch.empty((B, T, 2 * E), dtype=torch.float32, device=video.device), wav.get("transform"))
         lib = _lib.load(LIB_VARIANT.get(self.precision))
         slot = self._sync(feats.device)
         need = lib.svt_encoder_workspace_bytes(slot.handle, B, T)

@@ -392,6 +392,42 @@ def make_video_front_cases():
     torch.save(out, os.path.join(HERE, "video_front.pt"))
 
 
+def make_video_u8_cases():
+    """The video recipes' input side, by the reference's own classes: ``Compose([Normalize(0.0, 255.0), CenterCrop((88, 88)),
+    Normalize(0.421, 0.165)])`` (N20EMv2/video_only/train_video_ssl.py:445-457, classes of N20EMv2/video_only/utils.py:22-84; cv2 --
+    imported by that file for its video reader only -- is stubbed) applied to uint8 ROIs the way utterance_eval_pipeline does
+    (:528-533: transform, expand_dims, astype(np.float32)), then the reference's SubModel on the result.  Cases: the recipes' 96 x 96
+    ROI, an odd-sized one (97 x 99: CenterCrop's truncating offsets), a ROI that is already 88 x 88, and every byte value at once."""
+    import importlib.util
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("ref_video_utils", REF + "/N20EMv2/video_only/utils.py")
+    ut = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ut)
+    spec = importlib.util.spec_from_file_location("ref_video_resnet", REF + "/N20EMv2/video_only/resnet.py")
+    res = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(res)
+    transform_eval = ut.Compose([ut.Normalize(0.0, 255.0), ut.CenterCrop((88, 88)), ut.Normalize(0.421, 0.165)])
+    E, seed = 64, 5186
+    sd = W.seeded_video_frontend_state_dict(E, seed=seed)
+    m = res.SubModel(512, E, "prelu").eval()
+    m.load_state_dict(sd, strict=True)
+    out = {}
+    rng = np.random.RandomState(86)
+    for name, T, H, Wd in [("roi96", 6, 96, 96), ("roi97x99", 3, 97, 99), ("roi88", 2, 88, 88), ("ramp", 2, 96, 96)]:
+        roi = rng.randint(0, 256, size=(T, H, Wd)).astype(np.uint8)
+        if name == "ramp":   # every byte value, many times, inside the crop
+            roi = (np.arange(T * H * Wd, dtype=np.int64) % 256).astype(np.uint8).reshape(T, H, Wd)
+        sig = transform_eval(roi)
+        sig = np.expand_dims(sig, axis=-1)
+        sig = torch.from_numpy(sig.astype(np.float32))                     # (T, 88, 88, 1)
+        video = sig.unsqueeze(0).permute(0, 4, 1, 2, 3).contiguous()       # extract_ssl_feats.py:34 -> (1, 1, T, 88, 88)
+        with torch.no_grad():
+            y = m(video).transpose(1, 2).contiguous()                      # (1, T, E)
+        out[name] = dict(roi=torch.from_numpy(roi.copy()), sig=sig[..., 0].clone(), feats=y, E=E, weight_seed=seed, sd_sha256=sd_digest(sd))
+        print("video_u8", name, tuple(sig.shape), float(sig.mean()), tuple(y.shape))
+    torch.save(out, os.path.join(HERE, "video_u8.pt"))
+
+
 def import_reference_video():
     """``N20EMv2/video_only/hubert.py`` and ``fairseq_interface.py`` THEMSELVES, with the third-party names they import at module
     level (fairseq.*, omegaconf -- absent from the build container) stubbed in ``sys.modules`` for the duration of the import.
@@ -655,6 +691,7 @@ def main():
         "losses": make_loss_cases,
         "video_front": make_video_front_cases,
         "video_glue": make_video_glue_cases,
+        "video_u8": make_video_u8_cases,
         "dataio": make_dataio_cases,
         "fbank_ext": make_fbank_ext_cases,
         "ckpt_tree": lambda: make_ckpt_tree(hi),

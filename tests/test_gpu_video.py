@@ -258,3 +258,105 @@ def test_avhubert_per_clip_norm_batch_equals_batch1():
     whole = m({"video": video, "audio": None})
     assert (batched - one).abs().max().item() < 1e-5
     assert (whole - one).abs().max().item() > 1e-3
+
+
+# ---- the recipe's input side (round 6): uint8 ROI -> transform_eval inside the padding kernel (svt_video_forward_u8) ----
+U8_CASES = ["roi96", "roi97x99", "roi88", "ramp"]
+
+
+def _u8_model(fx, precision):
+    m = SubModel(512, fx["E"], "prelu", precision=precision, seed=1)
+    m.load_state_dict(W.seeded_video_frontend_state_dict(fx["E"], seed=fx["weight_seed"]), strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", U8_CASES)
+def test_u8_input_transform_is_bit_identical_to_the_reference(golden, name):
+    """The padded operand the stem reads, written by video_pad_u8_kernel from the RAW uint8 ROI (exact-fp32 mode: fp32 pixels at
+    (t + 2, y + 3, x + 4) of the workspace's first region, zeros elsewhere), against what the reference's own
+    Compose([Normalize(0, 255), CenterCrop((88, 88)), Normalize(0.421, 0.165)]) + astype(float32) made of the same bytes
+    (tests/golden/video_u8.pt): every bit.  Then the features against the reference SubModel's on its transformed frames."""
+    fx = golden("video_u8")[name]
+    m = _u8_model(fx, "fp32")
+    roi = fx["roi"].to(DEV)                                    # (T, H, W) uint8, as np.load gives it
+    y = m.forward_into(roi.unsqueeze(0))                      # (1, T, E)
+    slot = m._sync(torch.device(DEV))
+    T = roi.shape[0]
+    Hp, Wp = 88 + 6, ((88 + 8 + 7) // 8) * 8
+    torch.cuda.synchronize()
+    vp = slot.ws[:(T + 4) * Hp * Wp * 4].view(torch.float32).view(T + 4, Hp, Wp).cpu()
+    inner = vp[2:T + 2, 3:3 + 88, 4:4 + 88]
+    assert torch.equal(inner.view(torch.int32), fx["sig"].view(torch.int32)), "transform_eval in the kernel differs from numpy's bits"
+    halo = vp.clone()
+    halo[2:T + 2, 3:3 + 88, 4:4 + 88] = 0
+    assert not halo.any()
+    ref = fx["feats"]
+    assert (y.cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "fp16x3"])
+@pytest.mark.parametrize("name", U8_CASES)
+def test_u8_path_equals_float_path_on_the_references_transformed_frames(golden, name, precision):
+    """Same model, two inputs: the raw uint8 ROI (transform in the kernel, 1 byte per pixel) and the reference's transformed float32
+    frames through the float entry point (4 bytes per pixel).  The padded operand is the same, so the features are bit-identical in
+    every precision; accepted layouts: (B, T, H, W), (B, 1, T, H, W) and the recipe's (B, T, H, W, 1)."""
+    fx = golden("video_u8")[name]
+    m = _u8_model(fx, precision)
+    roi = fx["roi"].to(DEV)
+    a = m.forward_into(roi.unsqueeze(0)).clone()
+    b = m.forward_into(fx["sig"].to(DEV)[None, None]).clone()             # (1, 1, T, 88, 88) float
+    assert torch.equal(a, b)
+    assert torch.equal(m.forward_into(roi[None, None]), a) and torch.equal(m.forward_into(roi[None, ..., None]), a)
+    assert torch.equal(m(roi.unsqueeze(0)), a.transpose(1, 2))              # the reference's (B, E, T) layout
+    with pytest.raises(ValueError):
+        m.forward_into(fx["sig"].to(DEV)[None, None], transform=S.EvalTransform())   # a float tensor is already normalised
+    with pytest.raises(_lib.SvtError):
+        m.forward_into(roi[:, :80, :80].contiguous().unsqueeze(0))                   # CenterCrop(88) of an 80 x 80 frame
+
+
+def test_fused_concat_buffer_is_written_in_place(golden):
+    """cat([zeros, video], -1) of AV-HuBERT's concat fusion (hubert.py:700-712) written by the front-end's own call: right half = the
+    features (row pitch 2E), left half zeroed by the call's 2-D memset -- from a buffer full of NaNs, and identical to the plain call."""
+    fx = golden("video_u8")["roi96"]
+    for precision in ("fp32", "bf16"):
+        m = _u8_model(fx, precision)
+        roi = fx["roi"].to(DEV).unsqueeze(0).repeat(2, 1, 1, 1)
+        E, T = fx["E"], roi.shape[1]
+        plain = m.forward_into(roi).clone()
+        fused = torch.full((2, T, 2 * E), float("nan"), device=DEV)
+        out = m.forward_into(roi, fused)
+        assert out.data_ptr() == fused.data_ptr()
+        assert torch.equal(fused[..., E:], plain) and not fused[..., :E].any()
+        with pytest.raises(ValueError):
+            m.forward_into(roi, torch.empty((2, T, 2 * E + 1), device=DEV))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.35)])
+def test_avhubert_encoder_takes_the_raw_uint8_roi_and_writes_song_features(golden, tmp_path, prec, tol):
+    """FairseqAVHubertPretrain on {"video": uint8 ROI}: equal to the float path on the host-transformed frames (bit for bit: same
+    operand), and the per-song extraction pass (N20EMv2/video_only/extract_ssl_feats.py:28-36, 99-111): utterances of 5 s at 50
+    frames/s as batch-1 forwards, concatenated, saved as <song folder>/noise_data/video_feats.pt."""
+    from svt_speechbrain_amd.video import FairseqAVHubertPretrain
+    cfg = S.PRESETS["tiny-avhubert-video"]
+    m = FairseqAVHubertPretrain(config=cfg, precision=prec, seed=1, output_norm=True)
+    m.load_fairseq_model_state(W.seeded_avhubert_video_state_dict(cfg, seed=321))
+    m = m.to(DEV)
+    rng = torch.Generator().manual_seed(4)
+    song = torch.randint(0, 256, (560, 96, 96), generator=rng, dtype=torch.uint8)        # 11.2 s at 50 fps -> 2 utterances (250 + 310)
+    tf = S.EvalTransform()
+    bounds = S.utterance_bounds(560, 50, 5.0)
+    assert bounds == [(0, 250), (250, 560)]
+    want = []
+    for lo, hi in bounds:
+        fl = torch.from_numpy(tf(song[lo:hi].numpy()))[None, None].to(DEV)
+        want.append(m({"video": fl, "audio": None})[0])
+    want = torch.cat(want)
+    got = S.song_video_features(m, song.to(DEV))
+    assert got.shape == (560, cfg.hidden_size) and torch.equal(got, want)
+    path = S.save_song_video_features(got, str(tmp_path / "song_0001"))
+    assert path.endswith("song_0001/noise_data/video_feats.pt")
+    back = torch.load(path)
+    assert back.device.type == "cpu" and torch.equal(back, got.cpu())
+    # the recipe's own batch layout: batch.sig is (B, T, H, W, 1) before its permute (extract_ssl_feats.py:30-35)
+    one = m({"video": song[:250].to(DEV)[None, ..., None], "audio": None})
+    assert torch.equal(one[0], want[:250])

@@ -171,6 +171,30 @@ def test_oracle_video_frontend_matches_reference_golden(golden, name):
 # ---- §8 a15 / f2: the AV-HuBERT video branch through the reference's own glue (hubert.py:688-739 extract_finetune, :532-541,
 # :318-326; fairseq_interface.py:454-485 -- tests/golden/make_golden.py::make_video_glue_cases runs those methods themselves over the
 # real lip front-end and an HF encoder module standing where fairseq's TransformerEncoder stands) ----
+@pytest.mark.parametrize("name", ["roi96", "roi97x99", "roi88", "ramp"])
+def test_oracle_video_input_transform_matches_reference_golden(golden, name):
+    """tests/golden/video_u8.pt: the reference's own Compose([Normalize, CenterCrop, Normalize]) + astype(float32) on uint8 ROIs.  The
+    oracle's restatement and the product's host helper (svt_speechbrain_amd.video.EvalTransform.__call__) give the same BITS, and the
+    oracle front-end on the transformed frames gives the reference SubModel's features."""
+    import numpy as np
+    from svt_speechbrain_amd.video import EvalTransform
+    fx = golden("video_u8")[name]
+    roi = fx["roi"].numpy()
+    want = fx["sig"].numpy()
+    got = O.video_transform_eval(roi)
+    assert got.dtype == np.float32 and got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    tf = EvalTransform()
+    host = tf(roi)
+    assert host.dtype == np.float32 and np.array_equal(host.view(np.uint32), want.view(np.uint32))
+    assert tf.offsets(roi.shape[1], roi.shape[2]) == ((roi.shape[1] - 88) // 2, (roi.shape[2] - 88) // 2)
+    sd = W.seeded_video_frontend_state_dict(fx["E"], seed=fx["weight_seed"])
+    assert sd_digest(sd) == fx["sd_sha256"]
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        y = O.video_frontend_forward(sd, torch.from_numpy(got)[None, None])
+    assert (y - fx["feats"]).abs().max().item() < 2e-4 * max(1.0, fx["feats"].abs().max().item())
+
+
 @pytest.mark.parametrize("name", ["tiny_stable", "tiny_stable_t1", "tiny_postln"])
 def test_oracle_avhubert_video_glue_matches_reference_golden(golden, name):
     fx = golden("video_glue")[name]
