@@ -26,6 +26,8 @@ After the timed region (never part of `value`):
                       argmax differs, clips with identical note lists, note-level precision / recall (`parity`, `meets_north_star_parity`);
   * parity-grade leg -- the same workload in precision "fp16x3", the fast mode that meets the north star's tolerance
                       (`parity_grade`: clips/s, its own roofline fraction against 2.5 PF / 3, max |dlogit| vs the exact fp32 mode);
+  * trained-like leg -- the numeric modes on seeded synthetic singing with the head fitted to it (`trained_like`: frames, identical note
+                      lists, note F1 against the clips' ground truth: what 16-bit operands cost when decisions have margins);
   * cpu_baseline   -- the oracle on the host cores, SURVEY.md §8(d) protocol (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -618,6 +620,18 @@ def main():
                                 "one-stream replay with HIP events around every dense launch; max |logit - exact-fp32-mode logit| over the "
                                 "first clips of the batch"}
 
+    # trained-like leg (round 6, N = 1, default workload only): the numeric modes on seeded synthetic singing with the head FITTED to it
+    # (svt_speechbrain_amd/agreement.py, trained_like_study) -- what 16-bit operands cost when decisions have trained-like margins,
+    # in frames, identical note lists, and note-level F1 against the clips' ground truth.  After the timed region; ~3 s.
+    trained_like = None
+    if (world == 1 and not args.no_extra_legs and not args.no_parity_leg and args.model == "wav2vec2-base"
+            and os.path.exists(os.path.join(ROOT, "tests", "golden", "trained_like_head.pt"))):
+        from svt_speechbrain_amd.agreement import trained_like_study
+        modes = [args.precision] + [m for m in ("fp16", "fp16x3") if m != args.precision and args.precision == "bf16"]
+        t_tl = time.perf_counter()
+        trained_like = trained_like_study(dev, modes=[m for m in modes if m != "fp32"])
+        trained_like["seconds"] = round(time.perf_counter() - t_tl, 2)
+
     if rank == 0:
         clips_per_s = n_total * args.steps / elapsed
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -701,6 +715,8 @@ def main():
         if notes_out is not None:
             res_json["notes_out_clips_per_s"] = notes_out["clips_per_s"]
             res_json["notes_out"] = notes_out
+        if trained_like is not None:
+            res_json["trained_like"] = trained_like
         if parity_grade is not None:
             res_json["parity_grade_clips_per_s"] = parity_grade["clips_per_s"]
             res_json["parity_grade"] = parity_grade

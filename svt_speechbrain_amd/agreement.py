@@ -105,3 +105,65 @@ def mode_agreement(logits: torch.Tensor, frames, ref_logits: torch.Tensor, ref_f
     out["meets_1e-3_and_identical_argmax_up_to_near_ties"] = bool(out["max_abs_dlogit"] <= 1e-3 and
                                                                   out["frames_argmax_mismatch_beyond_near_ties"] == 0)
     return out
+
+
+def trained_like_study(device, modes=("bf16", "fp16", "fp16x3"), fixture: Optional[str] = None, held_out: bool = False) -> Dict[str, object]:
+    """What the numeric modes do to a transcription whose decisions have TRAINED-LIKE margins (VERDICT r05 "next" #3).
+
+    The bench batch is noise through a random head: every decision is a near tie.  Here the batch is seeded synthetic singing
+    (``synth.synth_singing``) and the head is the fixture ``tests/golden/trained_like_head.pt`` -- the 20-way head fitted with the
+    recipes' loss to those clips' labels on the frozen seeded encoder's exact features (``tools/make_trained_like_head.py``).  Per mode,
+    against the exact-fp32 mode on the same clips: the ``mode_agreement`` figures, and -- what a user of the recipes cares about -- the
+    note-level F1 of each mode's notes against the GROUND-TRUTH notes of the clips, beside the exact mode's own.  ``held_out`` uses the
+    fixture's second seed (clips the head was not fitted on)."""
+    import os
+    import svt_speechbrain_amd as S
+    from .synth import synth_singing
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = torch.load(fixture or os.path.join(root, "tests", "golden", "trained_like_head.pt"), weights_only=False)
+    cfg = S.PRESETS[fx["model"]]
+    wav, lab, notes = synth_singing(fx["clips"], fx["seconds"], seed=fx["held_out_seed"] if held_out else fx["train_seed"])
+    truth = [[[float(a), float(b), int(m)] for a, b, m in n] for n in notes]
+    x = torch.from_numpy(wav).to(device)
+    head = S.Linear(20, input_size=cfg.hidden_size)
+    head.load_state_dict({"w.weight": fx["w.weight"], "w.bias": fx["w.bias"]})
+    head = head.to(device)
+    T = cfg.frames(x.shape[1])
+
+    def run(precision):
+        enc = S.HuggingFaceWav2Vec2(fx["model"], None, config=cfg, precision=precision, normalize_wav=True, seed=fx["encoder_seed"]).to(device)
+        frames = torch.empty((x.shape[0], T, 4), dtype=torch.int32, device=device)
+        logits = enc.forward_head(x, head, frames=frames)
+        torch.cuda.synchronize()
+        del enc
+        return logits, frames
+
+    ref_logits, ref_frames = run("fp32")
+    ref_notes = frames2note_batch(_frames_host(ref_frames), 0.4, 0.5, 1 / 49.8)
+    lab_t = torch.from_numpy(lab)
+    fr = _frames_host(ref_frames)
+    srt = ref_logits[..., 7:].float().sort(-1).values
+    margin = (srt[..., -1] - srt[..., -2]).reshape(-1).cpu().numpy()
+    out: Dict[str, object] = {
+        "batch": f"{x.shape[0]} x {fx['seconds']:g} s of seeded synthetic singing ({'held-out' if held_out else 'the clips the head was fitted on'})",
+        "head": "tests/golden/trained_like_head.pt: recipe loss on the frozen seeded encoder's exact features (tools/make_trained_like_head.py)",
+        "ground_truth_notes": sum(len(n) for n in truth),
+        "exact_fp32": {"frame_accuracy_octave": float((torch.from_numpy(fr["octave"].astype(np.int64)) == lab_t[..., 2]).float().mean()),
+                       "frame_accuracy_pitch_class": float((torch.from_numpy(fr["pitch_class"].astype(np.int64)) == lab_t[..., 3]).float().mean()),
+                       "pitch_class_top2_margin_percentiles_1_5_25_50": [round(float(np.percentile(margin, q)), 4) for q in (1, 5, 25, 50)],
+                       "notes_vs_ground_truth": {k: v for k, v in note_agreement(ref_notes, truth).items() if k.endswith("_f1") or k in ("notes", "reference_notes")}},
+        "modes": {},
+    }
+    for m in modes:
+        lg, frm = run(m)
+        ag = mode_agreement(lg, frm, ref_logits, ref_frames, 0.4, 0.5, 1 / 49.8)
+        own_notes = frames2note_batch(_frames_host(frm), 0.4, 0.5, 1 / 49.8)
+        vs_truth = note_agreement(own_notes, truth)
+        out["modes"][m] = {"max_abs_dlogit": ag["max_abs_dlogit"], "mean_abs_dlogit": ag["mean_abs_dlogit"], "frames": ag["frames"],
+                           "frames_argmax_mismatch": ag["frames_argmax_mismatch"],
+                           "frames_argmax_mismatch_beyond_near_ties": ag["frames_argmax_mismatch_beyond_near_ties"],
+                           "clips_with_identical_notes": ag["clips_with_identical_notes"], "clips": ag["clips"],
+                           "COnPOff_f1_vs_exact_mode": ag["COnPOff_f1"], "COn_f1_vs_exact_mode": ag["COn_f1"],
+                           "meets_1e-3_and_identical_notes": ag["meets_1e-3_and_identical_notes"],
+                           "notes_vs_ground_truth": {k: v for k, v in vs_truth.items() if k.endswith("_f1") or k in ("notes", "reference_notes")}}
+    return out

@@ -1168,7 +1168,9 @@ int gemm_walk_pm(const GemmArgs& a, int bm) {
   if (g_gemm_walk >= 0) return g_gemm_walk;
   const int tiles_n = a.N / 256, tiles_m = (a.M + bm - 1) / bm;
   const double w_bytes = (double)a.N * a.K * 2.0;
-  if (tiles_n < 8 || tiles_m < 16 || w_bytes <= 3.0 * 1024 * 1024) return 0;
+  // measured (profiles/r06_gemm_tile_walk.txt, us at pm = 0 / 8): FFN-1 of the base model (W 4.5 MiB) 76.1 / 70.6, the large FFN-1 (8 MiB) 262 / 255,
+  // the large QKV (6 MiB) 181 / 177, 8192^3 800 / 746; QKV of the base model (W 3.4 MiB: resident) 52.3 / 53.5 -- hence the 4 MiB line
+  if (tiles_n < 8 || tiles_m < 16 || w_bytes <= 4.0 * 1024 * 1024) return 0;
   return 8;
 }
 int g_x3_pairs = 1;

@@ -392,6 +392,20 @@ def make_video_front_cases():
     torch.save(out, os.path.join(HERE, "video_front.pt"))
 
 
+def make_note2frame_cases(utils):
+    """The reference's own note2frame (MIR_ST500/utils.py:10-69) on the note lists of the first synthetic-singing clips of the two
+    seeds the trained-like head uses (svt_speechbrain_amd/synth.py): the labels the head is fitted to are the reference's labels."""
+    from svt_speechbrain_amd.synth import synth_singing
+    out = {}
+    for seed in (2986, 3986):
+        _, _, notes = synth_singing(6, 10.0, seed=seed)
+        for i, n in enumerate(notes):
+            gt = [[float(a), float(b), int(m)] for a, b, m in n]
+            out[f"seed{seed}_clip{i}"] = dict(notes=gt, frames=torch.from_numpy(np.array(utils.note2frame(gt, 499, 1 / 49.8), dtype=np.int64)))
+    torch.save(out, os.path.join(HERE, "note2frame.pt"))
+    print("note2frame", len(out), "clips")
+
+
 def make_video_u8_cases():
     """The video recipes' input side, by the reference's own classes: ``Compose([Normalize(0.0, 255.0), CenterCrop((88, 88)),
     Normalize(0.421, 0.165)])`` (N20EMv2/video_only/train_video_ssl.py:445-457, classes of N20EMv2/video_only/utils.py:22-84; cv2 --
@@ -687,6 +701,7 @@ def main():
         "data2vec_base_c1": lambda: make_encoder_case(hi, utils, "data2vec_base_c1", "data2vec-audio-base", 1, 48000, 25, full=False),
         "fusion": lambda: make_fusion_cases(fusion_mod),
         "frame2note": lambda: make_frame2note_cases(utils),
+        "note2frame": lambda: make_note2frame_cases(utils),
         "ctc_fbank": make_ctc_fbank_cases,
         "losses": make_loss_cases,
         "video_front": make_video_front_cases,

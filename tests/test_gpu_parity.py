@@ -154,35 +154,53 @@ def simulated_error(name, fx, mode):
     return _SIM_CACHE[key]
 
 
-def check_16bit_mode_bound(tag, logits, fx, sim):
-    """GPU 16-bit-operand mode against the operand-rounding simulation `sim` of the same golden.  The kernels round more than the
-    operands (branch outputs and conv activations are STORED in 16 bits, the bf16 GELU is a polynomial), so: mean |dlogit| within 1.4x
-    of the simulation's (measured on MI355X, rounds 2-4, nine goldens x two modes: 1.0-1.27), max |dlogit| -- the largest of ~20 000
-    values, a noisy statistic -- within 1.6x (measured 0.95-1.41), and the number of frames whose argmax differs within 1.35x + three
-    standard deviations of a count of that size + 3 (near-ties flip like a Poisson process: 2 x 10 s of wav2vec2-base, bf16:
-    simulation 74 frames of 998, kernels 71-89 depending on the LayerNorm's summation order; wav2vec2-large 2 x 10 s: simulation 14,
-    kernels 31 -- the stored bf16 activations of 24 pre-LN layers weigh more there; a tighter 1.2x + 2 sigma rule refused that).
-    Note level (round 5): the notes frame2note makes of the mode's frames against the REFERENCE's notes of the golden, scored like the
-    recipes score a transcription (COnPOff / COnP / COn F1, svt_speechbrain_amd/agreement.py): at least the simulation's F1 minus what
+def check_16bit_mode_bound(tag, logits, fx, sim, stored=None, measured=None):
+    """GPU 16-bit-operand mode against two CPU simulations of the same golden (tools/sim_split.py, committed as
+    tests/golden/sim_bounds.json): `sim` rounds the OPERANDS of every dense product to 16 bits and nothing else; `stored` (round 6,
+    modes bf16x1s / f16x1s) also rounds what the kernels STORE in 16 bits -- every GEMM result and every GELU result, a fused
+    linear -> GELU pair once.  The stored simulation is the yardstick: over nine goldens x two modes the kernels' mean |dlogit| is
+    0.94-1.18 x its figure (1.0-1.25 x the operand-only one), max |dlogit| 0.83-1.30 x (a noisy statistic: the largest of ~20 000 values).
+    Bounds: mean <= 1.25 x, max <= 1.4 x, frames whose argmax differs <= 1.2 x + 2.5 sigma of a count of that size + 2 (near ties flip
+    like a Poisson process).  wav2vec2-large 2 x 10 s is the one case the simulation does not explain to within its noise: operand
+    rounding alone predicts 14 frames, + stored activations 19, the kernels measure 31 (2.7 sigma above 19; mean |dlogit| 1.16 x):
+    what is left is outside both simulations -- the multi-frame positional convolution's 16-bit partial rows and the polynomial GELU are
+    the candidates -- and stays inside the bound only through the sigma term.  `measured` (tests/golden/kernel_16bit_measured_r06.json,
+    this round's kernels on MI355X) adds a REGRESSION ceiling beside the physics one: at most the measured count + 2 sigma + 1 and
+    1.15 x the measured mean.
+    Note level: the notes frame2note makes of the mode's frames against the REFERENCE's notes of the golden, scored like the recipes
+    score a transcription (COnPOff / COnP / COn F1, svt_speechbrain_amd/agreement.py): at least the operand simulation's F1 minus what
     moving two notes of this many would cost, minus 0.03."""
     from svt_speechbrain_amd.agreement import note_agreement
     s_max, s_mean, s_mism, total, n_ref, s_f_full, s_f_nooff, s_f_on = sim
+    y_max, y_mean, y_mism = (stored[0], stored[1], stored[2]) if stored is not None else (s_max, s_mean, s_mism)
     err = (logits.cpu() - fx["logits"]).abs()
     mism = check_decode(logits, fx, exact=False)
     frames = S.decode_frames(logits)
     notes = [S.frame2note(S.frames_to_info(frames[b]), 0.4, 0.5) for b in range(len(fx["decode"]))]
     na = note_agreement(notes, [d["notes"] for d in fx["decode"]])
-    print(f"{tag}: max|dlogit| {err.max():.4f} mean {err.mean():.4f} (simulation {s_max:.4f} / {s_mean:.4f}; logit std {fx['logits'].std():.2f}); "
-          f"frames with a different octave/pitch-class argmax: {mism}/{total} (simulation {s_mism}); notes {na['notes']} vs {n_ref} of the "
-          f"reference, F1 COnPOff {na['COnPOff_f1']:.3f} COnP {na['COnP_f1']:.3f} COn {na['COn_f1']:.3f} (simulation {s_f_full:.3f} / "
-          f"{s_f_nooff:.3f} / {s_f_on:.3f}), clips with identical notes {na['clips_with_identical_notes']}/{na['clips']}")
-    assert err.max() < 1.6 * s_max + 1e-3, (float(err.max()), s_max)
-    assert err.mean() < 1.4 * s_mean + 1e-4, (float(err.mean()), s_mean)
-    assert mism <= 1.35 * s_mism + 3.0 * (s_mism ** 0.5) + 3, (mism, s_mism, total)
+    print(f"{tag}: max|dlogit| {err.max():.4f} mean {err.mean():.4f} (simulation {s_max:.4f} / {s_mean:.4f}, + stored activations {y_max:.4f} / {y_mean:.4f}; "
+          f"logit std {fx['logits'].std():.2f}); frames with a different octave/pitch-class argmax: {mism}/{total} (simulation {s_mism}, + stored {y_mism}); "
+          f"notes {na['notes']} vs {n_ref} of the reference, F1 COnPOff {na['COnPOff_f1']:.3f} COnP {na['COnP_f1']:.3f} COn {na['COn_f1']:.3f} "
+          f"(simulation {s_f_full:.3f} / {s_f_nooff:.3f} / {s_f_on:.3f}), clips with identical notes {na['clips_with_identical_notes']}/{na['clips']}")
+    assert err.max() < 1.4 * y_max + 1e-3, (float(err.max()), y_max)
+    assert err.mean() < 1.25 * y_mean + 1e-4, (float(err.mean()), y_mean)
+    assert mism <= 1.2 * y_mism + 2.5 * (y_mism ** 0.5) + 2, (mism, y_mism, total)
+    if measured is not None:
+        m_max, m_mean, m_mism, m_total = measured
+        assert m_total == total
+        assert mism <= m_mism + 2.0 * max(1.0, m_mism) ** 0.5 + 1 and err.mean() < 1.15 * m_mean + 1e-4, ("regression against round 6", mism, m_mism, float(err.mean()), m_mean)
     assert na["reference_notes"] == n_ref
     slack = 0.03 + 2.0 / max(1, n_ref)
     assert na["COnPOff_f1"] >= s_f_full - slack and na["COnP_f1"] >= s_f_nooff - slack and na["COn_f1"] >= s_f_on - slack, (na, sim)
     return na
+
+
+def measured_16bit(name, mode):
+    """this round's kernels on MI355X (tests/golden/kernel_16bit_measured_r06.json; written from the printed figures of a GPU run)"""
+    table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_16bit_measured_r06.json")
+    if not os.path.exists(table):
+        return None
+    return json.load(open(table)).get(name, {}).get(mode)
 
 
 BOUND_CASES = ["tiny_group", "tiny_layer", "base_c1", "base_b2", "large_c1", "data2vec_base_c1", "wavlm_base_c1", "large_b2",
@@ -199,7 +217,7 @@ def test_bf16_mode_error_bound(golden, name):
     wav = golden_wav(fx).to(DEV)
     logits = head(enc(wav))
     assert torch.isfinite(logits).all()
-    check_16bit_mode_bound(f"bf16[{name}]", logits, fx, simulated_error(name, fx, "bf16x1"))
+    check_16bit_mode_bound(f"bf16[{name}]", logits, fx, simulated_error(name, fx, "bf16x1"), simulated_error(name, fx, "bf16x1s"), measured_16bit(name, "bf16"))
 
 
 @pytest.mark.parametrize("name", BOUND_CASES)
@@ -213,7 +231,7 @@ def test_fp16_mode_error_bound(golden, name):
     wav = golden_wav(fx).to(DEV)
     logits = head(enc(wav))
     assert torch.isfinite(logits).all()
-    check_16bit_mode_bound(f"fp16[{name}]", logits, fx, simulated_error(name, fx, "f16x1"))
+    check_16bit_mode_bound(f"fp16[{name}]", logits, fx, simulated_error(name, fx, "f16x1"), simulated_error(name, fx, "f16x1s"), measured_16bit(name, "fp16"))
     # the fused tail serves this build too, and agrees with encoder -> head
     fused = enc.forward_head(wav, head) if S.HuggingFaceWav2Vec2.can_fuse_head(head) else logits
     assert (fused - logits).abs().max().item() < 2e-4

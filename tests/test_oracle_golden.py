@@ -2,6 +2,7 @@
 itself (tests/golden/make_golden.py).  Tolerances: 2e-5 on O(1) feats/logits (fp32 op-order noise
 between the oracle's functional ops and HF modules), exact on argmax / notes."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -225,3 +226,22 @@ def test_oracle_fbank_deltas_and_context_match_reference_golden(golden):
     for c in fx["context"]:
         got = O.context_window(c["x"], c["left"], c["right"])
         assert got.shape == c["expect"].shape and torch.equal(got, c["expect"])
+
+
+def test_synthetic_singing_labels_are_the_references_note2frame(golden):
+    """svt_speechbrain_amd/synth.py (the clips the trained-like head of tests/golden/trained_like_head.pt is fitted to): seeded and
+    reproducible, and its frame labels are what the REFERENCE's note2frame makes of the same note lists (tests/golden/note2frame.pt)."""
+    import hashlib
+    from svt_speechbrain_amd.synth import synth_singing
+    fx = golden("note2frame")
+    for seed in (2986, 3986):
+        wav, lab, notes = synth_singing(6, 10.0, seed=seed)
+        assert wav.shape == (6, 160000) and wav.dtype == np.float32 and np.abs(wav).max() <= 1.0 and lab.shape == (6, 499, 4)
+        for i in range(6):
+            c = fx[f"seed{seed}_clip{i}"]
+            assert [[float(a), float(b), int(m)] for a, b, m in notes[i]] == c["notes"]
+            assert np.array_equal(lab[i], c["frames"].numpy())
+    again, _, _ = synth_singing(2, 10.0, seed=2986)
+    assert np.array_equal(again, synth_singing(6, 10.0, seed=2986)[0][:2])          # clip i depends on (seed, i) only
+    head = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_like_head.pt"), weights_only=False)
+    assert head["w.weight"].shape == (20, 768) and head["train_seed"] == 2986 and head["held_out_seed"] == 3986 and head["encoder_seed"] == 1986
