@@ -1047,7 +1047,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     set_error("encoder_forward: features-in mode has no input norm to group");
     return SVT_ERR_INVALID;
   }
-  SVT_HIP(hipMemsetAsync(w.mom, 0, w.mom_zero, s));
+  if (launch_zero_bytes(w.mom, w.mom_zero, s)) return SVT_ERR_HIP;   // (a kernel, not a memset node: see kernels.hip)
   double* wav_mom = c.normalize_wav ? w.mom : nullptr;
   double* out_mom = w.mom + 2 * (size_t)B;
   double* wm = w.mom + 4 * (size_t)B;
@@ -1108,7 +1108,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     // features-in mode: `wav` is the (B, T, C) fp32 feature tensor
     const int64_t n = (int64_t)B * L * c.conv_dim[0];
     if (prec) { if (int r = launch_f32_to_bf16(wav, (bf16_t*)w.act[0], n, s)) return r; }
-    else SVT_HIP(hipMemcpyAsync(w.act[0], wav, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    else if (launch_copy_f32(wav, (float*)w.act[0], n, s)) return SVT_ERR_HIP;
   } else {
   int64_t t1 = (L - c.conv_kernel[0]) / c.conv_stride[0] + 1;
   const ConvLayerW& c0 = e->conv[0];
@@ -1421,7 +1421,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     if (global_norm) { if (int r = reduce_now(&rctx)) return r; }
     if (int r = launch_global_norm(final_x, feats, n_out / groups, out_mom, 1e-5f, s, groups, n_out_stat)) return r;
   } else {
-    SVT_HIP(hipMemcpyAsync(feats, final_x, (size_t)n_out * 4, hipMemcpyDeviceToDevice, s));
+    if (launch_copy_f32(final_x, feats, n_out, s)) return SVT_ERR_HIP;
   }
   return SVT_OK;
 }
@@ -2025,7 +2025,7 @@ static int video_forward_impl(svt_video* v, const float* video_dev, const unsign
     if (launch_video_pad_u8(prec, roi_dev, batch, t, h_in, w_in, dy, dx, h, w, g.Hp0, g.Wp0, *tf, ws.vp, s)) return SVT_ERR_HIP;
   } else if (launch_video_pad(prec, video_dev, batch, t, h, w, g.Hp0, g.Wp0, ws.vp, s)) return SVT_ERR_HIP;
   if (zero_left > 0)
-    SVT_HIP(hipMemset2DAsync(out_dev - zero_left, (size_t)out_ld * 4, 0, (size_t)zero_left * 4, (size_t)F, s));
+    if (launch_zero_cols(out_dev - zero_left, F, zero_left, out_ld, s)) return SVT_ERR_HIP;
   const bool fused_stem = v->gp == 1 && conv3d_front_pool_ok(prec, g.Hp0, g.Wp0, g.W0);
   if (!fused_stem && launch_conv3d_front(prec, ws.vp, v->stem_w.p, v->stem_bias.as<float>(), v->stem_slope.as<float>(), F, t, g.Hp0, g.Wp0,
                                          g.H0, g.W0, ws.o0, s)) return SVT_ERR_HIP;

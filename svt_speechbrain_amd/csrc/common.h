@@ -320,6 +320,9 @@ int launch_f32_to_pairs(int kind, const float* x, void* out, int64_t n, hipStrea
 int launch_pairs_to_f32(int kind, const void* in, const void* lo_plane, float* y, int64_t n, hipStream_t s);
 // moments[0] = sum(x), moments[1] = sum(x^2) over n fp32 values (fp64 accumulation, workgroup partials added in a fixed order: the
 // result is reproducible bit for bit); scratch = moments_scratch_bytes(groups_max) bytes whose first 4 * groups_max bytes are ZERO
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t s);            // kernel nodes instead of memset / memcpy nodes (kernels.hip)
+int launch_copy_f32(const float* in, float* out, int64_t n, hipStream_t s);
+int launch_zero_cols(float* p, int64_t rows, int cols, int64_t ld, hipStream_t s);
 int set_ticket_fenced(int on);   // svt_debug_set key 32 (kernels.hip, last_workgroup)
 int launch_moments(const float* x, int64_t n, double* moments, void* scratch, int groups_max, hipStream_t s, int groups = 1);  // groups > 1: n elements and 2 doubles per group
 size_t moments_scratch_bytes(int groups_max);

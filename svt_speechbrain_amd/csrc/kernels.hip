@@ -1539,6 +1539,56 @@ int launch_pairs_to_f32(int kind, const void* in, const void* lo_plane, float* y
   return 0;
 }
 
+// Fills and copies as KERNELS of this library, not hipMemsetAsync / hipMemcpyAsync (round 6): inside a captured hipGraph the runtime's
+// memset node ran out of order from the second replay on -- the statistics region of the workspace was zeroed AFTER the moments kernel had
+// written it, the output norm saw (0, 0) and scaled by 1 / sqrt(eps) (tools/scratch/graph_debug.py; tests/test_gpu_graph.py).  A kernel
+// node keeps stream order.  Sizes and addresses are multiples of 16 bytes (the workspace carve is 256-byte aligned).
+namespace {
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* p, int64_t n16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* in, uint4* out, int64_t n16, const float* in_tail, float* out_tail, int n_tail) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (i < n_tail) out_tail[i] = in_tail[i];
+  for (; i < n16; i += stride) out[i] = in[i];
+}
+// rows x cols fp32 block with row pitch ld (elements) set to zero (cols, ld multiples of 4, 16-byte aligned base: the launcher checks)
+__global__ __launch_bounds__(256) void zero_cols_kernel(float* p, int64_t rows, int cols4, int64_t ld) {
+  const int64_t n = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4);
+    *(float4*)(p + r * ld + 4 * c) = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+}  // namespace
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  if (bytes % 16 || ((uintptr_t)p & 15)) { set_error("launch_zero_bytes: 16-byte granularity"); return -1; }
+  if (!bytes) return 0;
+  hipLaunchKernelGGL(zero16_kernel, dim3(grid_for((int64_t)(bytes / 16))), dim3(256), 0, s, (uint4*)p, (int64_t)(bytes / 16));
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_copy_f32(const float* in, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15)) { set_error("launch_copy_f32: 16-byte alignment"); return -1; }
+  const int64_t n16 = n / 4;
+  hipLaunchKernelGGL(copy16_kernel, dim3(grid_for(n16 > 0 ? n16 : 1)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, n16, in + 4 * n16, out + 4 * n16,
+                     (int)(n - 4 * n16));
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_zero_cols(float* p, int64_t rows, int cols, int64_t ld, hipStream_t s) {
+  if (cols % 4 || ld % 4 || ((uintptr_t)p & 15)) { set_error("launch_zero_cols: 16-byte granularity"); return -1; }
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(zero_cols_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, s, p, rows, cols / 4, ld);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
   SVT_LAUNCH_CHECK();

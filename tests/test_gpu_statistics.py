@@ -54,8 +54,9 @@ def test_ordered_sums_equal_host_fp64_sums(fenced):
             torch.cuda.synchronize()
             mom = ws[offs[0]:offs[0] + (4 * B + 65 * B) * 8].view(torch.float64).cpu()
             got_mom, got_win = mom[:2], mom[4 * B:].view(B, 65)
-            assert torch.allclose(got_mom, want_mom, rtol=1e-12, atol=1e-12), (it, got_mom, want_mom)
-            assert torch.allclose(got_win, want_win, rtol=1e-11, atol=1e-11), (it, (got_win - want_win).abs().max())
+            # (the kernel adds four elements in fp32 before it goes to fp64 -- ~1e-8 relative; a missing workgroup's share is >= 1e-3)
+            assert torch.allclose(got_mom, want_mom, rtol=1e-6, atol=1e-6), (it, got_mom, want_mom, (got_mom - want_mom).abs())
+            assert torch.allclose(got_win, want_win, rtol=1e-7, atol=1e-7), (it, (got_win - want_win).abs().max())
             # the output norm's moments belong to the un-normalised encoder output, which this call does not return: what it returns has
             # unit statistics over the whole batch iff those moments were complete
             yd = y.double()
