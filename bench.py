@@ -283,6 +283,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
                     "object and workspace), so one step's HBM-bound kernels (LayerNorm, conv0, norms) run under the next step's MFMA-bound "
                     "ones: measured +5 %% with 2, less with 3.  The roofline leg always runs on one stream.")
+    ap.add_argument("--graph", action="store_true", help="capture each lane's step (one svt_encoder_forward_head call: ~130-190 kernel nodes) into a "
+                    "hipGraph after the warm-up and REPLAY it in the timed region (include/svt_mi355.h: forward calls neither synchronise nor "
+                    "allocate; tests/test_gpu_graph.py).  config.launch reports it.  Measured: the one-utterance forward is bound by its kernels, "
+                    "not by launch gaps (kernel time 0.91 of 0.95 ms), so the default stays eager")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of cpu_baseline.by_procs
     args = ap.parse_args()
     if args.cpu_worker:
@@ -368,7 +372,32 @@ def main():
         return fwd
 
     fwds = [make_forward(i) for i in range(ns)]
+    fwds_eager = fwds                               # the roofline leg's HIP events live in eager launches
     lanes = [(lambda s=s: torch.cuda.stream(s)) for s in streams] if ns > 1 else [None]
+    if args.graph:
+        if args.h2d or args.separate_tail or world > 1:
+            raise SystemExit("[bench] --graph captures the fused single-rank step only (no --h2d / --separate-tail / N > 1)")
+        graphs, static_out = [], []
+        for i in range(ns):
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                for _ in range(2):
+                    fwds[i]()                       # uploads, workspace and kernel attributes exist before the capture
+            torch.cuda.current_stream().wait_stream(cap)
+            torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                static_out.append(encs[i].forward_head(wav, head, frames=frames_l[i]))
+            graphs.append(g_)
+
+        def make_replay(i):
+            def fwd():
+                graphs[i].replay()                  # on the lane's stream (run_sharded issues it inside the lane's context)
+                return frames_l[i] if gather_frames else static_out[i]
+            return fwd
+
+        fwds = [make_replay(i) for i in range(ns)]
 
     def run(steps, warmup, n_lanes=ns):
         return D.run_sharded(fwds[:n_lanes], n_total, rank, world, steps, warmup, dev, lanes=lanes[:n_lanes],
@@ -460,7 +489,7 @@ def main():
     # job finishes sooner -- a per-launch duration under overlap says nothing about the kernel.
     lib.svt_prof_reset()
     lib.svt_prof_enable(1)
-    run(args.steps, 0, n_lanes=1)
+    D.run_sharded(fwds_eager[:1], n_total, rank, world, args.steps, 0, dev, lanes=lanes[:1], gatherers=gatherers[:1], sync=torch.cuda.synchronize)
     lib.svt_prof_enable(0)
     k_dom, k_other, k_attn = prof(0), prof(1), prof(2)
 
@@ -668,7 +697,7 @@ def main():
                                    f"{B} x {args.seconds:g} s @16 kHz mono clips per GPU",
                        "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
-                       "launch": "eager", "streams": ns,
+                       "launch": "hipGraph replay (one captured svt_encoder_forward_head per lane)" if args.graph else "eager", "streams": ns,
                        "inputs": "pinned host memory, copied every step (diagnostic)" if args.h2d else "resident in HBM",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates
