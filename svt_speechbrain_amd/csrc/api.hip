@@ -517,6 +517,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 33) g_gemm_skinny_small_tiles = value;
   else if (key == 32) return set_ticket_fenced(value);
   else if (key == 34) g_gemm_walk = value;
+  else if (key == 36) g_ffn2_ksplit = value;
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
@@ -877,8 +878,13 @@ struct EncWs {
   void* attn_o;
   void* ffn;
   float* dots;      // fused tail: raw head dots, rows x 32
+  float* ksplit;    // partial products of a K-split small GEMM (FFN-2 of a few utterances): 4 x rows x D fp32, or null
   size_t total;
 };
+
+// FFN-2 of a small batch splits K four ways over workgroups and leaves the sum to the LayerNorm behind it (gemm_skinny.hip, ksplit;
+// svt_debug_set key 36 = 0 switches it off): up to this many rows (8 utterances of 5 s)
+static const size_t kKsplitMaxRows = 2048;
 
 EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   const svt_encoder_config& c = e->cfg;
@@ -944,6 +950,7 @@ EncWs carve_encoder(const svt_encoder* e, int B, int64_t L, void* base) {
   w.gate = c.rel_pos_buckets ? (float*)cv.take((size_t)B * H * T * 4) : nullptr;
   w.relpb = c.rel_pos_buckets ? (float*)cv.take((size_t)H * (2 * T - 1) * 4) : nullptr;
   w.dots = (float*)cv.take(rows * 32 * 4);
+  w.ksplit = (sp && rows <= kKsplitMaxRows) ? (float*)cv.take((size_t)4 * rows * D * 4) : nullptr;
   w.total = cv.off;
   return w;
 }
@@ -1311,6 +1318,13 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     bf16_t* xl = (bf16_t*)w.xlo;
     if (int r = launch_layernorm_hilo(nullptr, nullptr, nullptr, w.preF, rows, D, e->enc_g.as<float>(), e->enc_b.as<float>(), eps,
                                       xh, xl, nullptr, s)) return r;
+    // FFN-2 as a K-split small GEMM: when the one-utterance kernel would serve it with less than one workgroup per CU (gemm_skinny.hip)
+    bool ffn2_split = false;
+    if (g_ffn2_ksplit && w.ksplit && gp == 1 && F % 256 == 0 && F >= 2048 && g_ln_two_rows) {
+      GemmArgs g;
+      g.A = w.ffn; g.W = e->layers[0].w2.p; g.C = tmp; g.M = (int)rows; g.N = D; g.K = F; g.a_rpb = (int)rows; g.a_rstride = F; g.ldw = F; g.ldc = D;
+      ffn2_split = g_gemm_skinny && gemm_skinny_eligible(g) && (long)((rows + 31) / 32) * (D / 32) <= 256;
+    }
     for (int l = 0; l < c.num_layers; ++l) {
       const EncLayerW& Lw = e->layers[l];
       const bool last = l + 1 == c.num_layers;
@@ -1323,6 +1337,17 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
       if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln1g.as<float>(), Lw.ln1b.as<float>(), eps,
                                         xh, xl, nullptr, s)) return r;
       if (int r = gemm_rows(w.xb, D, Lw.w1, Lw.b1, F, w.ffn, 0, ACT_GELU, nullptr)) return r;
+      if (ffn2_split) {
+        // a few utterances: K = F split four ways over workgroups, raw fp32 partial tiles, summed (+ bias, rounded to the operand type
+        // like the un-split product's stored result) by the LayerNorm that reads them
+        GemmArgs g;
+        g.A = w.ffn; g.W = Lw.w2.p; g.C = w.ksplit; g.M = (int)rows; g.N = D; g.K = F; g.a_rpb = (int)rows; g.a_rstride = F; g.ldw = F; g.ldc = D;
+        g.out_f32 = 1; g.ksplit = 4; g.ksplit_stride = (long)rows * D;
+        if (int r = launch_gemm_skinny(g, s)) return r;
+        if (int r = launch_layernorm_hilo_parts(w.ksplit, 4, (long)rows * D, Lw.b2.as<float>(), xh, xl, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(),
+                                                eps, xh, xl, last ? w.xF : nullptr, s)) return r;
+        continue;
+      }
       if (int r = gemm_rows(w.ffn, F, Lw.w2, Lw.b2, D, tmp, 0, ACT_NONE, nullptr)) return r;
       if (int r = launch_layernorm_hilo((const bf16_t*)tmp, xh, xl, nullptr, rows, D, Lw.ln2g.as<float>(), Lw.ln2b.as<float>(), eps,
                                         xh, xl, last ? w.xF : nullptr, s)) return r;

@@ -206,6 +206,8 @@ struct GemmArgs {
   int act = ACT_NONE;
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
+  int ksplit = 1;   // gemm_skinny_kernel only: K split over this many workgroups (blockIdx.z); each writes its RAW fp32 partial tile (no bias /
+  long ksplit_stride = 0;   // activation / residual) to (float*)C + part * ksplit_stride: summed by layernorm_hilo2_kernel<D, true> (round 6)
   int walk_pm = 0;  // persistent kernels' tile walk (tile_walk below): 0 = n fastest, > 0 = panels of this many tile rows (set by gemm_walk_pm)
   int c_vec = 1;    // set by launch_gemm: C / resid / bias rows are 16-byte aligned -> vector epilogue
   int raster_gm = 8;  // set by the register-staged launcher: M-tiles per band of the block -> tile map (gemm.hip)
@@ -286,6 +288,7 @@ extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny_small_tiles;   // svt_debug_set key 33
+extern int g_ffn2_ksplit;   // svt_debug_set key 36 (api.hip): FFN-2 of a small batch as a K-split small GEMM + summing LayerNorm
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
 extern int g_stamp_ends;
 extern int g_pps_half_barriers;
@@ -404,6 +407,9 @@ int launch_linear_f32(const float* x, int64_t rows, int K, const float* w, const
 // frame head for K in {512,768,1024}, N <= 32: weight in LDS, four rows per wave (HBM-bound)
 // post-LN residual stream as a bf16 (hi, lo) pair (throughput mode, D in {512, 768, 1024})
 bool layernorm_hilo_ok(int D);
+// the same LayerNorm with the branch given as `nparts` fp32 partial products + bias (a K-split small GEMM: gemm_skinny.hip, ksplit)
+int launch_layernorm_hilo_parts(const float* parts, int nparts, long part_stride, const float* pbias, const bf16_t* rh, const bf16_t* rl, int64_t rows,
+                                int D, const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s);
 int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
                           const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s);
 // attention output projection + residual + LayerNorm in one kernel (gemm_ln.hip; hidden size 768, bf16 mode)

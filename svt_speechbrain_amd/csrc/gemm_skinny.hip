@@ -59,7 +59,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   // sits on the same two of the sixteen L2 channels: with the four waves on adjacent slabs and every workgroup in
   // lockstep the whole launch camps on a few channels (FFN-2 at M = 249: 2 us per slab).  Quarters put the waves
   // K/4 apart, the rotation puts the workgroups apart.
-  const int nslab = p.K / 64;
+  // K split over workgroups (p.ksplit > 1, blockIdx.z = part; round 6): one 5 s utterance's FFN-2 is 192 workgroups walking 48 slabs
+  // each -- 14 us of serial memory round trips on a quarter-filled chip; four parts make it 768 workgroups of 12 slabs (three per wave, all
+  // in flight at once), and the partial tiles are summed by the LayerNorm that follows (layernorm_hilo2_kernel<D, true>)
+  const int kpart = p.ksplit > 1 ? (int)blockIdx.z : 0;
+  const int slab0 = p.ksplit > 1 ? (int)((long)kpart * (p.K / 64) / p.ksplit) : 0;
+  const int nslab = p.ksplit > 1 ? (int)((long)(kpart + 1) * (p.K / 64) / p.ksplit) - slab0 : p.K / 64;
+  if (p.ksplit > 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { ap[b] += (long)slab0 * 64; wp[b] += (long)slab0 * 64; }
+  }
   const int per = (nslab + 3) / 4;
   const int lo = wave * per;
   const int mine = nslab - lo < per ? (nslab - lo > 0 ? nslab - lo : 0) : per;
@@ -175,6 +184,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     v[j] = s[0]; v[j + 1] = s[1]; v[j + 2] = s[2]; v[j + 3] = s[3];
   }
   const long idx = e_idx;
+  if (p.ksplit > 1) {   // the raw partial sum of this K part, fp32: bias / activation / residual belong to whoever adds the parts
+    float* o = (float*)p.C + (long)kpart * p.ksplit_stride + idx;
+#pragma unroll
+    for (int j = 0; j < CP; j += 4) *(float4*)(o + j) = float4{v[j], v[j + 1], v[j + 2], v[j + 3]};
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < CP; ++j) {
     float t = v[j] * p.alpha + e_bias[j];
@@ -206,7 +221,7 @@ int launch_skinny(const GemmArgs& a, hipStream_t s) {
   const size_t lds_bytes = 4 * TS * (TS + 4) * sizeof(float);
   if (int r_ = ensure_dyn_lds((const void*)gemm_skinny_kernel<NB>, (int)lds_bytes)) return r_;
   prof_begin(s);
-  hipLaunchKernelGGL((gemm_skinny_kernel<NB>), dim3(tiles_m * tiles_n, a.nz, 1), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL((gemm_skinny_kernel<NB>), dim3(tiles_m * tiles_n, a.nz, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds_bytes, s, a);
   prof_end(s, flops, bytes, 1);
   SVT_LAUNCH_CHECK();
   return 0;
@@ -222,8 +237,11 @@ bool gemm_skinny_eligible(const GemmArgs& a) {
   return big_tiles <= g_gemm_skinny_max_tiles;
 }
 
+int g_ffn2_ksplit = 1;   // svt_debug_set key 36: the encoder's FFN-2 of a small batch as a K-split launch of this kernel (api.hip)
 int g_gemm_skinny_small_tiles = 96;   // svt_debug_set key 33: 32 x 32 tiles while the 64 x 64 tiling has at most this many workgroups
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t s) {
+  if (a.ksplit > 1 && (a.bias || a.resid || a.act != ACT_NONE || !a.out_f32 || a.alpha != 1.f || (a.K / 64) < a.ksplit || a.ksplit_stride < (long)a.M * a.ldc)) {
+    set_error("gemm_skinny: a K-split launch writes raw fp32 partial tiles (no bias / activation / residual)"); return -1; }
   const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.nz;
   return tiles64 <= g_gemm_skinny_small_tiles ? launch_skinny<2>(a, s) : launch_skinny<4>(a, s);
 }

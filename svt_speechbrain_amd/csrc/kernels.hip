@@ -379,10 +379,14 @@ __global__ __launch_bounds__(256) void layernorm_op16_rows2_kernel(const bf16_t*
 // instead of six: 23.2 -> 20.5 us per pass at 32 x 10 s (HBM-bound: the same bytes at a higher achieved rate).  The sums are taken in a
 // different order than in the one-row kernel, which moves near-tie frames of the bf16 mode (tests/test_gpu_parity.py
 // check_16bit_mode_bound holds the mode to the operand-rounding simulation, not to one summation order).
-template <int D>
+// PARTS: the branch arrives as `nparts` fp32 partial products of a K-split GEMM (gemm_skinny.hip, ksplit) + its bias: they are added in
+// part order, the bias last, and the sum is rounded to the operand type -- the value the un-split GEMM's epilogue would have stored
+// (same rounding points as the 16-bit modes' stored-activation simulation, tools/sim_split.py)
+template <int D, bool PARTS = false>
 __global__ __launch_bounds__(256) void layernorm_hilo2_kernel(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl,
                                                               int64_t rows, const float* gamma, const float* beta, float eps,
-                                                              bf16_t* yh, bf16_t* yl, float* yF) {
+                                                              bf16_t* yh, bf16_t* yl, float* yF, const float* parts = nullptr, int nparts = 0,
+                                                              long part_stride = 0, const float* pbias = nullptr) {
   constexpr int NC = D / 256;   // 16-byte chunks (8 elements) per lane: 32 lanes x NC x 8 = D
   const int lane = threadIdx.x & 63, sub = lane & 31;
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
@@ -395,7 +399,22 @@ __global__ __launch_bounds__(256) void layernorm_hilo2_kernel(const bf16_t* bran
     const bf16x8 h = *(const bf16x8*)(rh + o), l = *(const bf16x8*)(rl + o);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[j][i] = (float)h[i] + (float)l[i];
-    if (branch) {
+    if constexpr (PARTS) {
+      float a[8];
+      {
+        const float4 t0 = *(const float4*)(parts + o), t1 = *(const float4*)(parts + o + 4);
+        a[0] = t0.x; a[1] = t0.y; a[2] = t0.z; a[3] = t0.w; a[4] = t1.x; a[5] = t1.y; a[6] = t1.z; a[7] = t1.w;
+      }
+      for (int k = 1; k < nparts; ++k) {
+        const float4 t0 = *(const float4*)(parts + k * part_stride + o), t1 = *(const float4*)(parts + k * part_stride + o + 4);
+        a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w; a[4] += t1.x; a[5] += t1.y; a[6] += t1.z; a[7] += t1.w;
+      }
+      const int c = (sub + 32 * j) * 8;
+      const float4 b0 = *(const float4*)(pbias + c), b1 = *(const float4*)(pbias + c + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[j][i] += (float)(bf16_t)(a[i] + bb[i]);
+    } else if (branch) {
       const bf16x8 a = *(const bf16x8*)(branch + o);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[j][i] += (float)a[i];
@@ -1719,6 +1738,18 @@ int launch_layernorm(int prec, const void* x, int x_is_f32, int64_t rows, int D,
 
 bool layernorm_hilo_ok(int D) { return D == 512 || D == 768 || D == 1024; }
 // branch == nullptr && x32 != nullptr: y = LN(x32);  otherwise y = LN(branch + rh + rl)
+int launch_layernorm_hilo_parts(const float* parts, int nparts, long part_stride, const float* pbias, const bf16_t* rh, const bf16_t* rl, int64_t rows,
+                                int D, const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s) {
+  if (!parts || nparts < 1 || !pbias || !(D == 512 || D == 768 || D == 1024) || ((uintptr_t)parts & 15) || (part_stride & 3) || ((uintptr_t)pbias & 15) ||
+      ((uintptr_t)rh & 15) || ((uintptr_t)rl & 15) || ((uintptr_t)yh & 15) || ((uintptr_t)yl & 15) || ((uintptr_t)yF & 15) || ((uintptr_t)gamma & 15) ||
+      ((uintptr_t)beta & 15)) { set_error("layernorm (K-split branch): D in {512, 768, 1024} and 16-byte aligned buffers"); return -1; }
+  const dim3 grid2((unsigned)((rows + 7) / 8)), block(256);
+  if (D == 512) hipLaunchKernelGGL((layernorm_hilo2_kernel<512, true>), grid2, block, 0, s, nullptr, rh, rl, rows, gamma, beta, eps, yh, yl, yF, parts, nparts, part_stride, pbias);
+  else if (D == 768) hipLaunchKernelGGL((layernorm_hilo2_kernel<768, true>), grid2, block, 0, s, nullptr, rh, rl, rows, gamma, beta, eps, yh, yl, yF, parts, nparts, part_stride, pbias);
+  else hipLaunchKernelGGL((layernorm_hilo2_kernel<1024, true>), grid2, block, 0, s, nullptr, rh, rl, rows, gamma, beta, eps, yh, yl, yF, parts, nparts, part_stride, pbias);
+  SVT_LAUNCH_CHECK();
+  return 0;
+}
 int launch_layernorm_hilo(const bf16_t* branch, const bf16_t* rh, const bf16_t* rl, const float* x32, int64_t rows, int D,
                           const float* gamma, const float* beta, float eps, bf16_t* yh, bf16_t* yl, float* yF, hipStream_t s) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);

@@ -25,6 +25,24 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
   __syncthreads();
 }
 
+// the same with the waiting done by RELAXED loads (no cache maintenance per poll) and one acquire fence behind the loop: what a tuned
+// phase boundary would use (the acquire loads of the first form invalidate the XCD's L2 on every poll)
+__device__ __forceinline__ void grid_barrier_tuned(unsigned* counter, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void barrier_tuned_kernel(unsigned* counter, int steps, unsigned long long* cycles) {
+  const unsigned n = gridDim.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int s = 1; s <= steps; ++s) grid_barrier_tuned(counter, (unsigned)s * n);
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = __builtin_amdgcn_s_memrealtime() - t0;
+}
+
 template <bool CHECK>
 __global__ __launch_bounds__(256) void barrier_kernel(unsigned* counter, int steps, unsigned* data, unsigned* bad, unsigned long long* cycles) {
   const unsigned n = gridDim.x;
@@ -73,6 +91,15 @@ int main() {
       printf("grid barrier, %3d workgroups%s: %.2f us per step (kernel %.3f ms, in-kernel %.2f us per step), stale reads %u\n", grid,
              check ? ", write -> barrier -> read another workgroup's slot -> barrier" : "", 1e3 * ms / steps, ms, hc * 0.01 / steps, hb);
     }
+  }
+  for (int grid : {64, 128, 256}) {
+    const int steps = 2000;
+    CK(hipMemsetAsync(counter, 0, 1024, s));
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(barrier_tuned_kernel, dim3(grid), dim3(256), 0, s, counter, steps, cyc);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("grid barrier, %3d workgroups, relaxed polling + one acquire fence: %.2f us per step\n", grid, 1e3 * ms / steps);
   }
   return 0;
 }
