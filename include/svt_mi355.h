@@ -325,7 +325,8 @@ int svt_debug_attention(int32_t precision, const void* q, const void* k, const v
  * 31 = query: returns the number of device buffers this process has FREED so far (value ignored; uploads and re-uploads must not free:
  * tests/test_gpu_uploads.py), 32 = the tickets of the three ordered cross-workgroup sums as acquire-release atomics (1) or relaxed ones behind
  * write-through stores (0, default: kernels.hip, last_workgroup; same bits, tests/test_gpu_statistics.py), 34 = the persistent 16-bit GEMM
- * kernels' tile walk: -1 (default) chosen per launch, 0 = n fastest, n > 0 = panels of n tile rows (common.h, tile_walk; same bits), 36 = FFN-2 of a small batch (<= 2048 rows) as a K-split small GEMM whose partial
+ * kernels' tile walk: -1 (default) chosen per launch, 0 = n fastest, n > 0 = panels of n tile rows (common.h, tile_walk; same bits), 35 = the kernel-3 convolutions' K slabs tap-minor (1, default: the frame two
+ * neighbouring output rows share is re-read out of L2) or tap-major (0) on gemm_p1w_kernel, 36 = FFN-2 of a small batch (<= 2048 rows) as a K-split small GEMM whose partial
  * products the following LayerNorm adds (1, default) or as one product (0), 33 = the small-problem GEMM uses 32 x 32 tiles while its 64 x 64 tiling has at most this many workgroups
  * (96, default; swept on the one-utterance forward: 150 / 200 / 1000 are 1.5-4.5 % slower).
  * Returns 0 (keys 24, 31: the count), SVT_ERR_INVALID for an unknown key. */

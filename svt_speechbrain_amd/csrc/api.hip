@@ -314,6 +314,7 @@ static int g_conv_ln_bf16 = 1;     // svt_debug_set(9, 0): fp32 conv output + La
 // =================================================================================================
 struct ConvLayerW {
   DevBuf w;      // layer 0: fp32 (C,k); others: operand type (Cout, k*Cin) tap-major
+  DevBuf w_kperm;   // 16-bit modes, kernel 3 / stride 2: the same matrix with its K axis in tap-minor slab order (svt_encoder_finalize)
   DevBuf bias;   // fp32 or empty
   DevBuf gamma, beta;
 };
@@ -518,6 +519,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 32) return set_ticket_fenced(value);
   else if (key == 34) g_gemm_walk = value;
   else if (key == 36) g_ffn2_ksplit = value;
+  else if (key == 35) g_conv_kperm = value;
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;
@@ -657,6 +659,18 @@ int svt_encoder_finalize(svt_encoder* e) {
         for (int ci = 0; ci < cin; ++ci)
           for (int j = 0; j < k; ++j) wt[((size_t)o * k + j) * cin + ci] = p->v[((size_t)o * cin + ci) * k + j];
       if (int r = upload_weight(c.precision, L.w, wt.data(), (size_t)co, (size_t)k * cin)) return r;
+      // 16-bit modes, kernel 3: a second copy with the K axis in TAP-MINOR slab order -- slab g = tap g % 3 of channels [(g / 3) * 64, + 64)
+      // -- for gemm_p1w_kernel (GemmArgs::k_taps): the input frame two neighbouring output rows share is re-read two slabs later instead
+      // of sixteen, i.e. out of L2 (1.5 MiB per layer)
+      if (prec && k == 3 && cin % 64 == 0 && c.conv_stride[i] == 2) {
+        std::vector<float> wp((size_t)co * k * cin);
+        const int nb = cin / 64;
+        for (int o = 0; o < co; ++o)
+          for (int cb = 0; cb < nb; ++cb)
+            for (int j = 0; j < k; ++j)
+              memcpy(&wp[((size_t)o * k * nb + (size_t)cb * k + j) * 64], &wt[((size_t)o * k + j) * cin + (size_t)cb * 64], 64 * sizeof(float));
+        if (int r = upload_weight(c.precision, L.w_kperm, wp.data(), (size_t)co, (size_t)k * cin)) return r;
+      } else L.w_kperm.release();
     }
     if (c.conv_bias) {
       if (int r = need(P, pre + "conv.bias", {co}, &p)) return r;
@@ -1150,6 +1164,7 @@ static int encoder_forward_impl(svt_encoder* e, const float* wav, int32_t B, int
     g.M = (int)((int64_t)B * tout); g.N = co; g.K = k * cin;
     g.a_rpb = (int)tout; g.a_bstride = tin * cin; g.a_rstride = (long)st * cin;
     g.ldw = g.K; g.ldc = co;
+    if (Lw.w_kperm.p) { g.W_kperm = Lw.w_kperm.p; g.kperm_taps = k; g.kperm_cin = cin; }
     g.bias = c.conv_bias ? Lw.bias.as<float>() : nullptr;
     if ((int64_t)B * tout > 2147483647LL) { set_error("encoder_forward: batch*frames exceeds 2^31"); return SVT_ERR_INVALID; }
     // pair rows: this layer reads them; it writes them too unless the feature projection's LayerNorm (an fp32 reader) comes next

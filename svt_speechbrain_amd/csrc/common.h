@@ -206,6 +206,13 @@ struct GemmArgs {
   int act = ACT_NONE;
   int out_f32 = 0;  // C is fp32 regardless of the operand type
   int dbg = 0;      // diagnostic variants (tools/gemm_bench.py): 1 = skip DMA after the prologue, 2 = skip MFMAs
+  // gemm_p1w_kernel only (round 6): K slabs of the A operand visited TAP-MINOR.  An implicit-convolution row is k_taps consecutive input
+  // frames of k_cin channels (K = k_taps * k_cin); slab g reads tap g % k_taps, channels [(g / k_taps) * 64, + 64), and W is stored in that
+  // slab order (W_kperm, written at finalize).  The frame shared by two neighbouring output rows (tap 2 of row t = tap 0 of row t + 1 at
+  // kernel 3 / stride 2) is then re-read two slabs later instead of sixteen -- out of L2 instead of HBM (profiles/r06_pmc_conv_kperm.txt).
+  int k_taps = 1, k_cin = 0;
+  const void* W_kperm = nullptr;   // set by the caller beside W: the dispatcher swaps it in (with k_taps / k_cin below) when it picks gemm_p1w_kernel
+  int kperm_taps = 0, kperm_cin = 0;
   int ksplit = 1;   // gemm_skinny_kernel only: K split over this many workgroups (blockIdx.z); each writes its RAW fp32 partial tile (no bias /
   long ksplit_stride = 0;   // activation / residual) to (float*)C + part * ksplit_stride: summed by layernorm_hilo2_kernel<D, true> (round 6)
   int walk_pm = 0;  // persistent kernels' tile walk (tile_walk below): 0 = n fastest, > 0 = panels of this many tile rows (set by gemm_walk_pm)
@@ -288,6 +295,7 @@ extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny_small_tiles;   // svt_debug_set key 33
+extern int g_conv_kperm;     // svt_debug_set key 35: 1 (default) = tap-minor K order for the kernel-3 convolutions on gemm_p1w_kernel, 0 = tap-major
 extern int g_ffn2_ksplit;   // svt_debug_set key 36 (api.hip): FFN-2 of a small batch as a K-split small GEMM + summing LayerNorm
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)
 extern int g_stamp_ends;

@@ -1164,6 +1164,7 @@ void split_weights_forget(const void* w_f32) {
 // svt_debug_set key 34 (tile_walk, common.h).  The automatic choice: panels when W does not fit an XCD's L2 beside the A stream and the
 // problem has enough columns of tiles to form them.
 int g_gemm_walk = -1;
+int g_conv_kperm = 1;   // svt_debug_set key 35
 int gemm_walk_pm(const GemmArgs& a, int bm) {
   if (g_gemm_walk >= 0) return g_gemm_walk;
   const int tiles_n = a.N / 256, tiles_m = (a.M + bm - 1) / bm;
@@ -1377,7 +1378,14 @@ int launch_gemm_dma(const GemmArgs& a0, hipStream_t s) {
   if (g_gemm_variant != 49 && g_gemm_ring == 0 && best >= 128 && ntiles >= 100 && gemm_pps_eligible(a)) {
     // single-wave-per-SIMD kernel (gemm_p1w.hip, round 5): 5-11 % faster per launch wherever its un-overlapped epilogue is small beside the
     // tile -- everything except GELU launches with fewer than 16 K slabs (FFN-1 of the base model: 12 slabs, 72.8 us here against 81.9)
-    if (g_gemm_p1w && a.K >= 192 && (!a.trace || g_gemm_p1w == 2) && (g_gemm_p1w == 2 || !(a.act == ACT_GELU && a.K < 1024))) return launch_gemm_p1w(a, best, s);   // key 29 = 2: everywhere, traced launches included (tools/gemm_trace.py --p1w)
+    if (g_gemm_p1w && a.K >= 192 && (!a.trace || g_gemm_p1w == 2) && (g_gemm_p1w == 2 || !(a.act == ACT_GELU && a.K < 1024))) {   // key 29 = 2: everywhere, traced launches included (tools/gemm_trace.py --p1w)
+      if (a.W_kperm && g_conv_kperm && a.kperm_taps >= 2 && a.kperm_taps <= 3 && a.kperm_cin % 64 == 0 && a.K == a.kperm_taps * a.kperm_cin && a.ldw == a.K) {
+        GemmArgs b = a;   // a kernel-3 convolution: tap-minor K order (GemmArgs::k_taps; the caller's second copy of W is stored that way)
+        b.W = a.W_kperm; b.k_taps = a.kperm_taps; b.k_cin = a.kperm_cin;
+        return launch_gemm_p1w(b, best, s);
+      }
+      return launch_gemm_p1w(a, best, s);
+    }
     return launch_gemm_pps(a, best, s, 2);
   }
   const bool pers_ok = !a.resid && a.nz == 1 && a.K >= 128 && a.N % 256 == 0 && a.c_z1 == 0 && a.c_z2 == 0 &&

@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
   const int woff = (wn * 8) * 128;    // ... of the W unit
 
   const int nk = p.K / BK;             // >= 2 (launcher)
+  // byte offset of K slab kk inside an A row: linear, or tap-minor for the kernel-3 convolutions (GemmArgs::k_taps; W is stored in slab order)
+  const int taps = p.k_taps;
+  auto aoff = [&](int kk) -> long {
+    if (taps <= 1) return (long)kk * (BK * 2);
+    const int cb = taps == 3 ? (kk * 21846) >> 16 : kk >> 1;     // kk / taps for taps in {2, 3}, kk < 32768
+    return ((long)(kk - cb * taps) * p.k_cin + (long)cb * BK) * 2;
+  };
   const bool no_epi = p.dbg == 3, has_bias = p.bias != nullptr;
   // diagnostics (tools/gemm_trace.py --p1w; dbg = 9 sets p.trace): wall-clock stamps at entry / first slab / exit, the epilogues' share, core
   // cycles over the stream and the cycles the wave spent between reaching a slab's counted wait and leaving its barrier
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
 #pragma unroll
   for (int i = 0; i < GW; ++i) p1_dma(wofE, gW + w_piece(i), lds_unit(1, i));
 #pragma unroll
-  for (int i = 0; i < GA; ++i) p1_dma(aofE[i], gA + BK * 2, lds_unit(2, i));
+  for (int i = 0; i < GA; ++i) p1_dma(aofE[i], gA + aoff(1), lds_unit(2, i));
 #pragma unroll
   for (int i = 0; i < GW; ++i) p1_dma(wofE, gW + BK * 2 + w_piece(i), lds_unit(3, i));
   p1_wait_vm<GA + GW>();   // A_0 and W_0 (and the bias loads, older still) have landed
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
     asm volatile("" : "+v"(bq[0]), "+v"(bq[1]));   // this tile's bias: fetched a slab before the previous tile's end, covered by a counted wait since
     // ---- slab 0: the accumulators start from the bias; the stream's very first slab issues its own A request ----
     {
-      const char* sA = gA + 2L * (BK * 2);
+      const char* sA = gA + aoff(2);
       const char* sW = gW + 2L * (BK * 2);
       if (first_tile) {
         kstep(c0{}, c1{}, c1{}, sa, 1, te, sA, slot_add(sa, 4), te, sW, sa);
@@ -312,10 +319,11 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
     for (int k = 1; k + 1 < nk; ++k) {
       const bool cur2 = k + 2 < nk;
       const bool ev = cur2 == te;
-      const long ko = (long)(cur2 ? k + 2 : k + 2 - nk) * (BK * 2);
-      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + ko, slot_add(sa, 4), ev, gW + ko, sa);
+      const int kk = cur2 ? k + 2 : k + 2 - nk;
+      const long ko = (long)kk * (BK * 2), koa = aoff(kk);
+      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + koa, slot_add(sa, 4), ev, gW + ko, sa);
       mid_barrier(w_a{});
-      kstep(c1{}, c2{}, c0{}, slot_add(sa, 2), 0, ev, gA + ko, 0, ev, gW + ko, sa);
+      kstep(c1{}, c2{}, c0{}, slot_add(sa, 2), 0, ev, gA + koa, 0, ev, gW + ko, sa);
       sa = slot_add(sa, 2);
     }
     // ---- slab nk - 1: its requests belong to the next tile's slab 1 (A, W) and slab 2 (A); its second k-step carries the tile's epilogue ----
@@ -328,13 +336,13 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
                      : "+v"(bq[0]), "+v"(bq[1]) : "v"(bp) : "memory");
       }
       const bool ev = !te;            // the other parity: the next tile
-      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + 1L * (BK * 2), slot_add(sa, 4), ev, gW, sa);
+      kstep(c0{}, c1{}, c0{}, sa, 1, ev, gA + aoff(1), slot_add(sa, 4), ev, gW, sa);
       mid_barrier(w_a{});
       long long t_e0 = 0;
       if (tr) t_e0 = wall_clock64();
       // W of the next tile's slab 1 into A_g's slot, A of its slab 2 into W_g's (= the new first slab's "two ahead" slot): both free behind
       // this barrier; the next tile's first A fragments are read here too, its W fragments behind the k-step (their registers are in use)
-      kstep_last(slot_add(sa, 2), ev, gA + 2L * (BK * 2), slot_add(sa, 1), gW + 1L * (BK * 2), sa);
+      kstep_last(slot_add(sa, 2), ev, gA + aoff(2), slot_add(sa, 1), gW + 1L * (BK * 2), sa);
       sa = slot_add(sa, 2);
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) read_w(sa, 0, nb);
