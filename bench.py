@@ -63,7 +63,7 @@ PARITY_BOUNDS = {
     "fp16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.0, "COnPOff_f1": 0.999},
     "bf16x3": {"max_abs_dlogit": 1e-3, "frames_mismatch_frac": 0.003, "COnPOff_f1": 0.99},
 }
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_hbm_traffic.json")
 
 
 def synth_wav(B, L, seed=1986):
