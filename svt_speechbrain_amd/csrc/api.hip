@@ -520,6 +520,7 @@ int svt_debug_set(int key, int value) {
   else if (key == 34) g_gemm_walk = value;
   else if (key == 36) g_ffn2_ksplit = value;
   else if (key == 35) g_conv_kperm = value;
+  else if (key == 37) { if (value < 8 || value > 256 || value % 8) { set_error("svt_debug_set(37): 8 .. 256, a multiple of 8"); return SVT_ERR_INVALID; } g_gemm_persist_wgs = value; }
   else if (key == 18) g_attn_stamp = value;
   else if (key == 5) { /* retired: the fused out-projection + LayerNorm kernel */ }
   else if (key == 6) g_gemm_skinny = value;

@@ -295,6 +295,7 @@ extern int g_gemm_x3;  // 1 (default): use it where eligible; 0: register-staged
 extern int g_flash_wide;  // fused attention: 8-wave (256-query) workgroups for head_dim 64 (1, default) or 4-wave ones (0)
 extern int g_gemm_skinny_max_tiles;
 extern int g_gemm_skinny_small_tiles;   // svt_debug_set key 33
+extern int g_gemm_persist_wgs;   // svt_debug_set key 37: workgroups of a persistent GEMM launch (256 = one per CU, default; a multiple of 8)
 extern int g_conv_kperm;     // svt_debug_set key 35: 1 (default) = tap-minor K order for the kernel-3 convolutions on gemm_p1w_kernel, 0 = tap-major
 extern int g_ffn2_ksplit;   // svt_debug_set key 36 (api.hip): FFN-2 of a small batch as a K-split small GEMM + summing LayerNorm
 extern int g_gemm_skinny;  // 1 (default): small problems use it; 0: never (diagnostics, svt_debug_set key 6)

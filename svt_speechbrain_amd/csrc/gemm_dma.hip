@@ -1165,6 +1165,7 @@ void split_weights_forget(const void* w_f32) {
 // problem has enough columns of tiles to form them.
 int g_gemm_walk = -1;
 int g_conv_kperm = 1;   // svt_debug_set key 35
+int g_gemm_persist_wgs = 256;   // svt_debug_set key 37
 int gemm_walk_pm(const GemmArgs& a, int bm) {
   if (g_gemm_walk >= 0) return g_gemm_walk;
   const int tiles_n = a.N / 256, tiles_m = (a.M + bm - 1) / bm;

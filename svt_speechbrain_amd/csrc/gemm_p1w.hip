@@ -369,7 +369,7 @@ template <int BM, int ACT, bool TR = false>
 int launch_p1w_t(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
-  const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  const int nblk = ntiles < g_gemm_persist_wgs ? ((ntiles + 7) / 8) * 8 : g_gemm_persist_wgs;   // (svt_debug_set key 37: workgroups of a persistent launch)
   const size_t lds_bytes = 5 * 32768;
   GemmArgs aw = a;
   aw.walk_pm = gemm_walk_pm(a, BM);

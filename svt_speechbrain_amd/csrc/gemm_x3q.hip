@@ -452,7 +452,7 @@ template <bool F16, int BM, int OUT, int DBG = 0, int NQ = 3>
 int launch_x3q_t(const GemmArgs& a, const void* packed, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
   const int ntiles = tiles_m * tiles_n;
-  const int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+  const int nblk = ntiles < g_gemm_persist_wgs ? ((ntiles + 7) / 8) * 8 : g_gemm_persist_wgs;   // (svt_debug_set key 37: workgroups of a persistent launch)
   const size_t lds_bytes = 5 * 32768;
   if (int r_ = ensure_dyn_lds((const void*)gemm_x3q_kernel<F16, BM, OUT, DBG, NQ>, (int)lds_bytes)) return r_;
   hipLaunchKernelGGL((gemm_x3q_kernel<F16, BM, OUT, DBG, NQ>), dim3(nblk), dim3(512), lds_bytes, s, a, packed, tiles_n, ntiles);
