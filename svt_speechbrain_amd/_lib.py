@@ -142,6 +142,11 @@ def load(variant: str = None) -> C.CDLL:
     key = variant or ""
     if key in _libs:
         return _libs[key]
+    if not variant and os.environ.get("SVT_LIB_SUFFIX"):   # diagnostics: an experimental build of the bf16 library (csrc/Makefile, XNAME)
+        variant_path = LIB_PATH.replace("libsvt_mi355.so", f"libsvt_mi355_{os.environ['SVT_LIB_SUFFIX']}.so")
+        if not os.path.exists(variant_path):
+            raise SvtError(f"SVT_LIB_SUFFIX: {variant_path} not found")
+        globals()["LIB_PATH"] = variant_path
     root, ext = os.path.splitext(LIB_PATH)   # only the file's suffix: the checkout may live under a directory with ".so" in its name
     path = LIB_PATH if not variant else f"{root}_{variant}{ext}"
     if not os.path.exists(path):

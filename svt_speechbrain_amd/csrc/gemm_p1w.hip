@@ -26,6 +26,11 @@
 namespace svt {
 namespace {
 
+// cache policy of the tile's row stores: 16 = sc1 (write-through, dispatched: measured against write-back in round 3 on gemm_pps_kernel and again in
+// round 6 on this kernel, profiles/r06_gemm_store_policy_ab.txt); an experimental build may override it (make XNAME=wb XDEFS=-DSVT_P1W_STORE_AUX=0)
+#ifndef SVT_P1W_STORE_AUX
+#define SVT_P1W_STORE_AUX 16
+#endif
 template <int N> __device__ __forceinline__ void p1_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void p1_dma(unsigned voff, const void* sbase, unsigned lds_addr) {
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm_p1w_kernel(GemmArgs p, int tiles_n, 
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(FIN_VGPR ? fin[j][r] : acc[j][mb][r]);
           }
           // the row goes into the VECTOR offset (range check of a raw buffer; see gemm_pps_kernel for the soffset hazard)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, o), crsrc, off0 + (mb * 16 + r) * row_pitch, 0, SVT_P1W_STORE_AUX);
           if constexpr (ACT == ACT_GELU) __builtin_amdgcn_sched_barrier(0);   // one row's polynomial at a time (register pressure)
         }
       } else {
