@@ -280,3 +280,28 @@ def test_gemm_rejects_unaligned():
     assert rc != 0 and b"multiple" in lib.svt_last_error()
 
 
+
+
+@pytest.mark.parametrize("name,M,N,K,act", [("ffn1_base", 15968, 3072, 768, 1),        # gemm_pps_kernel (GELU, K < 1024), 63 x 12 tiles of 256 rows
+                                            ("ragged_panels", 5200, 2304, 768, 0),      # gemm_p1w_kernel, 28 tile rows: the last panel is short for pm = 3 / 5 / 8 / 16
+                                            ("large_ffn1", 12000, 4096, 1024, 1),       # gemm_p1w_kernel<256, GELU>
+                                            ("narrow", 40000, 512, 1536, 0)])           # 2 columns of tiles: fewer than a panel is wide
+def test_persistent_gemm_tile_walk_is_a_permutation(name, M, N, K, act):
+    """Round 6 (csrc/common.h, tile_walk; svt_debug_set key 34): the persistent 16-bit GEMM kernels map logical tile indices to (tile_m, tile_n)
+    either n fastest (0) or in panels of pm tile rows walked column by column.  The map must be a permutation of the tiles for EVERY pm --
+    a tile computed twice or never would leave NaN-poisoned or stale rows -- and a tile's arithmetic does not depend on who computes it:
+    the outputs are bit-identical to the n-fastest walk for panel heights that divide the tile rows, that do not, and that exceed them."""
+    lib = _lib.load()
+    outs = {}
+    try:
+        for pm in (0, 3, 5, 8, 16, 64):
+            lib.svt_debug_set(34, pm)
+            C, ref = run_gemm(1, M, N, K, None, act, 0, False, seed=5)
+            assert torch.isfinite(C).all(), (name, pm)
+            outs[pm] = C
+    finally:
+        lib.svt_debug_set(34, -1)
+    err = (outs[0] - ref).abs().max().item()
+    assert err < 0.05, (name, err)
+    for pm, C in outs.items():
+        assert torch.equal(C, outs[0]), (name, pm, (C - outs[0]).abs().max().item())
