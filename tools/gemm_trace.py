@@ -109,7 +109,10 @@ def main():
                     "launches, two slots each")
     ap.add_argument("--p1w", action="store_true", help="trace gemm_p1w_kernel (svt_debug_set key 29 = 2) instead of gemm_pps_kernel; adds the "
                     "cycles its waves spend at the slab barriers")
+    ap.add_argument("--set", action="append", default=[], help="key=value for svt_debug_set (repeatable), e.g. --set 37=128: persistent launches of 128 workgroups")
     a = ap.parse_args()
+    for kv in a.set:
+        _lib.load().svt_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     if a.x3_slots:
         return x3_slots(a)
     if a.p1w:
