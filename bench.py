@@ -12,7 +12,7 @@ fixed, ranks own disjoint clips.  Prints ONE JSON line on rank 
 
 The timed loop is ``svt_speechbrain_amd.distributed.run_sharded`` (the same function the 2-rank gloo test runs on CPU):
 W warm-up steps, barrier + device sync, EXACTLY K steps, device sync + barrier, MAX over ranks.  Successive steps are
-issued round-robin on two HIP streams (--streams, each with its own encoder object, workspace and preallocated gather
+issued round-robin on two HIP streams (at N = 1 each lane REPLAYS its step from a hipGraph captured after the warm-up: --no-graph for eager launches) (--streams, each with its own encoder object, workspace and preallocated gather
 buffers): every step still computes its whole batch, but the HBM-bound kernels of one step overlap the MFMA-bound
 kernels of the next.
 
@@ -283,10 +283,13 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="issue successive steps round-robin on this many HIP streams (each with its own encoder "
                     "object and workspace), so one step's HBM-bound kernels (LayerNorm, conv0, norms) run under the next step's MFMA-bound "
                     "ones: measured +5 %% with 2, less with 3.  The roofline leg always runs on one stream.")
-    ap.add_argument("--graph", action="store_true", help="capture each lane's step (one svt_encoder_forward_head call: ~130-190 kernel nodes) into a "
-                    "hipGraph after the warm-up and REPLAY it in the timed region (include/svt_mi355.h: forward calls neither synchronise nor "
-                    "allocate; tests/test_gpu_graph.py).  config.launch reports it.  Measured: the one-utterance forward is bound by its kernels, "
-                    "not by launch gaps (kernel time 0.91 of 0.95 ms), so the default stays eager")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay each lane's step (one svt_encoder_forward_head call: ~190 kernel nodes, no memset / memcpy nodes) from a hipGraph "
+                    "captured after the warm-up (include/svt_mi355.h: forward calls neither synchronise nor allocate; tests/test_gpu_graph.py).  "
+                    "DEFAULT for N = 1 (round 6: C2 -0.8...-2.3 %, the one-utterance step 0.96 -> 0.92 ms); N > 1 launches eagerly unless this flag is "
+                    "given (the collective stays outside the graph either way).  Before it is used, one replay is compared bit for bit with an "
+                    "eager forward; a capture that fails or differs falls back to eager launches and config.launch says so")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every step eagerly (the mode of rounds 1-5)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of cpu_baseline.by_procs
     args = ap.parse_args()
     if args.cpu_worker:
@@ -374,30 +377,48 @@ def main():
     fwds = [make_forward(i) for i in range(ns)]
     fwds_eager = fwds                               # the roofline leg's HIP events live in eager launches
     lanes = [(lambda s=s: torch.cuda.stream(s)) for s in streams] if ns > 1 else [None]
-    if args.graph:
-        if args.h2d or args.separate_tail or world > 1:
-            raise SystemExit("[bench] --graph captures the fused single-rank step only (no --h2d / --separate-tail / N > 1)")
-        graphs, static_out = [], []
-        for i in range(ns):
-            cap = torch.cuda.Stream()
-            cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
+    use_graph = args.graph if args.graph is not None else (world == 1 and not args.h2d and not args.separate_tail)
+    launch_mode = "eager"
+    if use_graph and (args.h2d or args.separate_tail):
+        raise SystemExit("[bench] --graph captures the fused step with resident inputs only (no --h2d / --separate-tail)")
+    if use_graph:
+        try:
+            graphs, static_out = [], []
+            for i in range(ns):
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    for _ in range(2):
+                        want = fwds[i]()                    # uploads, workspace and kernel attributes exist before the capture
+                    want = encs[i].forward_head(wav, head, frames=frames_l[i]).clone()
+                    want_frames = frames_l[i].clone()
+                torch.cuda.current_stream().wait_stream(cap)
+                torch.cuda.synchronize()
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    out_i = encs[i].forward_head(wav, head, frames=frames_l[i])
+                # the replay must BE the eager step: two replays (the second one is where a mis-ordered node shows), bit for bit
                 for _ in range(2):
-                    fwds[i]()                       # uploads, workspace and kernel attributes exist before the capture
-            torch.cuda.current_stream().wait_stream(cap)
-            torch.cuda.synchronize()
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
-                static_out.append(encs[i].forward_head(wav, head, frames=frames_l[i]))
-            graphs.append(g_)
+                    out_i.zero_(); frames_l[i].zero_()
+                    g_.replay()
+                torch.cuda.synchronize()
+                if not (torch.equal(out_i, want) and torch.equal(frames_l[i], want_frames)):
+                    raise RuntimeError("a replayed step differs from the eager step")
+                graphs.append(g_)
+                static_out.append(out_i)
 
-        def make_replay(i):
-            def fwd():
-                graphs[i].replay()                  # on the lane's stream (run_sharded issues it inside the lane's context)
-                return frames_l[i] if gather_frames else static_out[i]
-            return fwd
+            def make_replay(i):
+                def fwd():
+                    graphs[i].replay()                  # on the lane's stream (run_sharded issues it inside the lane's context)
+                    return frames_l[i] if gather_frames else static_out[i]
+                return fwd
 
-        fwds = [make_replay(i) for i in range(ns)]
+            fwds = [make_replay(i) for i in range(ns)]
+            launch_mode = "hipGraph replay (one captured svt_encoder_forward_head per lane, checked bit for bit against the eager step)"
+        except Exception as ex:   # noqa: BLE001 -- never lose the measurement to the launch mechanism
+            fwds = fwds_eager
+            launch_mode = f"eager (hipGraph capture unavailable: {type(ex).__name__}: {ex})"
+            print(f"[bench] {launch_mode}", file=sys.stderr)
 
     def run(steps, warmup, n_lanes=ns):
         return D.run_sharded(fwds[:n_lanes], n_total, rank, world, steps, warmup, dev, lanes=lanes[:n_lanes],
@@ -700,7 +721,7 @@ def main():
                                    f"{B} x {args.seconds:g} s @16 kHz mono clips per GPU",
                        "global_batch": n_total, "per_gpu_batch": B, "samples_per_clip": L, "frames_per_clip": T,
                        "gflop_per_clip": round(flops_clip / 1e9, 2), "parallelism": f"clips sharded over {world} rank(s)",
-                       "launch": "hipGraph replay (one captured svt_encoder_forward_head per lane)" if args.graph else "eager", "streams": ns,
+                       "launch": launch_mode, "streams": ns,
                        "inputs": "pinned host memory, copied every step (diagnostic)" if args.h2d else "resident in HBM",
                        "end_to_end_mfma_frac": round(clips_per_s / world * flops_clip / (peak * 1e12), 4)},
             # ranks as torch.distributed reports them after init, what each rank gathered per step, per-rank rates

@@ -76,3 +76,29 @@ def test_plain_launch_starts_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["verified"] is True and j["config"]["global_batch"] == 4
     assert "launching 2 ranks" in r.stderr
+
+
+def test_two_ranks_with_the_step_replayed_from_a_hip_graph():
+    """`--graph` at N > 1 (opt-in; the default there is eager launches): every rank captures its lane's forward, replays it, and the
+    collective stays outside the graph on the lane's stream; the gathered rows still equal a local recomputation of every shard."""
+    j = launch(29561, "--graph")
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["verified"] is True
+    assert j["config"]["launch"].startswith("hipGraph replay"), j["config"]["launch"]
+
+
+def test_one_rank_default_replays_a_checked_graph_and_no_graph_launches_eagerly():
+    """N = 1: the default line replays a captured step that was compared bit for bit with the eager step; `--no-graph` is the mode of
+    rounds 1-5.  Both report what they did in config.launch."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SVT_SHARE_GPU", "SVT_DIST_BACKEND"):
+        env.pop(k, None)
+    seen = {}
+    for flag in ((), ("--no-graph",)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--seconds", "2", "--no-cpu-baseline",
+               "--no-extra-legs", *flag]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+        seen[flag] = json.loads(lines[0])
+    assert seen[()]["config"]["launch"].startswith("hipGraph replay") and seen[("--no-graph",)]["config"]["launch"] == "eager"
+    assert seen[()]["verified"] is None and seen[()]["n_gpus"] == 1
