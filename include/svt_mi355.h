@@ -258,7 +258,7 @@ int svt_video_forward(svt_video* v, const float* video_dev, int32_t batch, int32
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 /* the same with a row pitch: out row (b, t) starts at out_dev + (b * t_total + t) * out_ld (out_ld >= embed_dim); zero_left > 0 also zeroes
  * the `zero_left` columns to the LEFT of every row (out_dev - zero_left must be inside the caller's buffer, out_ld >= embed_dim +
- * zero_left): with out_dev = feats + E, out_ld = 2 E, zero_left = E this writes AV-HuBERT's concat fusion input
+ * zero_left; zero_left and out_ld multiples of 4, out_dev - zero_left 16-byte aligned): with out_dev = feats + E, out_ld = 2 E, zero_left = E this writes AV-HuBERT's concat fusion input
  * cat([zeros (absent audio), video], -1) in place (N20EMv2/video_only/hubert.py:700-712) */
 int svt_video_forward_ex(svt_video* v, const float* video_dev, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev, int64_t out_ld,
                          int32_t zero_left, void* workspace_dev, size_t workspace_bytes, void* stream);

@@ -2044,7 +2044,7 @@ int svt_video_keep_workspace(svt_video* v, int keep) {
 
 // One body for the three entry points: `video_dev` fp32 (B,1,T,h,w) already normalised, or `roi_dev` uint8 (B,T,h_in,w_in) with the
 // recipe's transform `tf` and crop offsets (dy, dx) fused into the padding pass; out rows with pitch out_ld, `zero_left` columns to the
-// left of every row zeroed (one 2-D memset node: no torch kernel, capturable)
+// left of every row zeroed by a kernel of the library (zero_cols_kernel: no torch kernel, no memset node -- capturable)
 static int video_forward_impl(svt_video* v, const float* video_dev, const unsigned char* roi_dev, int h_in, int w_in, int dy, int dx,
                               const VideoTransform* tf, int32_t batch, int32_t t, int32_t h, int32_t w, float* out_dev, int64_t out_ld,
                               int32_t zero_left, void* workspace_dev, size_t workspace_bytes, void* stream) {
