@@ -52,7 +52,8 @@ def test_no_split_vector_loads(lib):
 def test_vmem_instructions_beside_hand_counted_waits(lib):
     """every kernel with hand-written `s_waitcnt vmcnt(N)` is held to the committed table of its VMEM
     instructions and counted waits (tools/isa_vmem_table.py: written when the GPU suite, the soak and the determinism stress were green on
-    this code) -- a spill, a split / widened / duplicated load or a wait the compiler added or dropped changes the table.  Beyond the
+    this code) -- a spill, a split / widened / duplicated load, a wait the compiler added or dropped, or a load moved ACROSS a counted wait
+    (the table holds a digest of the VMEM instructions between consecutive counted waits, in program order) changes the table.  Beyond the
     table: no scratch traffic at all in these kernels, and the LDS-DMA GEMM stream issues nothing but 16-byte requests, 16-byte
     bias loads and 8- / 16-byte row stores."""
     import json

@@ -44,7 +44,11 @@ def disassemble(lib_path):
 
 
 def table_of(lib_path):
-    """{mangled kernel name: {"vmem": {mnemonic: count}, "waits": {"N": count}}} for the hand-counted families."""
+    """{mangled kernel name: {"vmem": {mnemonic: count}, "waits": {"N": count}, "order": sha1, "order_len": n}} for the hand-counted
+    families.  "order" is a digest of the kernel's VMEM instructions and counted waits IN PROGRAM ORDER -- for every `s_waitcnt vmcnt(N)`
+    the pair (N, the loads / stores issued since the previous counted wait, by mnemonic) -- so a load hoisted or sunk across a wait
+    changes it even when the totals stay the same."""
+    import hashlib
     out = collections.OrderedDict()
     for dis in disassemble(lib_path):
         cur = None
@@ -54,19 +58,26 @@ def table_of(lib_path):
                 name = m.group(1)
                 cur = None
                 if any(f in name for f in FAMILIES):
-                    cur = out.setdefault(name, {"vmem": collections.Counter(), "waits": collections.Counter()})
+                    cur = out.setdefault(name, {"vmem": collections.Counter(), "waits": collections.Counter(), "seq": [], "since": []})
                 continue
             if cur is None:
                 continue
             m = VMEM.match(line.split("//")[0])
             if m:
                 cur["vmem"][m.group(1)] += 1
+                cur["since"].append(m.group(1))
                 continue
             m = re.search(r"s_waitcnt[^/]*vmcnt\((\d+)\)", line)
             if m:
                 cur["waits"][m.group(1)] += 1
-    return {k: {"vmem": dict(sorted(v["vmem"].items())), "waits": dict(sorted(v["waits"].items(), key=lambda kv: int(kv[0])))}
-            for k, v in sorted(out.items())}
+                cur["seq"].append((int(m.group(1)), tuple(cur["since"])))
+                cur["since"] = []
+    res = {}
+    for k, v in sorted(out.items()):
+        v["seq"].append((-1, tuple(v["since"])))       # what is issued behind the last counted wait
+        res[k] = {"vmem": dict(sorted(v["vmem"].items())), "waits": dict(sorted(v["waits"].items(), key=lambda kv: int(kv[0]))),
+                  "order": hashlib.sha1(repr(v["seq"]).encode()).hexdigest()[:16], "order_len": len(v["seq"])}
+    return res
 
 
 def main():
